@@ -1,0 +1,290 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (run in the build container only).
+
+    python -m oracle.gen_golden
+
+Imports the reference's own modules from /root/reference/code through
+oracle/_refshim.py (CPU, ``.cuda()`` no-op) and records inputs + outputs as small
+fixtures.  Weights are NOT stored: both sides rebuild them with
+oracle.unet_ref.seeded_state(seed).  The fixtures are data; no reference source
+text is written anywhere.  /root/reference does not exist on the GPU box -- only
+the committed .npz files travel.  torch version used: see meta['torch'].
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import _refshim  # noqa: E402
+
+_refshim.install()
+
+from oracle.unet_ref import seeded_state  # noqa: E402
+from fedicra_amd.synth import phantom_batch  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def checksum(t) -> np.ndarray:
+    """[sum, abs-sum, L2, 16 samples at fixed strided positions] as float64."""
+    a = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, 16).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[idx]])
+
+
+def state_checksums(model, prefix=""):
+    return {prefix + k: checksum(v.double()) for k, v in model.state_dict().items()}
+
+
+def ref_pcs_extra(model):
+    return {f"encoder.pcs_list.{i}.{k}": v for i, p in enumerate(model.encoder.pcs_list)
+            for k, v in p.state_dict().items()}
+
+
+def save(name, **arrs):
+    arrs["meta_torch"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in list(arrs.items())[:6]}, "...")
+
+
+def g2_unet():
+    from networks.unet import UNet
+    img, weak, dense = phantom_batch(4, 64, 1, 2, cid=0)
+    x = torch.from_numpy(img).unsqueeze(1)
+    m = UNet(1, 2)
+    seeded_state(m, 2022)
+    m.eval()
+    with torch.no_grad():
+        o = m(x)
+    d = {"x": img, "eval_logits": o[0].numpy()}
+    for i, f in enumerate(o[1]):
+        d[f"eval_feat{i}_ck"] = checksum(f)
+    for i in range(2, 6):
+        d[f"eval_de{i-1}_ck"] = checksum(o[i])
+    m.train()
+    torch.manual_seed(7)
+    o = m(x)
+    d["train_logits_seed7"] = o[0].detach().numpy()
+    for k, v in state_checksums(m, "after_train_fwd/").items():
+        if "running" in k or "num_batches" in k:
+            d[k] = v
+    # 3-channel / 3-class variant (ODOC-like), eval only
+    img3, _, _ = phantom_batch(2, 64, 3, 3, cid=1)
+    m3 = UNet(3, 3)
+    seeded_state(m3, 2023)
+    m3.eval()
+    with torch.no_grad():
+        d["x3"] = img3
+        d["eval_logits3"] = m3(torch.from_numpy(img3))[0].numpy()
+    save("g2_unet_fwd.npz", **d)
+
+
+def g2_unet_lc():
+    from networks.unet import UNet_LC, UNet_LC_MultiHead
+    img, _, _ = phantom_batch(4, 64, 1, 2, cid=3)
+    x = torch.from_numpy(img).unsqueeze(1)
+    m = UNet_LC(1, 2, 1, 8, 8, 3)
+    seeded_state(m, 2022, extra=ref_pcs_extra(m))
+    d = {"x": img}
+    m.eval()
+    with torch.no_grad():
+        for e in (None, 0, 5):
+            o = m(x, e)
+            d[f"eval_logits_e{e}"] = o[0].numpy()
+            d[f"eval_hmap_e{e}"] = o[6][-1].numpy()
+            d[f"eval_aux_e{e}"] = o[7].numpy()
+            d[f"eval_feat4_ck_e{e}"] = checksum(o[1][4])
+    m.train()
+    torch.manual_seed(11)
+    o = m(x)
+    d["train_logits_seed11"] = o[0].detach().numpy()
+    d["train_hmap_seed11"] = o[6][-1].detach().numpy()
+    d["train_aux_seed11"] = o[7].detach().numpy()
+    mh = UNet_LC_MultiHead(1, 2, 1, 8, 8, 2)
+    seeded_state(mh, 2024, extra=ref_pcs_extra(mh))
+    mh.eval()
+    with torch.no_grad():
+        o = mh(x)
+    d["mh_eval_logits"] = o[0].numpy()
+    for i in (7, 8, 9):
+        d[f"mh_eval_aux{i-6}_ck"] = checksum(o[i])
+    save("g2_unet_lc_fwd.npz", **d)
+
+
+def g3_losses():
+    from utils.losses import pDLoss, DiceLoss
+    rng = np.random.default_rng(33)
+    d = {}
+    for C in (2, 3):
+        logits = torch.tensor(rng.normal(0, 2, (4, C, 64, 64)).astype(np.float32), requires_grad=True)
+        lab = rng.integers(0, C, (4, 64, 64)).astype(np.uint8)
+        lab[rng.random(lab.shape) < 0.9] = C
+        lab_t = torch.from_numpy(lab)
+        ce = torch.nn.CrossEntropyLoss(ignore_index=C)(logits, lab_t.long())
+        (g_ce,) = torch.autograd.grad(ce, logits)
+        probs = torch.softmax(logits.detach(), 1).requires_grad_(True)
+        pd = pDLoss(C, ignore_index=C)(probs, lab_t.unsqueeze(1))
+        (g_pd,) = torch.autograd.grad(pd, probs)
+        dense = torch.from_numpy(rng.integers(0, C, (4, 1, 64, 64)).astype(np.uint8))
+        probs2 = torch.softmax(logits.detach(), 1).requires_grad_(True)
+        dl = DiceLoss(C)(probs2, dense)
+        (g_dl,) = torch.autograd.grad(dl, probs2)
+        d.update({f"logits{C}": logits.detach().numpy(), f"labels{C}": lab, f"dense{C}": dense.numpy(),
+                  f"ce{C}": np.float64(ce.item()), f"ce_grad{C}": g_ce.numpy(),
+                  f"pdice{C}": np.float64(pd.item()), f"pdice_grad{C}": g_pd.numpy(),
+                  f"dice{C}": np.float64(dl.item()), f"dice_grad{C}": g_dl.numpy()})
+    # all-ignored edge case: CE is nan (0/0) in torch
+    logits = torch.zeros(1, 2, 8, 8)
+    lab = torch.full((1, 8, 8), 2, dtype=torch.long)
+    d["ce_all_ignored_isnan"] = np.array(bool(torch.isnan(torch.nn.CrossEntropyLoss(ignore_index=2)(logits, lab))))
+    save("g3_losses.npz", **d)
+
+
+def _args(**kw):
+    a = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=0, min_num_clients=1, num_classes=2,
+                           img_class="faz", base_lr=0.01, max_iterations=30000, iters=5, rep_iters=3, alpha=0.5,
+                           snapshot_path="/tmp")
+    a.__dict__.update(kw)
+    return a
+
+
+def _loader(n_batches, B, S, cid, in_chns=1, ncls=2):
+    out = []
+    for i in range(n_batches):
+        img, weak, _ = phantom_batch(B, S, in_chns, ncls, cid=cid, index=i, labeled_frac=0.1)
+        out.append({"image": torch.from_numpy(img), "label": torch.from_numpy(weak)})
+    return out
+
+
+def g4_train():
+    """The reference's own MyClient._train (flower_pCE_2D.py:51-181), FedAvg, 'unet'."""
+    import flower_pCE_2D as ref
+    import flower_common as fc
+    logs = []
+    ref.log = lambda lvl, msg, *a: logs.append(msg)
+    args = _args()
+    loader = _loader(3, 4, 64, cid=0)
+    net = ref.net_factory(args, net_type="unet", in_chns=1, class_num=2)
+    seeded_state(net, 2022)
+    model = fc.MyModel(args, net, loader, loader)
+    client = ref.MyClient(args, model, loader, loader)
+    torch.manual_seed(2022)
+    cfg = {"iter_global": 5, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
+    last, metrics = client._train(cfg)
+    losses = [float(m.split("loss : ")[1].split(",")[0]) for m in logs if "loss :" in m]
+    d = {"losses_6dp": np.array(losses), "last_loss": np.float64(last), "lr_after": np.float64(client.current_lr)}
+    d.update(state_checksums(net, "state/"))
+    d["out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+    d["in_conv0_weight"] = net.state_dict()["encoder.in_conv.conv_conv.0.weight"].numpy().copy()
+    # second round: fresh AdamW, carried lr / current_iter (quirk 7)
+    logs.clear()
+    cfg["iters"] = 2
+    args.iters = 2
+    last2, _ = client._train(cfg)
+    d["losses_round2_6dp"] = np.array([float(m.split("loss : ")[1].split(",")[0]) for m in logs if "loss :" in m])
+    d["last_loss_round2"] = np.float64(last2)
+    d.update(state_checksums(net, "state_r2/"))
+    save("g4_train_unet.npz", **d)
+
+
+def g5_fedicra_train():
+    """Reference _train under FedICRA with 'unet_lc'.  As shipped, flower_pCE_2D.py:117-118
+    unpacks the 8-element UNet_LC return into 7 names -> ValueError (recorded).  The vector is
+    then produced with a wrapper *outside* the reference that truncates the return list to 7
+    entries, which makes the reference's own lines 84-157 executable unchanged."""
+    import flower_pCE_2D as ref
+    import flower_common as fc
+    logs = []
+    ref.log = lambda lvl, msg, *a: logs.append(msg)
+    K, cid = 3, 1
+    args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K, iters=5, rep_iters=2, alpha=1.0)
+    loader = _loader(2, 4, 64, cid=cid)
+    net = ref.net_factory(args, net_type="unet_lc", in_chns=1, class_num=2)
+    seeded_state(net, 2022, extra=ref_pcs_extra(net))
+
+    class AsShipped(fc.MyModel):
+        def forward(self, x, emb_idx=None):
+            return self.model(x, emb_idx)
+
+    class Repaired(fc.MyModel):
+        def forward(self, x, emb_idx=None):
+            return self.model(x, emb_idx)[:7]
+
+    broken = False
+    try:
+        c0 = ref.MyClient(args, AsShipped(args, net, loader, loader), loader, loader)
+        c0._train({"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    except ValueError:
+        broken = True
+    seeded_state(net, 2022, extra=ref_pcs_extra(net))
+    logs.clear()
+    client = ref.MyClient(args, Repaired(args, net, loader, loader), loader, loader)
+    torch.manual_seed(2022)
+    last, metrics = client._train({"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    d = {"as_shipped_raises_valueerror": np.array(broken),
+         "losses_6dp": np.array([float(m.split("loss : ")[1].split(",")[0]) for m in logs if "loss :" in m]),
+         "loss_ce_6dp": np.array([float(m.split("loss_ce: ")[1]) for m in logs if "loss :" in m]),
+         "last_loss": np.float64(last), "loss_lc_last": np.float64(metrics[f"client_{cid}_loss_lc"])}
+    d.update(state_checksums(net, "state/"))
+    d["out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+    save("g5_fedicra_train.npz", **d)
+
+
+def g7_ala():
+    """The reference's own MyModel.set_weights, FedICRA branch (flower_common.py:494-624)."""
+    import flower_common as fc
+    K, cid = 3, 1
+    args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K)
+    loader = _loader(3, 4, 64, cid=cid)
+    import flower_pCE_2D as ref
+    d = {}
+    for mode in ("eval", "train"):
+        net = ref.net_factory(args, net_type="unet_lc", in_chns=1, class_num=2)
+        seeded_state(net, 100, extra=ref_pcs_extra(net))            # "old local"
+        donor = ref.net_factory(args, net_type="unet_lc", in_chns=1, class_num=2)
+        seeded_state(donor, 200)                                    # "global"
+        glob = [v.numpy().copy() for v in donor.state_dict().values()]
+        model = fc.MyModel(args, net, loader, loader)
+        getattr(model, mode)()
+        # (a) iter_global <= 50 -> plain load
+        model.set_weights(glob, {"iter_global": 50})
+        d[f"{mode}/skip50_out_conv_ck"] = checksum(net.state_dict()["decoder.out_conv.weight"])
+        assert model.start_phase is True
+        # (b) first personalised call: converge loop
+        seeded_state(net, 100, extra=ref_pcs_extra(net))
+        torch.manual_seed(5)
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            model.set_weights(glob, {"iter_global": 60})
+        epochs1 = buf.getvalue().count("ALA epochs") - 1            # final line printed twice on convergence
+        d[f"{mode}/first_epochs"] = np.array(epochs1)
+        d.update(state_checksums(net, f"{mode}/first/"))
+        d[f"{mode}/first_out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+        d[f"{mode}/first_mix_ck"] = np.stack([checksum(w) for w in model.fedaa_weights])
+        # (c) second call with a different global: exactly one epoch
+        seeded_state(donor, 300)
+        glob2 = [v.numpy().copy() for v in donor.state_dict().values()]
+        torch.manual_seed(6)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.set_weights(glob2, {"iter_global": 70})
+        d.update(state_checksums(net, f"{mode}/second/"))
+        d[f"{mode}/second_mix_ck"] = np.stack([checksum(w) for w in model.fedaa_weights])
+        # (d) same global again -> early-out on sum(first param diff)==0: model == global entirely
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.set_weights(glob2, {"iter_global": 80})
+        d[f"{mode}/third_out_conv_ck"] = checksum(net.state_dict()["decoder.out_conv.weight"])
+    save("g7_ala.npz", **d)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,27 @@
+"""Shared test helpers (checksums identical to oracle/gen_golden.py)."""
+import numpy as np
+import torch
+
+
+def checksum(t) -> np.ndarray:
+    a = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, 16).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[idx]])
+
+
+def assert_ck(t, ck, rtol=1e-6, atol=1e-7, what=""):
+    got = checksum(t.double() if torch.is_tensor(t) else t)
+    scale = max(1.0, abs(ck[1]))            # abs-sum sets the scale for the two sum entries
+    assert abs(got[0] - ck[0]) <= rtol * scale + atol, (what, "sum", got[0], ck[0])
+    assert abs(got[1] - ck[1]) <= rtol * scale + atol, (what, "abssum", got[1], ck[1])
+    assert abs(got[2] - ck[2]) <= rtol * max(1.0, ck[2]) + atol, (what, "l2", got[2], ck[2])
+    np.testing.assert_allclose(got[3:], ck[3:], rtol=rtol * 100, atol=atol * 100, err_msg=what)
+
+
+def loader(n_batches, B, S, cid, in_chns=1, ncls=2, device="cpu"):
+    from fedicra_amd.synth import phantom_batch
+    out = []
+    for i in range(n_batches):
+        img, weak, _ = phantom_batch(B, S, in_chns, ncls, cid=cid, index=i, labeled_frac=0.1)
+        out.append({"image": torch.from_numpy(img).to(device), "label": torch.from_numpy(weak).to(device)})
+    return out
