@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- images/s of the FedICRA local-training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: FedAvg clients, 2D U-Net(in=1, classes=2), 12x1x256x256 synthetic
+slices, one client per GPU.  A *step* is one local training iteration (zero-grad, forward, pCE loss,
+backward, AdamW, poly-LR) on one batch of 12 images whose data is already resident in HBM; every
+``--round-iters`` (10, the reference default, flower_runner.py:38-39) steps form a federated round that ends
+with the weighted parameter aggregation (RCCL all-reduce over xGMI when N > 1) and the load of the global
+weights -- all inside the timed region.  value = images/s summed over all clients (weak scaling: per-GPU
+work is fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line (see DESIGN.md "measurement"):
+  roofline     -- the dominant kernel (largest share of GPU time) priced against its roofline; durations
+                  measured live with HIP events around each launch in a separate, eager, instrumented pass.
+  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample
+                  of the same workload (rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # TFLOP/s dense (guide: 2.5 PF bf16, 157.3 TF fp32-input MFMA)
+
+# conv-only algorithmic FLOPs per image, UNet(1,2): F_train = 3*F_fwd - first-layer dgrad
+F_FWD_256 = 5.8615e9
+
+
+def f_train(size, in_chns=1):
+    f_fwd = F_FWD_256 * (size / 256.0) ** 2
+    return 3.0 * f_fwd - 2.0 * in_chns * 16 * 9 * size * size
+
+
+def make_args(a, cid, nclients):
+    return argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=cid, min_num_clients=nclients,
+                              num_classes=2, img_class="faz", base_lr=0.01, max_iterations=30000,
+                              iters=a.round_iters, rep_iters=3, alpha=0.5, snapshot_path=None,
+                              use_graph=not a.no_graph)
+
+
+def device_loader(n_batches, batch, size, cid, device):
+    from fedicra_amd.synth import phantom_batch
+    out = []
+    for i in range(n_batches):
+        img, weak, _ = phantom_batch(batch, size, 1, 2, cid=cid, index=i)
+        out.append({"image": torch.from_numpy(img).to(device), "label": torch.from_numpy(weak).to(device)})
+    return out
+
+
+def cpu_baseline(a):
+    """The oracle's local_train on the host cores: bounded sample of the same workload."""
+    from oracle import fed_ref
+    from oracle.unet_ref import RefUNet
+    from fedicra_amd.synth import phantom_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(2022)
+    m = RefUNet(1, 2)
+    batches = []
+    for i in range(2):
+        img, weak, _ = phantom_batch(a.batch, a.size, 1, 2, cid=0, index=i)
+        batches.append({"image": torch.from_numpy(img), "label": torch.from_numpy(weak)})
+    st = fed_ref.TrainState(0.01)
+    fed_ref.local_train(m, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):
+        fed_ref.local_train(m, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * a.batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training iterations of {a.batch}x1x{a.size}x{a.size} (oracle.fed_ref.local_train, "
+                      f"torch {torch.__version__} CPU fp32) after 1 warm-up"}
+
+
+def roofline_pass(client, a, dtype_name):
+    """Eager, instrumented iterations: HIP events around every C-ABI launch on the launch stream."""
+    from fedicra_amd import _lib as L
+    client.use_graph = False
+    cfg = {"iter_global": 0, "iters": 3, "eval_iters": 10, "batch_size": a.batch, "stage": "fit"}
+    client._train(cfg)                                   # warm the eager path
+    L.profile_begin()
+    client._train(cfg)
+    prof = L.profile_end().summary()
+    total_ms = sum(v["ms"] for v in prof.values())
+    key, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    calls = dom["calls"]
+    avg_ms = dom["ms"] / calls
+    flops, nbytes = dom["flops"] / calls, dom["bytes"] / calls
+    ai = flops / max(nbytes, 1.0)
+    mf_peak = MFMA_PEAK["bf16" if "bfloat16" in key else "f32"]
+    ridge = mf_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if flops > 0 and ai >= ridge:
+        bound, ach, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, mf_peak, "TFLOP/s"
+    else:
+        bound, ach, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    breakdown = {}
+    for k, v in prof.items():
+        b = breakdown.setdefault(k[0], 0.0)
+        breakdown[k[0]] = b + v["ms"]
+    roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+            "traffic": None, "kernel": "/".join(map(str, key)), "avg_us": round(avg_ms * 1e3, 2),
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+            "share_of_gpu_time": round(dom["ms"] / total_ms, 4),
+            "kernel_time_breakdown_ms_per_iter": {k: round(v / 3.0, 4) for k, v in sorted(breakdown.items())}}
+    client.use_graph = not a.no_graph
+    return roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--round-iters", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    from fedicra_amd.comm import WeightedAllReduce, init_process_group_from_env
+    rank, local, world = init_process_group_from_env()
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    assert world == a.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {a.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    from fedicra_amd import _lib, fl
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks import net_factory
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from fedicra_amd.synth import client_num_batches
+    _lib.lib()
+
+    args = make_args(a, rank, world)
+    torch.manual_seed(2022)                              # the reference seeds every process with 2022
+    net = net_factory(args, net_type="unet", in_chns=1, class_num=2)
+    set_compute_dtype(net, a.dtype)
+    n_k = client_num_batches(max(world, 1), a.batch)[rank]
+    loader = device_loader(min(n_k, 8), a.batch, a.size, rank, dev)      # resident in HBM before timing starts
+    model = MyModel(args, net, loader, loader)
+    client = MyClient(args, model, loader, loader)
+    agg = WeightedAllReduce(n_k, device=dev)
+
+    def run_steps(nsteps):
+        """nsteps local iterations in rounds of round_iters, each round closed by the aggregation."""
+        done, agg_ms = 0, []
+        while done < nsteps:
+            it = min(a.round_iters, nsteps - done)
+            args.iters = it
+            client._train({"iter_global": done, "iters": it, "eval_iters": 10 * it, "batch_size": a.batch,
+                           "stage": "fit"})
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            agg.start(model.get_device_weights())        # side stream: pre-scale, all-reduce, divide
+            client.sampled_batches = list(loader)        # overlapped: next round's batch staging (epoch list)
+            glob = agg.finish()
+            model.set_weights(glob, {"iter_global": done})   # FedAvg: plain load of the global state
+            e1.record()
+            agg_ms.append((e0, e1))
+            done += it
+        return agg_ms
+
+    run_steps(a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    agg_events = run_steps(a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    agg_ms = sum(e0.elapsed_time(e1) for e0, e1 in agg_events) / max(len(agg_events), 1)
+
+    if rank == 0:
+        total_images = a.steps * a.batch * world
+        value = total_images / elapsed
+        ft = f_train(a.size)
+        conv_tflops_per_gpu = value / world * ft / 1e12
+        line = {
+            "metric": "images/sec (2D U-Net local training, all clients) ; ms/aggregation round in config",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {world} client(s) FedAvg, 2D U-Net(1,2) "
+                                   f"{a.batch}x1x{a.size}x{a.size}, 1 MI355X per client, round = {a.round_iters} "
+                                   f"local iterations + weighted all-reduce",
+                       "images_per_sec_per_client": round(value / world, 2),
+                       "ms_per_aggregation_round": round(agg_ms, 4),
+                       "conv_tflops_per_gpu": round(conv_tflops_per_gpu, 2),
+                       "frac_of_bf16_mfma_peak": round(conv_tflops_per_gpu / MFMA_PEAK["bf16"], 4),
+                       "hipgraph": not a.no_graph, "parallelism": f"fed-dp{world}"},
+        }
+        if not a.no_roofline:
+            try:
+                line["roofline"] = roofline_pass(client, a, a.dtype)
+            except Exception as e:  # noqa: BLE001  (never lose the headline number to the instrumented pass)
+                line["roofline"] = {"error": repr(e)}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,332 @@
+"""ctypes loader for libfedicra_hip.so (the C ABI declared in include/fedicra_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing this module raises at
+import time of any op (``lib()``), and every wrapper checks the return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfedicra_hip.so")
+
+FI_F32, FI_BF16 = 0, 1
+DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_pack_weights", "fi_bn_finalize", "fi_bn_act_fwd",
+    "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
+    "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_dice_counts", "fi_adamw_hyper",
+    "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
+    "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw",
+]
+
+
+class FiConv(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
+                ("c0", C.c_int), ("c1", C.c_int), ("co0", C.c_int), ("co1", C.c_int), ("accumulate0", C.c_int),
+                ("accumulate1", C.c_int), ("y_f32", C.c_int)]
+
+
+class FiBnAct(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("pixels", C.c_long), ("C", C.c_int), ("hw", C.c_int), ("slope", C.c_float),
+                ("drop_mode", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64), ("mask", C.c_void_p),
+                ("seed_offset", C.c_void_p)]
+
+
+class FiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C fedicra_amd/csrc).  fedicra_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise FiError(f"{what} failed with code {rc}" + (" (hipError_t)" if rc > 0 else " (FI_ERR_*)"))
+
+
+def dt(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return FI_F32
+    if t == torch.bfloat16:
+        return FI_BF16
+    raise FiError(f"unsupported dtype {t}")
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise FiError("fedicra_amd ops need device tensors (no CPU path)")
+    return t
+
+
+# ------------------------------------------------------------------ per-kernel timing (bench.py roofline leg)
+class KernelProfile:
+    """HIP-event timing of individual C-ABI launches on the stream they are issued on.  Only active
+    between profile_begin()/profile_end(); zero cost otherwise.  Each record carries the launch's
+    ALGORITHMIC flops and bytes (DESIGN.md 'roofline accounting') so that bench.py can price it."""
+
+    def __init__(self):
+        self.rows = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, nbytes, e0, e1 in self.rows:
+            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = KernelProfile()
+    return _prof
+
+
+def profile_end():
+    global _prof
+    p, _prof = _prof, None
+    return p
+
+
+class _Timed:
+    __slots__ = ("key", "flops", "bytes", "e0")
+
+    def __init__(self, key, flops, nbytes):
+        self.key, self.flops, self.bytes = key, flops, nbytes
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *a):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        _prof.rows.append((self.key, self.flops, self.bytes, self.e0, e1))
+
+
+class _NoTime:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *a):
+        pass
+
+
+_NOTIME = _NoTime()
+
+
+def _timed(kind, shape_key, flops, nbytes):
+    if _prof is None:
+        return _NOTIME
+    return _Timed((kind,) + tuple(shape_key), float(flops), float(nbytes))
+
+
+def _esz(t):
+    return t.element_size()
+
+
+# ------------------------------------------------------------------ thin wrappers
+def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False, y_f32=False, tag="conv_fwd"):
+    """x*: [N,H,W,C] dense NHWC; w: packed [Cout][k*k][Cin] (any shape, dense) in x0.dtype."""
+    _dev(x0)
+    N, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    co0 = y0.shape[3]
+    co1 = 0 if y1 is None else y1.shape[3]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, co0, co1, int(acc0), int(acc1), int(y_f32))
+    cin, cout, px = c0 + c1, co0 + co1, N * H * W
+    with _timed(tag, (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
+                px * cin * _esz(x0) + px * cout * _esz(y0) + cin * cout * ksize * ksize * _esz(x0)):
+        _chk(lib().fi_conv2d_fwd(C.byref(d), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y0), ptr(y1), ptr(stats),
+                                 stream()), "fi_conv2d_fwd")
+
+
+def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize):
+    _dev(x0)
+    N, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[3], 0, 0, 0, 0)
+    cin, cout, px = c0 + c1, dy.shape[3], N * H * W
+    with _timed("conv_wgrad", (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
+                px * cin * _esz(x0) + px * cout * _esz(dy) + cin * cout * ksize * ksize * 4):
+        _chk(lib().fi_conv2d_wgrad(C.byref(d), ptr(x0), ptr(x1), ptr(dy), ptr(dw), ptr(dbias), stream()),
+             "fi_conv2d_wgrad")
+
+
+def pack_weights(src, dst, cout, kk, cin, mode):
+    _chk(lib().fi_pack_weights(ptr(_dev(src)), ptr(dst), cout, kk, cin, mode, dt(dst.dtype), stream()),
+         "fi_pack_weights")
+
+
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training, scale, shift, mean, invstd):
+    _chk(lib().fi_bn_finalize(ptr(stats), C.c_double(count), ptr(_dev(gamma)), ptr(beta), ptr(rmean), ptr(rvar),
+                              ptr(nbt), C.c_float(momentum), C.c_float(eps), int(training), ptr(scale), ptr(shift),
+                              ptr(mean), ptr(invstd), gamma.numel(), stream()), "fi_bn_finalize")
+
+
+def _bnact(y, slope, drop):
+    N, H, W, Cc = y.shape
+    mode, p, seed, mask, soff = drop if drop is not None else (DROP_NONE, 0.0, 0, None, None)
+    return FiBnAct(dt(y.dtype), N * H * W, Cc, H * W, slope, mode, p, seed & 0xFFFFFFFFFFFFFFFF,
+                   None if mask is None else mask.data_ptr(), None if soff is None else soff.data_ptr())
+
+
+def bn_act_fwd(y, scale, shift, z, slope, drop=None):
+    d = _bnact(_dev(y), slope, drop)
+    with _timed("bn_act_fwd", (str(y.dtype)[6:],) + tuple(y.shape), 0, 2 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_act_fwd(C.byref(d), ptr(y), ptr(scale), ptr(shift), ptr(z), stream()), "fi_bn_act_fwd")
+
+
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, sums, slope, drop=None):
+    d = _bnact(_dev(y), slope, drop)
+    with _timed("bn_act_bwd_reduce", (str(y.dtype)[6:],) + tuple(y.shape), 0, 2 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_act_bwd_reduce(C.byref(d), ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                        ptr(sums), stream()), "fi_bn_act_bwd_reduce")
+
+
+def bn_act_bwd_apply(dz, y, scale, shift, mean, invstd, sums, training, dy, dgamma, dbeta, slope, drop=None,
+                     accumulate_param=False):
+    d = _bnact(_dev(y), slope, drop)
+    with _timed("bn_act_bwd_apply", (str(y.dtype)[6:],) + tuple(y.shape), 0, 3 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_act_bwd_apply(C.byref(d), ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                       ptr(sums), int(training), ptr(dy), ptr(dgamma), ptr(dbeta),
+                                       int(accumulate_param), stream()), "fi_bn_act_bwd_apply")
+
+
+def maxpool2_fwd(x, y):
+    N, H, W, Cc = _dev(x).shape
+    with _timed("maxpool_fwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 1.25 * x.numel() * _esz(x)):
+        _chk(lib().fi_maxpool2_fwd(dt(x.dtype), ptr(x), ptr(y), N, H, W, Cc, stream()), "fi_maxpool2_fwd")
+
+
+def maxpool2_bwd(x, dy, dx, accumulate=False):
+    N, H, W, Cc = _dev(x).shape
+    with _timed("maxpool_bwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 2.25 * x.numel() * _esz(x)):
+        _chk(lib().fi_maxpool2_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, int(accumulate), stream()),
+             "fi_maxpool2_bwd")
+
+
+def upsample2x_fwd(x, y):
+    N, h, w, Cc = _dev(x).shape
+    with _timed("upsample_fwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 5 * x.numel() * _esz(x)):
+        _chk(lib().fi_upsample2x_fwd(dt(x.dtype), ptr(x), ptr(y), N, h, w, Cc, stream()), "fi_upsample2x_fwd")
+
+
+def upsample2x_bwd(dy, dx, accumulate=False):
+    N, h, w, Cc = _dev(dx).shape
+    with _timed("upsample_bwd", (str(dx.dtype)[6:],) + tuple(dx.shape), 0, 5 * dx.numel() * _esz(dx)):
+        _chk(lib().fi_upsample2x_bwd(dt(dx.dtype), ptr(dy), ptr(dx), N, h, w, Cc, int(accumulate), stream()),
+             "fi_upsample2x_bwd")
+
+
+def ce_fwd(logits, labels, ignore_index, acc):
+    M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
+    _chk(lib().fi_ce_fwd(ptr(logits), ptr(labels), C.c_long(M), Cc, ignore_index, ptr(acc), stream()), "fi_ce_fwd")
+
+
+def ce_finalize(acc, loss):
+    _chk(lib().fi_ce_finalize(ptr(_dev(acc)), ptr(loss), stream()), "fi_ce_finalize")
+
+
+def ce_bwd(logits, labels, ignore_index, acc, gscale, dlogits):
+    M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
+    _chk(lib().fi_ce_bwd(ptr(logits), ptr(labels), C.c_long(M), Cc, ignore_index, ptr(acc), ptr(gscale), ptr(dlogits),
+                         dt(dlogits.dtype), stream()), "fi_ce_bwd")
+
+
+def dice_counts(logits, gt, counts):
+    M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
+    _chk(lib().fi_dice_counts(ptr(logits), ptr(gt), C.c_long(M), Cc, ptr(counts), stream()), "fi_dice_counts")
+
+
+def adamw_hyper(step, hyper, lr_state, beta1, beta2, wd):
+    _chk(lib().fi_adamw_hyper(ptr(_dev(step)), ptr(hyper), ptr(lr_state), C.c_float(beta1), C.c_float(beta2),
+                              C.c_float(wd), stream()), "fi_adamw_hyper")
+
+
+def lr_poly_advance(it, lr_state, base_lr, max_iter):
+    _chk(lib().fi_lr_poly_advance(ptr(_dev(it)), ptr(lr_state), C.c_double(base_lr), C.c_double(max_iter), stream()),
+         "fi_lr_poly_advance")
+
+
+def adamw_step(p, g, m, v, hyper, beta1, beta2, eps, shadow=None):
+    with _timed("adamw_step", (p.numel(),), 0, 28 * p.numel()):
+        _chk(lib().fi_adamw_step(ptr(_dev(p)), ptr(g), ptr(m), ptr(v), C.c_long(p.numel()), ptr(hyper),
+                                 C.c_float(beta1), C.c_float(beta2), C.c_float(eps), ptr(shadow), stream()),
+             "fi_adamw_step")
+
+
+def scale(x, y, a, divide=False):
+    _chk(lib().fi_scale(ptr(_dev(x)), ptr(y), C.c_long(x.numel()), C.c_float(a), int(divide), stream()), "fi_scale")
+
+
+def axpy(acc, x, a):
+    _chk(lib().fi_axpy(ptr(_dev(acc)), ptr(x), C.c_long(x.numel()), C.c_float(a), stream()), "fi_axpy")
+
+
+def ala_update(w, temp, grad, local, glob, eta):
+    _chk(lib().fi_ala_update(ptr(_dev(w)), ptr(temp), ptr(grad), ptr(local), ptr(glob), C.c_long(w.numel()),
+                             C.c_float(eta), stream()), "fi_ala_update")
+
+
+def global_avgmax(x, avg, mx, amax):
+    N, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_global_avgmax(dt(x.dtype), ptr(x), ptr(avg), ptr(mx), ptr(amax), N, H * W, Cc, stream()),
+         "fi_global_avgmax")
+
+
+def channel_gate_fwd(x, h, y):
+    N, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_channel_gate_fwd(dt(x.dtype), ptr(x), ptr(h), ptr(y), N, H * W, Cc, stream()), "fi_channel_gate_fwd")
+
+
+def channel_gate_bwd(x, dy, h, amax, davg, dmx, dx, dh):
+    N, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_channel_gate_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(h), ptr(amax), ptr(davg), ptr(dmx), ptr(dx),
+                                   ptr(dh), N, H * W, Cc, stream()), "fi_channel_gate_bwd")
+
+
+def cast(src, dst):
+    _chk(lib().fi_cast(ptr(_dev(src)), dt(src.dtype), ptr(dst), dt(dst.dtype), C.c_long(src.numel()), stream()),
+         "fi_cast")
+
+
+def nchw_to_nhwc(src, dst):
+    N, Cc, H, W = _dev(src).shape
+    _chk(lib().fi_nchw_to_nhwc(ptr(src), ptr(dst), dt(dst.dtype), N, Cc, H, W, stream()), "fi_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, dst):
+    N, Cc, H, W = dst.shape
+    _chk(lib().fi_nhwc_to_nchw(ptr(_dev(src)), dt(src.dtype), ptr(dst), N, Cc, H, W, stream()), "fi_nhwc_to_nchw")

@@ -1,0 +1,101 @@
+"""Per-round parameter aggregation as ONE weighted all-reduce over xGMI (RCCL).
+
+Replaces "N x gRPC upload of ~140 np.save blobs -> numpy weighted mean on the server -> N x gRPC
+download" (/root/reference/code/flower_common.py:262 -> flwr FedAvg.aggregate_fit -> aggregate,
+SURVEY.md 8-a16, 8e) with: every rank (= client = GPU) pre-multiplies its flat fp32 state by its
+own n_k = len(trainloader), one ``all_reduce(SUM)`` over the flat buffer, one divide by sum(n_k).
+The arithmetic is flwr's  reduce(add, [w_k * n_k]) / total  up to the summation order RCCL uses.
+The int64 num_batches_tracked counters are reduced separately as int64 (n_k * counter), then
+true-divided and truncated -- the reference's float64 round trip.
+
+The collective runs on a dedicated side HIP stream, fenced with events against the training
+stream, so the next round's batch staging (the reference's epoch pre-materialisation,
+flower_pCE_2D.py:66-70) overlaps with it.  State is 7-10 MB: the ring is latency-bound, so one
+large collective over the whole flat buffer (not one per tensor) is the right shape for xGMI.
+
+``backend='gloo'`` (CPU tensors) is supported for the world_size>1 unit tests on a box without GPUs;
+the device kernels are then replaced by the same torch expressions -- tests only, never the product.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .flower_common import DeviceWeights
+
+
+class WeightedAllReduce:
+    def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.n_k = int(num_examples)
+        if self.world > 1:
+            t = torch.tensor([self.n_k], dtype=torch.int64, device=device if self.on_gpu else "cpu")
+            gathered = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(gathered, t, group=group)        # n_k is constant: exchanged once
+            self.all_n = [int(g.item()) for g in gathered]
+        else:
+            self.all_n = [self.n_k]
+        self.total = sum(self.all_n)
+        self.side = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self._send = None
+        self._cnt = None
+        self._done = None
+
+    # ---------------------------------------------------------------------------------------------
+    def start(self, weights: DeviceWeights):
+        """Enqueue pre-scale + all-reduce + divide on the side stream; returns immediately."""
+        if self._send is None or self._send.shape != weights.state.shape:
+            self._send = torch.empty_like(weights.state)
+            self._cnt = torch.empty_like(weights.counters)
+        if self.on_gpu:
+            from . import _lib as L
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                L.scale(weights.state, self._send, float(self.n_k))
+                torch.mul(weights.counters, self.n_k, out=self._cnt)
+                if self.world > 1:
+                    dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
+                L.scale(self._send, self._send, float(self.total), divide=True)
+                self._done = torch.cuda.Event()
+                self._done.record(self.side)
+        else:   # gloo / CPU test path
+            torch.mul(weights.state, float(self.n_k), out=self._send)
+            torch.mul(weights.counters, self.n_k, out=self._cnt)
+            if self.world > 1:
+                dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
+            self._send.div_(float(self.total))
+
+    def finish(self) -> DeviceWeights:
+        """Fence the training stream behind the collective and return the global weights."""
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_event(self._done)
+        counters = (self._cnt.double() / self.total).to(torch.int64)     # true divide, then truncate
+        return DeviceWeights(self._send, counters)
+
+    def aggregate(self, weights: DeviceWeights) -> DeviceWeights:
+        self.start(weights)
+        return self.finish()
+
+
+def init_process_group_from_env(backend: Optional[str] = None):
+    """One process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 0, 1
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"     # 'nccl' IS RCCL on ROCm
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -1,0 +1,74 @@
+// Shared device helpers for the fedicra_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fedicra_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define FI_WAVE 64
+
+// ---- per-dtype traits: VG = elements per 16-byte global/LDS vector,
+//      KSTEP = contraction depth of one MFMA (16x16x4 f32 / 16x16x32 bf16),
+//      KV = contraction elements each lane feeds per MFMA.
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int VG = 4, KSTEP = 4, KV = 1;
+  typedef float4 vec_t;
+  typedef float frag_t;
+};
+template <> struct DT<bf16_t> {
+  static constexpr int VG = 8, KSTEP = 32, KV = 8;
+  typedef uint4 vec_t;
+  typedef bf16x8 frag_t;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// wave-wide sum via xor shuffles (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// counter-based RNG for dropout: one 32-bit draw per (seed, element index).
+// splitmix64 finaliser -- stateless, so backward regenerates the identical mask.
+__device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep with probability (1-p): threshold on a 32-bit uniform
+__device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t drop_thresh) {
+  return fi_rand32(seed, idx) >= drop_thresh;
+}
+
+static inline int fi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define FI_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)

@@ -1,0 +1,105 @@
+// C-ABI entry points for the convolution kernels: argument checks + tile-shape selection.
+#include "conv_impl.h"
+
+int fi_conv_fwd_f32_k1(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_f32_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_bf16_k1(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_bf16_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_wgrad_f32_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_f32_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_bf16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_bf16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+
+// Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
+// small feature maps fall through to TH = 4 (more, smaller workgroups).
+static int pick_th(int N, int H, int W, long per_tile_mult) {
+  const int cands[3] = {16, 8, 4};
+  for (int i = 0; i < 3; ++i) {
+    const int th = cands[i];
+    if (th > 4 && th / 2 >= H) continue;  // tile would be mostly empty
+    const long blocks = (long)N * fi_cdiv(H, th) * fi_cdiv(W, 16) * per_tile_mult;
+    if (blocks >= 512 || th == 4) return th;
+  }
+  return 4;
+}
+
+extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
+                             void* y0, void* y1, double* stats, void* stream) {
+  if (!d || !x0 || !w || !y0) return FI_ERR_NULL;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
+  if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1 || d->co1 < 0) return FI_ERR_SHAPE;
+  if ((d->c1 > 0 && !x1) || (d->co1 > 0 && !y1)) return FI_ERR_NULL;
+  const int cin = d->c0 + d->c1, cout = d->co0 + d->co1;
+  const bool f32 = d->dtype == FI_F32;
+  int ck;
+  if (f32)
+    ck = cin >= 16 ? 16 : (cin > 4 ? 8 : 4);
+  else
+    ck = cin >= 32 ? 32 : (cin > 8 ? 16 : 8);
+  const int nf = cout > 32 ? 4 : (cout > 16 ? 2 : 1);
+  const int nct = fi_cdiv(cout, nf * 16);
+  const int th = pick_th(d->N, d->H, d->W, nct);
+  ConvArgs a;
+  a.x0 = x0;
+  a.x1 = x1 ? x1 : x0;
+  a.w = w;
+  a.bias = bias;
+  a.y0 = y0;
+  a.y1 = y1 ? y1 : y0;
+  a.stats = stats;
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.co0 = d->co0;
+  a.co1 = d->co1;
+  a.acc0 = d->accumulate0;
+  a.acc1 = d->accumulate1;
+  a.y_f32 = f32 ? 0 : d->y_f32;
+  a.tilesX = fi_cdiv(d->W, 16);
+  a.tilesY = fi_cdiv(d->H, th);
+  a.nct = nct;
+  hipStream_t st = (hipStream_t)stream;
+  if (f32) return d->ksize == 3 ? fi_conv_fwd_f32_k3(th, nf, ck, a, st) : fi_conv_fwd_f32_k1(th, nf, ck, a, st);
+  return d->ksize == 3 ? fi_conv_fwd_bf16_k3(th, nf, ck, a, st) : fi_conv_fwd_bf16_k1(th, nf, ck, a, st);
+}
+
+extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
+                               float* dbias, void* stream) {
+  if (!d || !x0 || !dy || !dw) return FI_ERR_NULL;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
+  if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1) return FI_ERR_SHAPE;
+  if (d->c1 > 0 && !x1) return FI_ERR_NULL;
+  const int cin = d->c0 + d->c1, cout = d->co0;
+  const int nfo = 1, nfi = cin > 16 ? 2 : 1;
+  const int nco = fi_cdiv(cout, nfo * 16), nci = fi_cdiv(cin, nfi * 16);
+  const int th = pick_th(d->N, d->H, d->W, (long)nco * nci);
+  WgradArgs a;
+  a.x0 = x0;
+  a.x1 = x1 ? x1 : x0;
+  a.dy = dy;
+  a.dw = dw;
+  a.dbias = dbias;
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.cout = cout;
+  a.tilesX = fi_cdiv(d->W, 16);
+  a.tilesY = fi_cdiv(d->H, th);
+  a.nco = nco;
+  a.nci = nci;
+  const long ntiles = (long)a.N * a.tilesX * a.tilesY;
+  long sb = (256L * 4) / ((long)nco * nci);  // ~4 workgroups per CU in total
+  if (sb < 1) sb = 1;
+  if (sb > ntiles) sb = ntiles;
+  a.spatialBlocks = (int)sb;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FI_F32)
+    return d->ksize == 3 ? fi_conv_wgrad_f32_k3(th, nfo, nfi, a, st) : fi_conv_wgrad_f32_k1(th, nfo, nfi, a, st);
+  return d->ksize == 3 ? fi_conv_wgrad_bf16_k3(th, nfo, nfi, a, st) : fi_conv_wgrad_bf16_k1(th, nfo, nfi, a, st);
+}

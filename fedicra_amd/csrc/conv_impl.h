@@ -1,0 +1,458 @@
+// Implicit-GEMM 2D convolution for gfx950 (forward / dgrad share one kernel; wgrad is its own).
+//
+// Mapping onto the hardware (DESIGN.md section "conv"):
+//   GEMM view  M = output pixels, N = Cout, K = k*k*Cin.
+//   One 256-thread workgroup (4 waves) owns a TH x 16 pixel tile of one image and a BN = 16*NF
+//   slab of output channels.  Per Cin chunk (CK channels) the (TH+2) x 18 input halo tile and the
+//   [BN][k*k*CK] weight slab are staged ONCE through LDS with 16-byte coalesced NHWC loads; the
+//   k*k taps are then shifted LDS reads, so each activation byte leaves HBM/L2 once per
+//   workgroup.  A wave owns MF = TH/4 rows of the tile; one MFMA "M" fragment is the 16
+//   consecutive pixels of a row.  MFMA: v_mfma_f32_16x16x32_bf16 (bf16) or the exact-fp32
+//   v_mfma_f32_16x16x4_f32; accumulators are fp32 in both.
+//   Epilogue: + bias, optional fp32 store, optional read-modify-write (gradient accumulation),
+//   optional per-channel (sum, sum^2) for training-mode BatchNorm: per-lane partials ->
+//   wave shuffle over the 4 row groups -> LDS over the 4 waves -> one fp64 atomic per channel.
+//   The two-source loader folds torch.cat([skip, up], 1) into the gather; the two-destination
+//   epilogue is its adjoint for dgrad.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const void* x0;
+  const void* x1;
+  const void* w;
+  const float* bias;
+  void* y0;
+  void* y1;
+  double* stats;
+  int N, H, W;
+  int c0, c1, co0, co1;
+  int acc0, acc1, y_f32;
+  int tilesX, tilesY, nct;
+};
+
+// ---------------------------------------------------------------------------------------------
+// staging helpers
+// ---------------------------------------------------------------------------------------------
+// Load VG consecutive input channels [ci, ci+VG) of pixel `pix` (flat n*H*W index) from the
+// two-source concatenation; zero beyond cin.  `vec_ok`: c0 % VG == 0 && c1 % VG == 0.
+template <typename T>
+__device__ __forceinline__ typename DT<T>::vec_t load_cat(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+                                                          int c1, size_t pix, int ci, bool vec_ok) {
+  constexpr int VG = DT<T>::VG;
+  typedef typename DT<T>::vec_t vec_t;
+  const int cin = c0 + c1;
+  if (vec_ok) {
+    if (ci >= cin) {
+      vec_t z;
+      memset(&z, 0, sizeof(z));
+      return z;
+    }
+    const T* src = (ci < c0) ? x0 + pix * c0 + ci : x1 + pix * c1 + (ci - c0);
+    return *reinterpret_cast<const vec_t*>(src);
+  }
+  union {
+    vec_t v;
+    T e[VG];
+  } u;
+#pragma unroll
+  for (int j = 0; j < VG; ++j) {
+    const int c = ci + j;
+    T val = from_f32<T>(0.f);
+    if (c < cin) val = (c < c0) ? x0[pix * c0 + c] : x1[pix * c1 + (c - c0)];
+    u.e[j] = val;
+  }
+  return u.v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KS, int TH, int NF, int CK>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
+  constexpr int CKP = CK + VG;                                  // padded pixel stride in LDS
+  constexpr int KC = KK * CK;                                   // contraction length per chunk
+  constexpr int KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;       // rounded up to whole MFMAs
+  constexpr int WKP = KCP + VG;                                 // padded weight-row stride
+  constexpr int BN = NF * 16;
+  constexpr int MF = TH / 4;
+  constexpr int VPP = CK / VG;                                  // 16-byte vectors per pixel
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);                           // [XH*XW][CKP]
+  T* ws = xs + XH * XW * CKP;                                   // [BN][WKP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
+  int bid = blockIdx.x;
+  const int ct = bid % a.nct;
+  bid /= a.nct;
+  const int tx = bid % a.tilesX;
+  bid /= a.tilesX;
+  const int ty = bid % a.tilesY;
+  const int n = bid / a.tilesY;
+  const int H = a.H, W = a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0);
+  const T* x1 = reinterpret_cast<const T*>(a.x1);
+  const T* wg = reinterpret_cast<const T*>(a.w);
+  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
+  const bool wvec_ok = (cin % VG == 0);
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int cb = 0; cb < cin; cb += CK) {
+    __syncthreads();  // everyone finished reading the previous chunk
+    // ---- stage the input halo tile
+    for (int i = tid; i < XH * XW * VPP; i += 256) {
+      const int v = i % VPP, pix = i / VPP;
+      const int py = pix / XW, px = pix % XW;
+      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+      vec_t val;
+      memset(&val, 0, sizeof(val));
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cb + v * VG, vec_ok);
+      *reinterpret_cast<vec_t*>(&xs[pix * CKP + v * VG]) = val;
+    }
+    // ---- stage the weight slab  ws[co][t*CK + ci]
+    for (int i = tid; i < BN * KK * VPP; i += 256) {
+      const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
+      const int gco = ct * BN + co, ci = cb + v * VG;
+      union {
+        vec_t vv;
+        T e[VG];
+      } u;
+      memset(&u, 0, sizeof(u));
+      if (gco < cout) {
+        const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
+        if (wvec_ok) {
+          if (ci < cin) u.vv = *reinterpret_cast<const vec_t*>(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VG; ++j)
+            if (ci + j < cin) u.e[j] = src[j];
+        }
+      }
+      *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = u.vv;
+    }
+    if (KCP > KC) {  // zero the K padding so that clamped A reads multiply by 0
+      constexpr int PV = (KCP - KC) / VG;
+      for (int i = tid; i < BN * PV; i += 256) {
+        vec_t z;
+        memset(&z, 0, sizeof(z));
+        *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA over this chunk
+    if constexpr (CK >= KSTEP) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int r = t / KS, s = t % KS;
+#pragma unroll
+        for (int ks = 0; ks < CK / KSTEP; ++ks) {
+          frag_t b[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            b[f] = *reinterpret_cast<const frag_t*>(&ws[(f * 16 + li) * WKP + t * CK + ks * KSTEP + kg * KV]);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int row = wave * MF + m;
+            const frag_t av =
+                *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + ks * KSTEP + kg * KV]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(av, b[f], acc[m][f]);
+          }
+        }
+      }
+    } else {
+      // CK < KSTEP (bf16 with 8 or 16 staged channels): one MFMA spans several taps; each lane's
+      // 8 contraction elements stay inside one tap because CK % 8 == 0.
+#pragma unroll
+      for (int ks = 0; ks < KCP / KSTEP; ++ks) {
+        const int k0 = ks * KSTEP + kg * KV;
+        int t = k0 / CK;
+        const int cil = k0 % CK;
+        if (t > KK - 1) t = KK - 1;  // padded K: weights are zero there, any valid address will do
+        const int r = t / KS, s = t % KS;
+        frag_t b[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) b[f] = *reinterpret_cast<const frag_t*>(&ws[(f * 16 + li) * WKP + k0]);
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const int row = wave * MF + m;
+          const frag_t av = *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + cil]);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(av, b[f], acc[m][f]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue.  acc[m][f][r] = output(pixel row wave*MF+m, col kg*4+r ; channel f*16+li)
+  float ssum[NF], ssq[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) ssum[f] = ssq[f] = 0.f;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int co = ct * BN + f * 16 + li;
+    const bool cok = co < cout;
+    const float bv = (cok && a.bias) ? a.bias[co] : 0.f;
+    const bool second = co >= a.co0;
+    const int cdst = second ? a.co1 : a.co0;
+    const int cofs = second ? co - a.co0 : co;
+    void* ybase = second ? a.y1 : a.y0;
+    const int accum = second ? a.acc1 : a.acc0;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gy = ty * TH + wave * MF + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gx = tx * 16 + kg * 4 + r;
+        if (cok && gy < H && gx < W) {
+          const size_t o = (((size_t)n * H + gy) * W + gx) * cdst + cofs;
+          float v = acc[m][f][r] + bv;
+          if (a.y_f32) {
+            float* yp = reinterpret_cast<float*>(ybase) + o;
+            if (accum) v += *yp;
+            *yp = v;
+          } else {
+            T* yp = reinterpret_cast<T*>(ybase) + o;
+            if (accum) v += to_f32(*yp);
+            const T q = from_f32<T>(v);
+            *yp = q;
+            v = to_f32(q);
+          }
+          ssum[f] += v;
+          ssq[f] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();  // LDS reuse: all MFMA reads are done
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      float s = ssum[f], q = ssq[f];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (kg == 0) {
+        red[(wave * BN + f * 16 + li) * 2 + 0] = s;
+        red[(wave * BN + f * 16 + li) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN * 2) {
+      const int c = tid >> 1, which = tid & 1;
+      const int co = ct * BN + c;
+      if (co < cout) {
+        double tot = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) tot += (double)red[(wv * BN + c) * 2 + which];
+        atomicAdd(&a.stats[(size_t)co * 2 + which], tot);
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TH, int NF, int CK>
+static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
+  constexpr int CKP = CK + VG, KC = KK * CK, KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP, WKP = KCP + VG;
+  constexpr int BN = NF * 16;
+  size_t lds = (size_t)(XH * XW * CKP + BN * WKP) * sizeof(T);
+  const size_t red = (size_t)4 * BN * 2 * sizeof(float);
+  if (lds < red) lds = red;
+  const long blocks = (long)a.N * a.tilesX * a.tilesY * a.nct;
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad:  dw[co][t][ci] += sum_pix dy[pix][co] * x[pix + tap t][ci]
+//   GEMM view M = Cout, N = Cin (per tap), K = pixels.  A workgroup owns a (16*NFO) x (16*NFI)
+//   channel tile and walks spatial tiles (grid-stride), staging the x halo tile and the dy tile
+//   in LDS.  The 4 waves split the tile's pixels (K), each keeping all 9*NFO*NFI accumulators;
+//   they are combined through LDS atomics and flushed with one fp32 global atomic per element.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* x0;
+  const void* x1;
+  const void* dy;
+  float* dw;
+  float* dbias;
+  int N, H, W;
+  int c0, c1, cout;
+  int tilesX, tilesY, nco, nci, spatialBlocks;
+};
+
+template <typename T>
+__device__ __forceinline__ typename DT<T>::frag_t gather_k(const T* base, int stride);
+template <>
+__device__ __forceinline__ float gather_k<float>(const float* base, int) {
+  return base[0];
+}
+template <>
+__device__ __forceinline__ bf16x8 gather_k<bf16_t>(const bf16_t* base, int stride) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = base[e * stride];
+  return v;
+}
+
+template <typename T, int KS, int TH, int NFO, int NFI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
+  constexpr int BCI = NFI * 16, BCO = NFO * 16;
+  constexpr int XP = BCI + VG, DP = BCO + VG;  // padded LDS pixel strides
+  constexpr int VPX = BCI / VG, VPD = BCO / VG;
+  constexpr int NKS = TH * 16 / KSTEP;         // k-steps per spatial tile
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);           // [XH*XW][XP]
+  T* ds = xs + XH * XW * XP;                    // [TH*16][DP]
+  float* red = reinterpret_cast<float*>(smem);  // reused at the end: [KK][BCO][BCI] (+ [BCO] bias)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const int cin = a.c0 + a.c1, cout = a.cout;
+  int bid = blockIdx.x;
+  const int cit = bid % a.nci;
+  bid /= a.nci;
+  const int cot = bid % a.nco;
+  const int sb = bid / a.nco;
+  const int H = a.H, W = a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0);
+  const T* x1 = reinterpret_cast<const T*>(a.x1);
+  const T* dyg = reinterpret_cast<const T*>(a.dy);
+  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
+  const bool dvec_ok = (cout % VG == 0);
+
+  f32x4 acc[KK][NFO][NFI];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int o = 0; o < NFO; ++o)
+#pragma unroll
+      for (int i = 0; i < NFI; ++i) acc[t][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // thread tid < BCO accumulates dbias for channel tid (cit == 0 blocks only)
+
+  const int ntiles = a.N * a.tilesX * a.tilesY;
+  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
+    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
+    __syncthreads();
+    for (int i = tid; i < XH * XW * VPX; i += 256) {
+      const int v = i % VPX, pix = i / VPX;
+      const int py = pix / XW, px = pix % XW;
+      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+      vec_t val;
+      memset(&val, 0, sizeof(val));
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BCI + v * VG, vec_ok);
+      *reinterpret_cast<vec_t*>(&xs[pix * XP + v * VG]) = val;
+    }
+    for (int i = tid; i < TH * 16 * VPD; i += 256) {
+      const int v = i % VPD, pix = i / VPD;
+      const int py = pix / 16, px = pix % 16;
+      const int gy = ty * TH + py, gx = tx * 16 + px;
+      vec_t val;
+      memset(&val, 0, sizeof(val));
+      if (gy < H && gx < W)
+        val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BCO + v * VG, dvec_ok);
+      *reinterpret_cast<vec_t*>(&ds[pix * DP + v * VG]) = val;
+    }
+    __syncthreads();
+
+    for (int ks = wave; ks < NKS; ks += 4) {
+      // this lane's first contraction pixel inside the tile, and how its KV pixels are strided
+      int prow, pcol;
+      if constexpr (KSTEP == 4) {
+        const int p = ks * 4 + kg;
+        prow = p / 16;
+        pcol = p % 16;
+      } else {
+        prow = ks * 2 + (kg >> 1);
+        pcol = (kg & 1) * 8;
+      }
+      frag_t av[NFO];
+#pragma unroll
+      for (int o = 0; o < NFO; ++o) av[o] = gather_k<T>(&ds[(prow * 16 + pcol) * DP + o * 16 + li], DP);
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int r = t / KS, s = t % KS;
+#pragma unroll
+        for (int i = 0; i < NFI; ++i) {
+          const frag_t bv = gather_k<T>(&xs[((prow + r) * XW + pcol + s) * XP + i * 16 + li], XP);
+#pragma unroll
+          for (int o = 0; o < NFO; ++o) acc[t][o][i] = mfma16(av[o], bv, acc[t][o][i]);
+        }
+      }
+    }
+    if (a.dbias && cit == 0 && tid < BCO) {
+      float s = 0.f;
+      for (int p = 0; p < TH * 16; ++p) s += to_f32(ds[p * DP + tid]);
+      bsum += s;
+    }
+  }
+
+  // ---- combine the 4 waves through LDS, then one global atomic per dw element
+  __syncthreads();
+  for (int i = tid; i < KK * BCO * BCI; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int o = 0; o < NFO; ++o)
+#pragma unroll
+      for (int i = 0; i < NFI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // D[row = co = kg*4+r][col = ci = li]
+          const int co = o * 16 + kg * 4 + r, ci = i * 16 + li;
+          atomicAdd(&red[(t * BCO + co) * BCI + ci], acc[t][o][i][r]);
+        }
+  __syncthreads();
+  for (int i = tid; i < KK * BCO * BCI; i += 256) {
+    const int ci = i % BCI, co = (i / BCI) % BCO, t = i / (BCI * BCO);
+    const int gco = cot * BCO + co, gci = cit * BCI + ci;
+    if (gco < cout && gci < cin) {
+      const float v = red[i];
+      if (v != 0.f) atomicAdd(&a.dw[((size_t)gco * KK + t) * cin + gci], v);
+    }
+  }
+  if (a.dbias && cit == 0 && tid < BCO) {
+    const int gco = cot * BCO + tid;
+    if (gco < cout) atomicAdd(&a.dbias[gco], bsum);
+  }
+}
+
+template <typename T, int KS, int TH, int NFO, int NFI>
+static int launch_conv_wgrad(const WgradArgs& a, hipStream_t st) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG;
+  constexpr int BCI = NFI * 16, BCO = NFO * 16, XP = BCI + VG, DP = BCO + VG;
+  size_t lds = (size_t)(XH * XW * XP + TH * 16 * DP) * sizeof(T);
+  const size_t red = (size_t)KK * BCO * BCI * sizeof(float);
+  if (lds < red) lds = red;
+  const long blocks = (long)a.spatialBlocks * a.nco * a.nci;
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}

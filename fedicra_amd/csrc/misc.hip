@@ -1,0 +1,419 @@
+// Loss, metric, optimizer, aggregation and PCS helper kernels (gfx950).
+// Reductions: lane-private partials -> wavefront xor-shuffle (64 lanes) -> LDS across the
+// workgroup's waves -> one fp64 / int64 atomic per workgroup.
+#include "common.h"
+
+static inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define FI_MAX_CLASSES 8
+
+// block-wide sum of a double; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wv] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// partial cross-entropy
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
+                                                     const uint8_t* __restrict__ labels, long M, int C, int ignore,
+                                                     double* acc) {
+  __shared__ double sm[4];
+  double loss = 0.0, cnt = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+    const int lb = labels[i];
+    if (lb == ignore) continue;
+    const float* z = logits + i * C;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float zl = (lb >= 0 && lb < C) ? z[lb] : 0.f;
+    loss += (double)(logf(se) + mx - zl);
+    cnt += 1.0;
+  }
+  const double tl = block_sum(loss, sm);
+  const double tc = block_sum(cnt, sm);
+  if (threadIdx.x == 0 && tc > 0.0) {
+    atomicAdd(&acc[0], tl);
+    atomicAdd(&acc[1], tc);
+  }
+}
+
+__global__ void ce_finalize_kernel(const double* acc, float* loss) { loss[0] = (float)(acc[0] / acc[1]); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
+                                                     const uint8_t* __restrict__ labels, long M, int C, int ignore,
+                                                     const double* __restrict__ acc, const float* gscale,
+                                                     T* __restrict__ dl) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  const float inv = (float)((double)gs / acc[1]);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+    const int lb = labels[i];
+    T* o = dl + i * C;
+    if (lb == ignore) {
+      for (int c = 0; c < C; ++c) o[c] = from_f32<T>(0.f);
+      continue;
+    }
+    const float* z = logits + i * C;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float e[FI_MAX_CLASSES];
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+      e[c] = expf(z[c] - mx);
+      se += e[c];
+    }
+    const float rs = 1.f / se;
+    for (int c = 0; c < C; ++c) o[c] = from_f32<T>((e[c] * rs - (c == lb ? 1.f : 0.f)) * inv);
+  }
+}
+
+extern "C" int fi_ce_fwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index, double* acc,
+                         void* stream) {
+  if (!logits || !labels || !acc) return FI_ERR_NULL;
+  if (C < 1 || C > FI_MAX_CLASSES) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(M, 256 * 4)), dim3(256), 0, (hipStream_t)stream, logits, labels, M,
+                     C, ignore_index, acc);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_ce_finalize(const double* acc, float* loss, void* stream) {
+  if (!acc || !loss) return FI_ERR_NULL;
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, loss);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_ce_bwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index,
+                         const double* acc, const float* gscale, void* dlogits, int dtype, void* stream) {
+  if (!logits || !labels || !acc || !dlogits) return FI_ERR_NULL;
+  if (C < 1 || C > FI_MAX_CLASSES) return FI_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(grid_for(M, 256 * 2)), dim3(256), 0, st, logits, labels, M, C,
+                       ignore_index, acc, gscale, (float*)dlogits);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(grid_for(M, 256 * 2)), dim3(256), 0, st, logits, labels, M, C,
+                       ignore_index, acc, gscale, (bf16_t*)dlogits);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dice bookkeeping
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ logits,
+                                                          const uint8_t* __restrict__ gt, long M, int C,
+                                                          unsigned long long* counts) {
+  // per-thread counters for up to FI_MAX_CLASSES-1 foreground classes
+  unsigned int inter[FI_MAX_CLASSES - 1], np[FI_MAX_CLASSES - 1], ng[FI_MAX_CLASSES - 1];
+  for (int k = 0; k < FI_MAX_CLASSES - 1; ++k) inter[k] = np[k] = ng[k] = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+    const float* z = logits + i * C;
+    int best = 0;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c)
+      if (z[c] > mx) {
+        mx = z[c];
+        best = c;
+      }
+    const int g = gt[i];
+    for (int k = 1; k < C; ++k) {
+      const bool p = (k == 1) ? (best == 1) : (best >= 1);
+      const bool q = (k == 1) ? (g == 1) : (g >= 1);
+      inter[k - 1] += (p && q);
+      np[k - 1] += p;
+      ng[k - 1] += q;
+    }
+  }
+  __shared__ double sm[4];
+  for (int k = 0; k < C - 1; ++k) {
+    const double a = block_sum((double)inter[k], sm);
+    const double b = block_sum((double)np[k], sm);
+    const double c = block_sum((double)ng[k], sm);
+    if (threadIdx.x == 0) {
+      atomicAdd(&counts[k * 3 + 0], (unsigned long long)a);
+      atomicAdd(&counts[k * 3 + 1], (unsigned long long)b);
+      atomicAdd(&counts[k * 3 + 2], (unsigned long long)c);
+    }
+  }
+}
+
+extern "C" int fi_dice_counts(const float* logits, const uint8_t* gt, long M, int C, long long* counts,
+                              void* stream) {
+  if (!logits || !gt || !counts) return FI_ERR_NULL;
+  if (C < 2 || C > FI_MAX_CLASSES) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(dice_counts_kernel, dim3(grid_for(M, 256 * 4)), dim3(256), 0, (hipStream_t)stream, logits, gt, M,
+                     C, (unsigned long long*)counts);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_hyper_kernel(int* step, float* hyper, const double* lr_state, float beta1, float beta2,
+                                   float wd) {
+  const int t = step[0] + 1;
+  step[0] = t;
+  const double lr = lr_state[0];
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  hyper[0] = (float)lr;
+  hyper[1] = (float)(1.0 - lr * (double)wd);
+  hyper[2] = (float)(lr / bc1);
+  hyper[3] = (float)sqrt(bc2);
+}
+
+__global__ void lr_poly_kernel(int* iter, double* lr_state, double base_lr, double max_iter) {
+  const int it = iter[0] + 1;
+  iter[0] = it;
+  lr_state[0] = base_lr * pow(1.0 - (double)it / max_iter, 0.9);
+}
+
+extern "C" int fi_adamw_hyper(int* step, float* hyper, const double* lr_state, float beta1, float beta2, float wd,
+                              void* stream) {
+  if (!step || !hyper || !lr_state) return FI_ERR_NULL;
+  hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, hyper, lr_state, beta1,
+                     beta2, wd);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_lr_poly_advance(int* iter, double* lr_state, double base_lr, double max_iter, void* stream) {
+  if (!iter || !lr_state) return FI_ERR_NULL;
+  hipLaunchKernelGGL(lr_poly_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, iter, lr_state, base_lr, max_iter);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const float* __restrict__ hyper, float beta1, float beta2,
+                                                         float eps, bf16_t* __restrict__ shadow) {
+  const float decay = hyper[1], step = hyper[2], bc2s = hyper[3];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * decay;                       // param.mul_(1 - lr*wd)
+    const float mi = m[i] + omb1 * (gi - m[i]);    // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + (omb2 * gi) * gi;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) / bc2s + eps;
+    pi = pi + (-step * mi) / denom;                // param.addcdiv_(exp_avg, denom, -step_size)
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (shadow) shadow[i] = (bf16_t)pi;
+  }
+}
+
+extern "C" int fi_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1,
+                             float beta2, float eps, void* shadow_bf16, void* stream) {
+  if (!p || !g || !m || !v || !hyper) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adamw_step_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     hyper, beta1, beta2, eps, (bf16_t*)shadow_bf16);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregation helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a, int divide) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = divide ? __fdiv_rn(x[i], a) : __fmul_rn(x[i], a);
+}
+extern "C" int fi_scale(const float* x, float* y, long n, float a, int divide, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, divide);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void axpy_kernel(float* __restrict__ acc, const float* __restrict__ x, long n, float a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc[i] = __fadd_rn(acc[i], __fmul_rn(x[i], a));
+}
+extern "C" int fi_axpy(float* acc, const float* x, long n, float a, void* stream) {
+  if (!acc || !x) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, acc, x, n, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void ala_update_kernel(float* __restrict__ w, float* __restrict__ temp, const float* __restrict__ grad,
+                                  const float* __restrict__ local, const float* __restrict__ global, long n,
+                                  float eta) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = local[i] - global[i];
+    float wi = w[i] - eta * (grad[i] * d);
+    wi = fminf(fmaxf(wi, 0.f), 1.f);
+    w[i] = wi;
+    temp[i] = global[i] + d * wi;
+  }
+}
+extern "C" int fi_ala_update(float* w, float* temp, const float* grad, const float* local, const float* global,
+                             long n, float eta, void* stream) {
+  if (!w || !temp || !grad || !local || !global) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(ala_update_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, w, temp, grad,
+                     local, global, n, eta);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCS helpers: global avg / max pool, channel gate
+// ------------------------------------------------------------------------------------------------
+// grid (N, ceil(C/64)); block 256 = 4 pixel lanes x 64 channels
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgmax_kernel(const T* __restrict__ x, float* __restrict__ avg,
+                                                            float* __restrict__ mx, int* __restrict__ amax, int HW,
+                                                            int C) {
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f, m = -INFINITY;
+  int mi = 0;
+  if (c < C)
+    for (int p = pl; p < HW; p += 4) {
+      const float v = to_f32(x[((size_t)n * HW + p) * C + c]);
+      s += v;
+      if (v > m) {
+        m = v;
+        mi = p;
+      }
+    }
+  __shared__ float ss[4][64], sm[4][64];
+  __shared__ int si[4][64];
+  ss[pl][threadIdx.x & 63] = s;
+  sm[pl][threadIdx.x & 63] = m;
+  si[pl][threadIdx.x & 63] = mi;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    float ts = 0.f, tm = -INFINITY;
+    int ti = 0;
+    for (int q = 0; q < 4; ++q) {
+      ts += ss[q][l];
+      // first occurrence in scan order: strict > on value, lower index wins ties
+      if (sm[q][l] > tm || (sm[q][l] == tm && si[q][l] < ti)) {
+        tm = sm[q][l];
+        ti = si[q][l];
+      }
+    }
+    avg[(size_t)n * C + c] = ts / (float)HW;
+    mx[(size_t)n * C + c] = tm;
+    if (amax) amax[(size_t)n * C + c] = ti;
+  }
+}
+
+extern "C" int fi_global_avgmax(int dtype, const void* x, float* avg, float* mx, int* amax, int N, int HW, int C,
+                                void* stream) {
+  if (!x || !avg || !mx) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(N, fi_cdiv(C, 64)), b(256);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(global_avgmax_kernel<float>, g, b, 0, st, (const float*)x, avg, mx, amax, HW, C);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(global_avgmax_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, avg, mx, amax, HW, C);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_gate_fwd_kernel(const T* __restrict__ x, const float* __restrict__ h,
+                                                               T* __restrict__ y, long n_elem, int HW, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elem; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long n = i / ((long)C * HW);
+    const float xv = to_f32(x[i]);
+    y[i] = from_f32<T>(xv * h[n * C + c] + xv);
+  }
+}
+
+extern "C" int fi_channel_gate_fwd(int dtype, const void* x, const float* h, void* y, int N, int HW, int C,
+                                   void* stream) {
+  if (!x || !h || !y) return FI_ERR_NULL;
+  const long n = (long)N * HW * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(channel_gate_fwd_kernel<float>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, st, (const float*)x,
+                       h, (float*)y, n, HW, C);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(channel_gate_fwd_kernel<bf16_t>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, st,
+                       (const bf16_t*)x, h, (bf16_t*)y, n, HW, C);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// grid (N, ceil(C/64)); block 256 = 4 pixel lanes x 64 channels.  dh by LDS reduction over pixel lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const float* __restrict__ h,
+                                                               const int* __restrict__ amax,
+                                                               const float* __restrict__ davg,
+                                                               const float* __restrict__ dmx, T* __restrict__ dx,
+                                                               float* __restrict__ dh, int HW, int C) {
+  const int n = blockIdx.x, l = threadIdx.x & 63, c = blockIdx.y * 64 + l, pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
+    const float gate = 1.f + h[(size_t)n * C + c];
+    const float ga = davg ? davg[(size_t)n * C + c] / (float)HW : 0.f;
+    const float gm = dmx ? dmx[(size_t)n * C + c] : 0.f;
+    const int am = amax ? amax[(size_t)n * C + c] : -1;
+    for (int p = pl; p < HW; p += 4) {
+      const size_t o = ((size_t)n * HW + p) * C + c;
+      const float g = to_f32(dy[o]);
+      s += g * to_f32(x[o]);
+      float v = g * gate + ga;
+      if (p == am) v += gm;
+      dx[o] = from_f32<T>(v);
+    }
+  }
+  __shared__ float ss[4][64];
+  ss[pl][l] = s;
+  __syncthreads();
+  if (pl == 0 && c < C && dh) dh[(size_t)n * C + c] = ss[0][l] + ss[1][l] + ss[2][l] + ss[3][l];
+}
+
+extern "C" int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, const float* h, const int* amax,
+                                   const float* davg, const float* dmx, void* dx, float* dh, int N, int HW, int C,
+                                   void* stream) {
+  if (!x || !dy || !h || !dx) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(N, fi_cdiv(C, 64)), b(256);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(channel_gate_bwd_kernel<float>, g, b, 0, st, (const float*)x, (const float*)dy, h, amax, davg,
+                       dmx, (float*)dx, dh, HW, C);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(channel_gate_bwd_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, (const bf16_t*)dy, h, amax,
+                       davg, dmx, (bf16_t*)dx, dh, HW, C);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_abi_version(void) { return 1; }

@@ -1,0 +1,728 @@
+// Bandwidth-bound kernels of the FedICRA hot path for gfx950: BatchNorm finalize / apply /
+// backward, LeakyReLU + dropout, 2x2 max-pool, bilinear x2 up-sampling, weight repack, layout
+// and dtype conversion.  All are HBM-bound: 16-byte vectors per lane over dense NHWC, grid-stride
+// loops capped at a few workgroups per CU, per-channel reductions as lane-private partials ->
+// LDS -> one fp64 atomic per channel per workgroup.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers: VG elements of T <-> float[VG]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float (&f)[DT<T>::VG]) {
+  typedef typename DT<T>::vec_t vec_t;
+  union {
+    vec_t v;
+    T e[DT<T>::VG];
+  } u;
+  u.v = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+  for (int j = 0; j < DT<T>::VG; ++j) f[j] = to_f32(u.e[j]);
+}
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float (&f)[DT<T>::VG]) {
+  typedef typename DT<T>::vec_t vec_t;
+  union {
+    vec_t v;
+    T e[DT<T>::VG];
+  } u;
+#pragma unroll
+  for (int j = 0; j < DT<T>::VG; ++j) u.e[j] = from_f32<T>(f[j]);
+  *reinterpret_cast<vec_t*>(p) = u.v;
+}
+
+static inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, int64_t* nbt, float momentum, float eps, int training,
+                                   float* scale, float* shift, float* mean, float* invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  float mu, istd;
+  if (training) {
+    const double m = stats[2 * c] / count;
+    double var = stats[2 * c + 1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    istd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  } else {
+    mu = rmean[c];
+    istd = 1.0f / sqrtf(rvar[c] + eps);
+  }
+  const float sc = gamma[c] * istd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mu * sc;
+  mean[c] = mu;
+  invstd[c] = istd;
+}
+
+extern "C" int fi_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                              int training, float* scale, float* shift, float* mean, float* invstd, int C,
+                              void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || !mean || !invstd) return FI_ERR_NULL;
+  if (training && !stats) return FI_ERR_NULL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fi_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma,
+                     beta, running_mean, running_var, nbt, momentum, eps, training, scale, shift, mean, invstd, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN apply + activation + dropout
+// ------------------------------------------------------------------------------------------------
+struct DropSpec {
+  int mode;
+  uint32_t thresh;  // drop when rand32 < thresh
+  float keep_scale;
+  uint64_t seed;
+  const uint8_t* mask;
+  const int32_t* seed_offset;
+  int C, hw;
+};
+
+__device__ __forceinline__ uint64_t drop_seed(const DropSpec& d) {
+  uint64_t s = d.seed;
+  if (d.seed_offset) s += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)d.seed_offset[0];
+  return s;
+}
+
+// `seed` is the value of drop_seed(d), hoisted out of the element loop by the callers
+__device__ __forceinline__ float drop_factor(const DropSpec& d, uint64_t seed, size_t pixel, int c) {
+  switch (d.mode) {
+    case FI_DROP_MASK_ELEM:
+      return d.mask[pixel * d.C + c] ? d.keep_scale : 0.f;
+    case FI_DROP_RNG_ELEM:
+      return fi_keep(seed, pixel * d.C + c, d.thresh) ? d.keep_scale : 0.f;
+    case FI_DROP_MASK_CHAN:
+      return d.mask[(pixel / d.hw) * d.C + c] ? d.keep_scale : 0.f;
+    case FI_DROP_RNG_CHAN:
+      return fi_keep(seed, (pixel / d.hw) * d.C + c, d.thresh) ? d.keep_scale : 0.f;
+    default:
+      return 1.f;
+  }
+}
+
+static DropSpec make_drop(const FiBnAct* d) {
+  DropSpec s;
+  s.mode = d->drop_p > 0.f ? d->drop_mode : FI_DROP_NONE;
+  double t = (double)d->drop_p * 4294967296.0;
+  s.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  s.keep_scale = d->drop_p < 1.f ? 1.0f / (float)(1.0 - (double)d->drop_p) : 0.f;
+  s.seed = d->seed;
+  s.mask = d->mask;
+  s.seed_offset = d->seed_offset;
+  s.C = d->C;
+  s.hw = d->hw;
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, T* __restrict__ z,
+                                                         long nvec, int C, float slope, DropSpec dr) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG;
+  const uint64_t seed = drop_seed(dr);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VG;
+    const size_t pixel = (size_t)(i / CV);
+    float f[VG];
+    load_vec<T>(y + i * VG, f);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      float v = f[j] * scale[c0 + j] + shift[c0 + j];
+      v = v > 0.f ? v : v * slope;
+      if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel, c0 + j);
+      f[j] = v;
+    }
+    store_vec<T>(z + i * VG, f);
+  }
+}
+
+extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z,
+                             void* stream) {
+  if (!d || !y || !scale || !shift || !z) return FI_ERR_NULL;
+  const DropSpec dr = make_drop(d);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FI_F32) {
+    if (d->C % 4) return FI_ERR_SHAPE;
+    const long nvec = d->pixels * (d->C / 4);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const float*)y,
+                       scale, shift, (float*)z, nvec, d->C, d->slope, dr);
+  } else if (d->dtype == FI_BF16) {
+    if (d->C % 8) return FI_ERR_SHAPE;
+    const long nvec = d->pixels * (d->C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const bf16_t*)y,
+                       scale, shift, (bf16_t*)z, nvec, d->C, d->slope, dr);
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// g = dz through dropout and the activation, evaluated from the saved conv output y
+template <typename T>
+__device__ __forceinline__ void act_grad(const float (&dzv)[DT<T>::VG], const float (&yv)[DT<T>::VG],
+                                         const float* scale, const float* shift, int c0, size_t pixel, float slope,
+                                         const DropSpec& dr, uint64_t seed, float (&g)[DT<T>::VG]) {
+#pragma unroll
+  for (int j = 0; j < DT<T>::VG; ++j) {
+    const float v = yv[j] * scale[c0 + j] + shift[c0 + j];
+    float gg = dzv[j];
+    if (dr.mode != FI_DROP_NONE) gg *= drop_factor(dr, seed, pixel, c0 + j);
+    g[j] = v > 0.f ? gg : gg * slope;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, double* sums,
+                                                                long pixels, int C, float slope, DropSpec dr) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG;          // channel vectors per pixel; divides 256
+  const int PS = 256 / CV;        // pixels handled concurrently by one workgroup
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int c0 = cv * VG;
+  const uint64_t seed = drop_seed(dr);
+  float sg[VG], sgx[VG];
+#pragma unroll
+  for (int j = 0; j < VG; ++j) sg[j] = sgx[j] = 0.f;
+  for (long p = (long)blockIdx.x * PS + pl; p < pixels; p += (long)gridDim.x * PS) {
+    float dzv[VG], yv[VG], g[VG];
+    load_vec<T>(dz + (p * CV + cv) * VG, dzv);
+    load_vec<T>(y + (p * CV + cv) * VG, yv);
+    act_grad<T>(dzv, yv, scale, shift, c0, (size_t)p, slope, dr, seed, g);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      sg[j] += g[j];
+      sgx[j] += g[j] * (yv[j] - mean[c0 + j]) * invstd[c0 + j];
+    }
+  }
+  __shared__ float red[256][2 * VG + 1];
+#pragma unroll
+  for (int j = 0; j < VG; ++j) {
+    red[threadIdx.x][j] = sg[j];
+    red[threadIdx.x][VG + j] = sgx[j];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C * 2) {
+    const int c = threadIdx.x >> 1, which = threadIdx.x & 1;
+    const int tcv = c / VG, j = c % VG;
+    double tot = 0.0;
+    for (int q = 0; q < PS; ++q) tot += (double)red[q * CV + tcv][which * VG + j];
+    atomicAdd(&sums[2 * c + which], tot);
+  }
+  // C*2 can exceed 256 (C up to 512): remaining channels in further strides
+  for (int t = threadIdx.x + 256; t < C * 2; t += 256) {
+    const int c = t >> 1, which = t & 1;
+    const int tcv = c / VG, j = c % VG;
+    double tot = 0.0;
+    for (int q = 0; q < PS; ++q) tot += (double)red[q * CV + tcv][which * VG + j];
+    atomicAdd(&sums[2 * c + which], tot);
+  }
+}
+
+extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void* y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, double* sums,
+                                    void* stream) {
+  if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
+  const DropSpec dr = make_drop(d);
+  hipStream_t st = (hipStream_t)stream;
+  const int VG = d->dtype == FI_F32 ? 4 : 8;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->C % VG) return FI_ERR_SHAPE;
+  const int CV = d->C / VG;
+  if (CV > 256 || 256 % CV) return FI_ERR_SHAPE;
+  const int PS = 256 / CV;
+  const int grid = grid_for(d->pixels, PS * 8);
+  if (d->dtype == FI_F32)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
+                       (const float*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
+                       (const bf16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const double* __restrict__ sums, int training,
+                                                               T* __restrict__ dy, float* dgamma, float* dbeta,
+                                                               int accumulate_param, long nvec, long pixels, int C,
+                                                               float slope, DropSpec dr) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float dg = (float)sums[2 * c + 1], db = (float)sums[2 * c];
+      if (dgamma) dgamma[c] = accumulate_param ? dgamma[c] + dg : dg;
+      if (dbeta) dbeta[c] = accumulate_param ? dbeta[c] + db : db;
+    }
+  }
+  if (!dy) return;
+  const uint64_t seed = drop_seed(dr);
+  const float invM = (float)(1.0 / (double)pixels);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VG;
+    const size_t pixel = (size_t)(i / CV);
+    float dzv[VG], yv[VG], g[VG], out[VG];
+    load_vec<T>(dz + i * VG, dzv);
+    load_vec<T>(y + i * VG, yv);
+    act_grad<T>(dzv, yv, scale, shift, c0, pixel, slope, dr, seed, g);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      const int c = c0 + j;
+      if (training) {
+        const float xh = (yv[j] - mean[c]) * invstd[c];
+        out[j] = scale[c] * (g[j] - (float)sums[2 * c] * invM - xh * (float)sums[2 * c + 1] * invM);
+      } else {
+        out[j] = scale[c] * g[j];
+      }
+    }
+    store_vec<T>(dy + i * VG, out);
+  }
+}
+
+extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void* y, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd, const double* sums,
+                                   int training, void* dy, float* dgamma, float* dbeta, int accumulate_param,
+                                   void* stream) {
+  if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
+  const DropSpec dr = make_drop(d);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FI_F32) {
+    if (d->C % 4) return FI_ERR_SHAPE;
+    const long nvec = d->pixels * (d->C / 4);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
+                       (const float*)dz, (const float*)y, scale, shift, mean, invstd, sums, training, (float*)dy,
+                       dgamma, dbeta, accumulate_param, nvec, d->pixels, d->C, d->slope, dr);
+  } else if (d->dtype == FI_BF16) {
+    if (d->C % 8) return FI_ERR_SHAPE;
+    const long nvec = d->pixels * (d->C / 8);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
+                       (const bf16_t*)dz, (const bf16_t*)y, scale, shift, mean, invstd, sums, training, (bf16_t*)dy,
+                       dgamma, dbeta, accumulate_param, nvec, d->pixels, d->C, d->slope, dr);
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H,
+                                                          int W, int C) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Ho = H / 2, Wo = W / 2;
+  const long nvec = (long)N * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const T* base = x + ((((size_t)n * H + 2 * oy) * W + 2 * ox) * C + cv * VG);
+    float a[VG], b[VG], c[VG], d[VG], m[VG];
+    load_vec<T>(base, a);
+    load_vec<T>(base + C, b);
+    load_vec<T>(base + (size_t)W * C, c);
+    load_vec<T>(base + (size_t)W * C + C, d);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      float mm = a[j];
+      if (b[j] > mm) mm = b[j];
+      if (c[j] > mm) mm = c[j];
+      if (d[j] > mm) mm = d[j];
+      m[j] = mm;
+    }
+    store_vec<T>(y + i * VG, m);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int N, int H, int W, int C,
+                                                          int accumulate) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Ho = H / 2, Wo = W / 2;
+  const long nvec = (long)N * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const size_t o00 = (((size_t)n * H + 2 * oy) * W + 2 * ox) * C + cv * VG;
+    const size_t offs[4] = {o00, o00 + C, o00 + (size_t)W * C, o00 + (size_t)W * C + C};
+    float v[4][VG], g[VG], out[4][VG];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_vec<T>(x + offs[q], v[q]);
+    load_vec<T>(dy + i * VG, g);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      int best = 0;
+      float mm = v[0][j];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (v[q][j] > mm) {
+          mm = v[q][j];
+          best = q;
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q][j] = (q == best) ? g[j] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (accumulate) {
+        float old[VG];
+        load_vec<T>(dx + offs[q], old);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) out[q][j] += old[j];
+      }
+      store_vec<T>(dx + offs[q], out[q]);
+    }
+  }
+}
+
+extern "C" int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  if ((H & 1) || (W & 1)) return FI_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32) {
+    if (C % 4) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
+                       (float*)y, N, H, W, C);
+  } else if (dtype == FI_BF16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const bf16_t*)x,
+                       (bf16_t*)y, N, H, W, C);
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                               int accumulate, void* stream) {
+  if (!x || !dy || !dx) return FI_ERR_NULL;
+  if ((H & 1) || (W & 1)) return FI_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32) {
+    if (C % 4) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, (float*)dx, N, H, W, C, accumulate);
+  } else if (dtype == FI_BF16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
+                       (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear x2, align_corners=True
+//   src = dst * (in-1)/(out-1); i0 = floor(src) clamped; i1 = min(i0+1, in-1); l1 = src - i0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_coord(int o, int in, float sc, int& i0, int& i1, float& l0, float& l1) {
+  const float src = sc * (float)o;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  l1 = src - (float)i0;
+  if (l1 < 0.f) l1 = 0.f;
+  if (l1 > 1.f) l1 = 1.f;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int h,
+                                                           int w, int C, float sh, float sw) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Ho = 2 * h, Wo = 2 * w;
+  const long nvec = (long)N * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    lin_coord(oy, h, sh, y0, y1, ly0, ly1);
+    lin_coord(ox, w, sw, x0, x1, lx0, lx1);
+    const T* b = x + (size_t)n * h * w * C + cv * VG;
+    float a00[VG], a01[VG], a10[VG], a11[VG], o[VG];
+    load_vec<T>(b + ((size_t)y0 * w + x0) * C, a00);
+    load_vec<T>(b + ((size_t)y0 * w + x1) * C, a01);
+    load_vec<T>(b + ((size_t)y1 * w + x0) * C, a10);
+    load_vec<T>(b + ((size_t)y1 * w + x1) * C, a11);
+#pragma unroll
+    for (int j = 0; j < VG; ++j)
+      o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+    store_vec<T>(y + i * VG, o);
+  }
+}
+
+// backward as a gather: for every input pixel collect the outputs whose 2x2 footprint touches it
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int h,
+                                                           int w, int C, float sh, float sw, int accumulate) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Ho = 2 * h, Wo = 2 * w;
+  const long nvec = (long)N * h * w * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h);
+    const int n = (int)(p / h);
+    // candidate output range: src in (iy-1, iy+1)  ->  o in ((iy-1)/s, (iy+1)/s), widened by 1
+    int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+    if (sh > 0.f) {
+      oy_lo = (int)floorf((float)(iy - 1) / sh) - 1;
+      oy_hi = (int)ceilf((float)(iy + 1) / sh) + 1;
+      if (oy_lo < 0) oy_lo = 0;
+      if (oy_hi > Ho - 1) oy_hi = Ho - 1;
+    }
+    if (sw > 0.f) {
+      ox_lo = (int)floorf((float)(ix - 1) / sw) - 1;
+      ox_hi = (int)ceilf((float)(ix + 1) / sw) + 1;
+      if (ox_lo < 0) ox_lo = 0;
+      if (ox_hi > Wo - 1) ox_hi = Wo - 1;
+    }
+    float acc[VG];
+#pragma unroll
+    for (int j = 0; j < VG; ++j) acc[j] = 0.f;
+    const T* b = dy + (size_t)n * Ho * Wo * C + cv * VG;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      lin_coord(oy, h, sh, y0, y1, ly0, ly1);
+      float wy = 0.f;
+      if (y0 == iy) wy += ly0;
+      if (y1 == iy) wy += ly1;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        lin_coord(ox, w, sw, x0, x1, lx0, lx1);
+        float wx = 0.f;
+        if (x0 == ix) wx += lx0;
+        if (x1 == ix) wx += lx1;
+        if (wx == 0.f) continue;
+        float g[VG];
+        load_vec<T>(b + ((size_t)oy * Wo + ox) * C, g);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int j = 0; j < VG; ++j) acc[j] += wgt * g[j];
+      }
+    }
+    if (accumulate) {
+      float old[VG];
+      load_vec<T>(dx + i * VG, old);
+#pragma unroll
+      for (int j = 0; j < VG; ++j) acc[j] += old[j];
+    }
+    store_vec<T>(dx + i * VG, acc);
+  }
+}
+
+static inline float up_scale(int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
+
+extern "C" int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32) {
+    if (C % 4) return FI_ERR_SHAPE;
+    const long nvec = (long)N * 4 * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
+                       (float*)y, N, h, w, C, up_scale(h), up_scale(w));
+  } else if (dtype == FI_BF16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * 4 * h * w * (C / 8);
+    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
+                       (const bf16_t*)x, (bf16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate,
+                                 void* stream) {
+  if (!dy || !dx) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32) {
+    if (C % 4) return FI_ERR_SHAPE;
+    const long nvec = (long)N * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const float*)dy,
+                       (float*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
+  } else if (dtype == FI_BF16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * h * w * (C / 8);
+    hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const bf16_t*)dy,
+                       (bf16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
+  } else {
+    return FI_ERR_DTYPE;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight repack / casts / layout
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int kk, int cin,
+                                    int mode) {
+  const long n = (long)cout * kk * cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (mode == 0) {
+      dst[i] = from_f32<T>(src[i]);
+    } else {
+      const int ci = (int)(i % cin);
+      const int t = (int)((i / cin) % kk);
+      const int co = (int)(i / ((long)cin * kk));
+      dst[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = from_f32<T>(src[i]);
+    }
+  }
+}
+
+extern "C" int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype,
+                               void* stream) {
+  if (!src || !dst) return FI_ERR_NULL;
+  if (mode != 0 && mode != 1) return FI_ERR_UNSUPPORTED;
+  const long n = (long)cout * kk * cin;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (float*)dst, cout,
+                       kk, cin, mode);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (bf16_t*)dst, cout,
+                       kk, cin, mode);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    d[i] = from_f32<D>(to_f32(s[i]));
+}
+
+extern "C" int fi_cast(const void* src, int sd, void* dst, int dd, long n, void* stream) {
+  if (!src || !dst) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid_for(n, 256)), b(256);
+  if (sd == FI_F32 && dd == FI_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == FI_BF16 && dd == FI_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (sd == FI_F32 && dd == FI_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
+  else if (sd == FI_BF16 && dd == FI_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ s, T* __restrict__ d, int N, int C, int H, int W) {
+  const long n = (long)N * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    d[i] = from_f32<T>(s[(((size_t)b * C + c) * H + y) * W + x]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ s, float* __restrict__ d, int N, int C, int H, int W) {
+  const long n = (long)N * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long p = i / W;
+    const int y = (int)(p % H);
+    p /= H;
+    const int c = (int)(p % C);
+    const int b = (int)(p / C);
+    d[i] = to_f32(s[(((size_t)b * H + y) * W + x) * C + c]);
+  }
+}
+
+extern "C" int fi_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, void* stream) {
+  if (!src || !dst) return FI_ERR_NULL;
+  const long n = (long)N * C * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (float*)dst, N, C,
+                       H, W);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (bf16_t*)dst, N, C,
+                       H, W);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int C, int H, int W, void* stream) {
+  if (!src || !dst) return FI_ERR_NULL;
+  const long n = (long)N * C * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const float*)src, dst,
+                       N, C, H, W);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)src, dst,
+                       N, C, H, W);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,385 @@
+"""Client / model-wrapper / strategy layer with the reference's API, MI355X-native underneath.
+
+Mirrors /root/reference/code/flower_common.py for the hot path (SURVEY.md section 8-a1..a4, a16,
+a17): ``BaseClient`` (get_parameters / get_properties / fit / evaluate), ``MyModel``
+(get_weights / set_weights incl. the FedICRA adaptive local aggregation), ``evaluate``,
+``aggregate`` / ``FedAvg`` / ``FedICRA`` and the metric aggregation functions -- same names,
+argument meaning and quirks -- but
+
+  * weights stay resident in HBM as ONE flat fp32 buffer (fedicra_amd/flat.py).  ``get_weights``
+    still returns the reference's list of numpy arrays (wire format, state_dict order) for a
+    Flower/gRPC server; the RCCL path exchanges ``DeviceWeights`` (flat tensors) with no host hop;
+  * the ALA loop (flower_common.py:566-602) runs one fused element-wise kernel per batch over the
+    contiguous decoder range instead of 2x42 tensor sweeps;
+  * Dice bookkeeping (val_2D.py:9-22) is a device reduction; validation images go through the
+    network as one batch (eval-mode BN makes images independent).
+
+Third-party arithmetic restated (not vendored by the reference): flwr 1.0.0 ``aggregate``,
+medpy 0.4.0 ``metric.binary.*`` -- see oracle/fed_ref.py, oracle/losses_ref.py.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import timeit
+from collections import OrderedDict
+from dataclasses import dataclass
+from functools import reduce
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import fl, ops
+
+VAL_METRICS = ["dice", "hd95", "recall", "precision", "jc", "specificity", "ravd"]     # flower_common.py:121
+PERSONALIZED_FL = ["FedICRA"]
+CENTRALIZED_FL = ["FedAvg", "FedAdagrad", "FedAdam", "FedYogi"]
+ALA_KEYS = ["out_conv", "up4", "up3", "up2", "up1"]                                      # flower_common.py:506
+
+
+@dataclass
+class DeviceWeights:
+    """Zero-copy form of the wire payload for the RCCL path: the flat fp32 state (parameters + BN
+    running statistics) and the int64 num_batches_tracked counters, both on the device."""
+    state: torch.Tensor
+    counters: torch.Tensor
+
+
+# ------------------------------------------------------------------------------ evaluation
+def _batch_images(dataloader, img_class, device):
+    xs, ys = [], []
+    for b in dataloader:
+        x, y = b["image"], b["label"]
+        x = x.reshape((-1,) + tuple(x.shape[-2:])) if img_class == "faz" else x.reshape((-1,) + tuple(x.shape[-3:]))
+        xs.append(x.unsqueeze(1) if img_class == "faz" else x)
+        ys.append(y.reshape((-1,) + tuple(y.shape[-2:])))
+    return torch.cat(xs).float().to(device), torch.cat(ys).to(torch.uint8).to(device)
+
+
+def dice_table(logits_nchw_view, labels_u8, classes):
+    """Per-image integer counts {|P&G|, |P|, |G|} for classes 1..C-1 (val_2D.py:66-74) -> int64 [n, C-1, 3]."""
+    lg = logits_nchw_view.permute(0, 2, 3, 1)
+    if not lg.is_contiguous() or lg.dtype != torch.float32:
+        lg = lg.contiguous().float()
+    n = lg.shape[0]
+    counts = torch.zeros((n, classes - 1, 3), dtype=torch.int64, device=lg.device)
+    for i in range(n):
+        L.dice_counts(lg[i], labels_u8[i], counts[i])
+    return counts
+
+
+def metrics_from_counts(tp, npred, ngt, total):
+    """The count-based medpy metrics of val_2D.py:13-19 for ONE image/class; hd95 needs a distance
+    transform and is reported as NaN (out of scope)."""
+    if npred == 0:                                        # val_2D.py:12,21-22
+        return [0.0] * 7
+    fp, fn = npred - tp, ngt - tp
+    tn = total - tp - fp - fn
+    dice = 2.0 * tp / float(npred + ngt)
+    recall = tp / float(tp + fn) if (tp + fn) else 0.0
+    precision = tp / float(tp + fp) if (tp + fp) else 0.0
+    union = npred + ngt - tp
+    jc = tp / float(union) if union else 0.0
+    spec = tn / float(tn + fp) if (tn + fp) else 0.0
+    ravd = (npred - ngt) / float(ngt) if ngt else float("nan")
+    return [dice, float("nan"), recall, precision, jc, spec, ravd]
+
+
+def evaluate(args, model, dataloader, amp=False):
+    """flower_common.py:122-136."""
+    dev = next(model.parameters()).device
+    x, y = _batch_images(dataloader, args.img_class, dev)
+    was_training = model.training
+    model.eval()                                          # val_2D.py:40
+    with torch.no_grad():
+        logits = model(x)[0]
+    model.train(was_training) if was_training else None
+    counts = dice_table(logits, y, args.num_classes).cpu().numpy()
+    total = int(y.shape[-1] * y.shape[-2])
+    metric_list = np.zeros((args.num_classes - 1, len(VAL_METRICS)))
+    for i in range(counts.shape[0]):
+        metric_list += np.array([metrics_from_counts(*map(int, counts[i, c]), total)
+                                 for c in range(args.num_classes - 1)])
+    n_images = len(dataloader.dataset) if hasattr(dataloader, "dataset") else counts.shape[0]
+    metric_list = metric_list / n_images
+    metrics_ = {}
+    for class_i in range(args.num_classes - 1):
+        for mi, name in enumerate(VAL_METRICS):
+            metrics_["val_{}_{}".format(class_i + 1, name)] = metric_list[class_i, mi]
+    for mi, name in enumerate(VAL_METRICS):
+        metrics_["val_mean_{}".format(name)] = np.mean(metric_list, axis=0)[mi]
+    return metrics_
+
+
+# ------------------------------------------------------------------------------ model wrapper
+class MyModel(nn.Module):
+    """flower_common.py:458-633."""
+
+    def __init__(self, args, model, trainloader, valloader):
+        super().__init__()
+        self.args = args
+        self.model = model
+        self.trainloader = trainloader
+        self.valloader = valloader
+        self.amp = (getattr(args, "amp", 0) == 1)
+        if self.args.strategy in ["FedICRA"]:
+            self.start_phase = True
+        self.fedaa_weights = None
+        self.ala_epoch_losses: List[float] = []
+
+    def forward(self, x, emb_idx=None):
+        if emb_idx is None:
+            return self.model(x)
+        return self.model(x, emb_idx)
+
+    # -- weights I/O ----------------------------------------------------------------------------
+    def get_weights(self, config=None):
+        """List of numpy arrays in state_dict order (flower_common.py:488-489) -- the Flower wire format."""
+        return [val.detach().cpu().numpy() for _, val in self.model.state_dict().items()]
+
+    def get_device_weights(self) -> DeviceWeights:
+        return DeviceWeights(self.model.flat_state, self.model.flat_counters)
+
+    def _load_global(self, weights):
+        if isinstance(weights, DeviceWeights):
+            self.model.flat_state.copy_(weights.state)
+            self.model.flat_counters.copy_(weights.counters)
+        else:
+            sd = OrderedDict((k, torch.tensor(v)) for k, v in zip(self.model.state_dict().keys(), weights))
+            self.model.load_state_dict(sd, strict=False)      # int64 buffers: float64 -> truncation (quirk 6)
+
+    def _batch(self, sampled_batch):
+        dev = self.model.flat_state.device
+        if self.args.img_class == "faz":
+            x = sampled_batch["image"].unsqueeze(1)
+        else:
+            x = sampled_batch["image"]
+        return x.to(dev), sampled_batch["label"].to(dev)
+
+    def set_weights(self, weights, config):
+        if self.args.strategy not in ["FedICRA"]:
+            self._load_global(weights)                       # flower_common.py:627-633
+            return
+        # ---------------- FedICRA adaptive local aggregation, flower_common.py:494-624 -------------
+        eta, num_pre_loss, threshold = 1.0, 10, 0.1
+        net = self.model
+        old_local = net.flat_params.clone()                   # "server_model" deepcopy = OLD LOCAL weights (quirk 4)
+        self._load_global(weights)                            # self.model now holds the GLOBAL weights
+        glob = net.flat_params
+        first = next(iter(net.parameters()))
+        n0, o0 = first._fi_off, first.numel()
+        if torch.sum(old_local[n0:n0 + o0] - glob[n0:n0 + o0]) == 0:      # :520-522 (a sum test, as written)
+            return
+        if config["iter_global"] <= 50:                       # :524-526
+            print("skip", config)
+            return
+        local_keys = [n for n, _ in net.named_parameters() if any(k in n for k in ALA_KEYS)]
+        ranges = net.param_ranges(local_keys)
+        assert len(ranges) == 1, "decoder parameters are contiguous in the flat buffer"
+        s, e = ranges[0]
+        temp = copy.deepcopy(net)                             # :503 (own flat buffers, same train/eval mode)
+        for n, p in temp.named_parameters():                  # :542-546
+            p.requires_grad = n in local_keys
+        w = torch.ones(e - s, dtype=torch.float32, device=glob.device)     # re-initialised on every call (quirk 3)
+        tp, tg = temp.flat_params, temp.flat_grads
+        tp[s:e].copy_(old_local[s:e])                         # temp = global + (local - global) * 1
+        losses, count = [], 0
+        ncls = self.args.num_classes
+        while True:
+            loss = None
+            for sampled_batch in self.trainloader:            # :566-602
+                x, y = self._batch(sampled_batch)
+                temp.zero_grad()
+                out = temp(x)[0]
+                loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
+                loss.backward()
+                # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel)
+                L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta)
+            losses.append(float(loss.item()))
+            count += 1
+            print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,
+                  self.start_phase)
+            if not self.start_phase:                          # :611-612
+                break
+            if len(losses) > num_pre_loss and np.std(losses[-num_pre_loss:]) < threshold:      # :615
+                break
+        self.start_phase = False
+        glob[s:e].copy_(tp[s:e])                              # :623-624
+        self.fedaa_weights = w
+        self.ala_epoch_losses = losses
+
+
+# ------------------------------------------------------------------------------ client
+class BaseClient:
+    """flower_common.py:37-118 (fl.client.Client protocol)."""
+
+    def __init__(self, args, model, trainloader, valloader):
+        self.args = args
+        self.cid = args.cid
+        self.model = model
+        self.trainloader = trainloader
+        self.valloader = valloader
+        self.current_iter = 0
+        self.current_lr = self.args.base_lr
+        self.sampled_batches = []
+        self.properties = {"cid": self.cid}
+        self.best_performance = 0.0
+        self.amp = False
+
+    def get_parameters(self, ins):
+        weights = self.model.get_weights(getattr(ins, "config", None))
+        return fl.GetParametersRes(status=fl.Status("OK", "Success"), parameters=fl.ndarrays_to_parameters(weights))
+
+    def get_properties(self, ins):
+        return fl.GetPropertiesRes(status=fl.Status("OK", "Success"), properties=self.properties)
+
+    def fit(self, ins):
+        weights = ins.parameters if isinstance(ins.parameters, DeviceWeights) else fl.parameters_to_ndarrays(ins.parameters)
+        config = ins.config
+        fit_begin = timeit.default_timer()
+        self.model.set_weights(weights, config)
+        loss, metrics_ = self._train(config)
+        if isinstance(ins.parameters, DeviceWeights):
+            params_prime = self.model.get_device_weights()
+        else:
+            params_prime = fl.ndarrays_to_parameters(self.model.get_weights(config))
+        metrics_["fit_duration"] = timeit.default_timer() - fit_begin
+        return fl.FitRes(status=fl.Status("OK", "Success"), parameters=params_prime,
+                         num_examples=len(self.trainloader), metrics=metrics_)       # = number of BATCHES (quirk 5)
+
+    def evaluate(self, ins):
+        weights = ins.parameters if isinstance(ins.parameters, DeviceWeights) else fl.parameters_to_ndarrays(ins.parameters)
+        self.model.set_weights(weights, ins.config)          # FedICRA: re-runs an ALA epoch (quirk 9)
+        loss, metrics_ = self._validate(ins.config)
+        return fl.EvaluateRes(status=fl.Status("OK", "Success"), loss=loss, num_examples=len(self.valloader),
+                              metrics=metrics_)
+
+    def _train(self, config):
+        raise NotImplementedError
+
+    def _validate(self, config):
+        self.model.eval()
+        val_metrics = evaluate(self.args, self.model, self.valloader, self.amp)
+        if val_metrics["val_mean_dice"] > self.best_performance:
+            self.best_performance = val_metrics["val_mean_dice"]
+            snap = getattr(self.args, "snapshot_path", None)
+            if snap:                                          # flower_common.py:106-113 checkpoint names
+                sd = {k: v.detach().cpu().contiguous() for k, v in self.model.model.state_dict().items()}
+                torch.save(sd, os.path.join(snap, "client_{}_async_iter_{}_dice_{}.pth".format(
+                    self.cid, self.current_iter, round(self.best_performance, 4))))
+                torch.save(sd, os.path.join(snap, "client_{}_async_{}_best_model.pth".format(self.cid, self.args.model)))
+        return 0.0, {"client_{}_{}".format(self.cid, k): v for k, v in val_metrics.items()}
+
+
+# ------------------------------------------------------------------------------ server-side arithmetic
+def aggregate(results: Sequence[Tuple[Sequence[np.ndarray], int]]) -> List[np.ndarray]:
+    """flwr 1.0.0 ``aggregate`` on host arrays (compat path for a Flower server)."""
+    total = sum(n for _, n in results)
+    weighted = [[layer * n for layer in w] for w, n in results]
+    return [reduce(np.add, layers) / total for layers in zip(*weighted)]
+
+
+def aggregate_device(results: Sequence[Tuple[DeviceWeights, int]]) -> DeviceWeights:
+    """The same weighted mean over K flat device states held by ONE process (virtual clients):
+    acc = acc + (w_k * n_k) left to right, then / total -- numpy's order and roundings (fi_axpy / fi_scale)."""
+    total = sum(n for _, n in results)
+    first = results[0][0].state
+    acc = torch.empty_like(first)
+    L.scale(first, acc, float(results[0][1]))
+    for dw, n in results[1:]:
+        L.axpy(acc, dw.state, float(n))
+    L.scale(acc, acc, float(total), divide=True)
+    cnt = sum(dw.counters * int(n) for dw, n in results)      # int64 sum, then true divide -> float64 -> truncate
+    counters = (cnt.double() / total).to(torch.int64)
+    return DeviceWeights(acc, counters)
+
+
+class FedAvg:
+    """The slice of flwr.server.strategy.FedAvg the reference uses (aggregate_fit, weights = num_examples)."""
+
+    def __init__(self, fit_metrics_aggregation_fn=None, evaluate_metrics_aggregation_fn=None, accept_failures=False,
+                 **kwargs):
+        self.fit_metrics_aggregation_fn = fit_metrics_aggregation_fn
+        self.evaluate_metrics_aggregation_fn = evaluate_metrics_aggregation_fn
+        self.accept_failures = accept_failures
+        self.kwargs = kwargs
+
+    def aggregate_fit(self, server_round, results, failures):
+        if not results:
+            return None, {}
+        if not self.accept_failures and failures:
+            return None, {}
+        res = [r for _, r in results]
+        if isinstance(res[0].parameters, DeviceWeights):
+            agg = aggregate_device([(r.parameters, r.num_examples) for r in res])
+        else:
+            agg = fl.ndarrays_to_parameters(aggregate([(fl.parameters_to_ndarrays(r.parameters), r.num_examples)
+                                                       for r in res]))
+        metrics = {}
+        if self.fit_metrics_aggregation_fn:
+            metrics = self.fit_metrics_aggregation_fn([(r.num_examples, r.metrics) for r in res])
+        return agg, metrics
+
+    def aggregate_evaluate(self, server_round, results, failures):
+        if not results:
+            return None, {}
+        res = [r for _, r in results]
+        total = sum(r.num_examples for r in res)
+        loss = sum(r.num_examples * r.loss for r in res) / total
+        metrics = {}
+        if self.evaluate_metrics_aggregation_fn:
+            metrics = self.evaluate_metrics_aggregation_fn([(r.num_examples, r.metrics) for r in res])
+        return loss, metrics
+
+    def __repr__(self):
+        return f"FedAvg(accept_failures={self.accept_failures})"
+
+
+class FedICRA(FedAvg):
+    """flower_common.py:451-455: server side is plain FedAvg; the adaptive part lives in MyModel.set_weights."""
+
+    def __repr__(self):
+        return f"FedICRA(accept_failures={self.accept_failures})"
+
+
+def get_strategy(name, **kwargs):
+    assert name in (CENTRALIZED_FL + PERSONALIZED_FL)
+    if name == "FedAvg":
+        return FedAvg(**kwargs)
+    if name == "FedICRA":
+        return FedICRA(**kwargs)
+    raise NotImplementedError(name + " (FedAdagrad/FedAdam/FedYogi server optimizers are outside the hot path)")
+
+
+def fit_metrics_aggregation_fn(fit_metrics):
+    return {k: v for _, client_metrics in fit_metrics for k, v in client_metrics.items()}
+
+
+def get_evaluate_metrics_aggregation_fn(args, val_metrics):
+    """flower_common.py:398-428: example-weighted and unweighted means of client_{i}_val_*."""
+    def evaluate_metrics_aggregation_fn(evaluate_metrics):
+        metrics = {k: v for _, cm in evaluate_metrics for k, v in cm.items()}
+        weights = {}
+        for client_id in range(args.min_num_clients):
+            first = "client_{}_val_mean_{}".format(client_id, val_metrics[0])
+            for n_ex, cm in evaluate_metrics:
+                if first in cm:
+                    weights["client_{}".format(client_id)] = n_ex
+
+        def weighted_metric(name):
+            tot = sum(weights.values())
+            return sum(weights["client_{}".format(c)] * metrics["client_{}_{}".format(c, name)]
+                       for c in range(args.min_num_clients)) / tot
+
+        def mean_metric(name):
+            return np.mean([metrics["client_{}_{}".format(c, name)] for c in range(args.min_num_clients)])
+
+        metrics.update({"val_{}_{}".format(ci + 1, m): weighted_metric("val_{}_{}".format(ci + 1, m))
+                        for ci in range(args.num_classes - 1) for m in val_metrics})
+        metrics.update({"val_mean_{}".format(m): weighted_metric("val_mean_{}".format(m)) for m in val_metrics})
+        metrics.update({"val_avg_mean_{}".format(m): mean_metric("val_mean_{}".format(m)) for m in val_metrics})
+        return metrics
+    return evaluate_metrics_aggregation_fn

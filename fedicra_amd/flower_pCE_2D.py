@@ -1,0 +1,178 @@
+"""Local training procedure (pCE [+ LC] loss) with the reference's ``MyClient._train`` contract.
+
+Mirrors /root/reference/code/flower_pCE_2D.py:42-181: fresh AdamW per round, epoch
+pre-materialisation of the batch list, FedICRA freeze schedule and LC loss, poly LR after every
+iteration, the same metrics dict.  MI355X-native differences:
+
+  * forward / loss / backward / optimizer are the hand-written HIP kernels (fedicra_amd.ops);
+  * the optimizer is one fused kernel over the flat parameter buffer with device-resident lr and
+    step counters (fedicra_amd.optim), so the WHOLE iteration -- zero-grad, forward, CE,
+    backward, AdamW, LR update -- is captured once per freeze pattern into a hipGraph
+    (``args.use_graph``) and replayed; per-iteration losses stay on the device and are read back
+    once per round instead of the reference's ``loss.item()`` sync every iteration (:152);
+  * batches are staged into static device buffers (the graph's inputs).
+
+Reference defect handled: :117-118 unpacks UNet_LC's 8 outputs into 7 names; here the
+logits are ``out[0]`` and the heat-maps ``out[6]``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import fl, ops
+from .flower_common import BaseClient
+from .optim import FusedAdamW
+
+
+class _GraphStep:
+    """One captured training iteration for one freeze pattern."""
+
+    def __init__(self):
+        self.graph = None
+        self.loss = None
+        self.loss_ce = None
+        self.loss_lc = None
+        self.logits = None
+
+
+class MyClient(BaseClient):
+
+    def __init__(self, args, model, trainloader, valloader, amp=False):
+        super().__init__(args, model, trainloader, valloader)
+        self.amp = amp
+        self.best_performance = 0.0
+        self.use_graph = bool(getattr(args, "use_graph", False))
+        self.optimizer = None
+        self._steps = {}
+        self._xbuf = self._ybuf = None
+        self.last_losses = []
+
+    # ---------------------------------------------------------------------------------- helpers
+    def _net(self):
+        return self.model.model
+
+    def _ensure_optimizer(self):
+        if self.optimizer is None:
+            self.optimizer = FusedAdamW(self._net(), lr=self.current_lr, base_lr=self.args.base_lr,
+                                        max_iterations=self.args.max_iterations)
+            ops.set_dropout_seed_offset(self.optimizer.iter)
+        return self.optimizer
+
+    def _stage(self, sampled_batch):
+        """Copy one batch into the static device buffers (graph inputs)."""
+        dev = self._net().flat_state.device
+        x, y = sampled_batch["image"], sampled_batch["label"]
+        if self.args.img_class == "faz":
+            x = x.unsqueeze(1)                               # flower_pCE_2D.py:77
+        if self._xbuf is None or self._xbuf.shape != x.shape:
+            self._xbuf = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            self._ybuf = torch.empty(y.shape, dtype=torch.uint8, device=dev)
+            self._steps = {}
+        self._xbuf.copy_(x, non_blocking=True)
+        self._ybuf.copy_(y, non_blocking=True)
+        return self._xbuf, self._ybuf
+
+    def _set_freeze(self, i_iter):
+        """flower_pCE_2D.py:84-101.  Returns a hashable pattern id."""
+        if self.args.strategy not in ["FedICRA"]:
+            return "all"
+        local_keys = ["decoder.out_conv.weight", "decoder.out_conv.bias"]
+        head_phase = i_iter < self.args.iters - self.args.rep_iters
+        for name, param in self.model.named_parameters():
+            param.requires_grad = (name.replace("model.", "") in local_keys) == head_phase
+        return "head" if head_phase else "body"
+
+    def _iteration(self, x, y, rec: _GraphStep):
+        """zero-grad, forward, loss, backward, optimizer step, LR update -- all device work."""
+        args = self.args
+        opt = self.optimizer
+        opt.zero_grad()
+        out = self.model(x)
+        logits = out[0]
+        loss_ce = ops.ce_loss(logits.permute(0, 2, 3, 1), y, args.num_classes)       # :124
+        loss = loss_ce
+        loss_lc = None
+        if args.strategy in ["FedICRA"]:                                             # :128-139
+            heatmaps = out[6]
+            acc = 0
+            for other_client in range(args.min_num_clients):
+                if other_client == args.cid:
+                    continue
+                with torch.no_grad():
+                    _heatmaps = self.model(x, other_client)[6]
+                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], _heatmaps[-1].detach())
+            loss_lc = -acc / (args.min_num_clients - 1)
+            loss = torch.add(loss, loss_lc, alpha=args.alpha)
+        loss.backward()
+        opt.step()
+        opt.advance_lr()
+        rec.loss, rec.loss_ce, rec.loss_lc, rec.logits = loss.detach(), loss_ce.detach(), \
+            (None if loss_lc is None else loss_lc.detach()), logits.detach()
+
+    # ---------------------------------------------------------------------------------- _train
+    def _train(self, config):
+        args = self.args
+        self.model.train()
+        opt = self._ensure_optimizer()
+        opt.reset_round()                                    # fresh AdamW every round (:55)
+        opt.set_lr(self.current_lr, self.current_iter)
+        iters = config["iters"]
+        dev = self._net().flat_state.device
+        hist = torch.zeros((iters, 3), dtype=torch.float32, device=dev)
+        n_b = len(self.trainloader)
+        rec = None
+        for i_iter in range(iters):
+            if self.current_iter % n_b == 0:                 # :66-70 epoch pre-materialisation
+                self.sampled_batches.clear()
+                for sampled_batch in self.trainloader:
+                    self.sampled_batches.append(sampled_batch)
+            sampled_batch = self.sampled_batches[self.current_iter % n_b]
+            x, y = self._stage(sampled_batch)
+            pattern = self._set_freeze(i_iter)
+            if self.use_graph:
+                rec = self._steps.get(pattern)
+                if rec is None:
+                    rec = _GraphStep()
+                    self._iteration(x, y, rec)               # first use of a pattern runs eagerly (real step)
+                    self._steps[pattern] = rec
+                elif rec.graph is None:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):                # records only; nothing executes
+                        self._iteration(x, y, rec)
+                    rec.graph = g
+                    g.replay()
+                else:
+                    rec.graph.replay()
+            else:
+                rec = _GraphStep()
+                self._iteration(x, y, rec)
+            hist[i_iter, 0] = rec.loss
+            hist[i_iter, 1] = rec.loss_ce
+            if rec.loss_lc is not None:
+                hist[i_iter, 2] = rec.loss_lc
+            self.current_iter += 1
+            lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
+            self.current_lr = lr_
+        h = hist.cpu().numpy()                               # ONE sync per round
+        self.last_losses = h[:, 0].tolist()
+        # ---- pack general metrics (:160-175)
+        image = x[1, :, :, :]
+        image = (image - image.min()) / (image.max() - image.min())
+        pred = torch.argmax(torch.softmax(rec.logits, dim=1), dim=1, keepdim=True)
+        pred = pred[1, ...] * 50
+        labs = y[1, ...].unsqueeze(0) * 50
+        if args.img_class in ("odoc", "polyp"):
+            pred, labs = pred.repeat(3, 1, 1), labs.repeat(3, 1, 1)
+        metrics_ = {
+            "client_{}_lr".format(self.cid): self.current_lr,
+            "client_{}_total_loss".format(self.cid): float(h[-1, 0]),
+            "client_{}_loss_ce".format(self.cid): float(h[-1, 1]),
+            "client_{}_Image".format(self.cid): fl.ndarray_to_bytes(image.cpu().numpy()),
+            "client_{}_Prediction".format(self.cid): fl.ndarray_to_bytes(pred.cpu().numpy()),
+            "client_{}_GroundTruth".format(self.cid): fl.ndarray_to_bytes(labs.cpu().numpy()),
+        }
+        if args.strategy in ["FedICRA"]:
+            metrics_["client_{}_loss_lc".format(self.cid)] = float(h[-1, 2])
+        return float(h[-1, 0]), metrics_

@@ -1,0 +1,374 @@
+"""MI355X-native 2D U-Net family with the reference's module surface.
+
+Drop-in for /root/reference/code/networks/unet.py: same class names, constructor signatures,
+``forward`` return lists and ``state_dict()`` keys/shapes (the federated wire format), but every
+op underneath is a hand-written gfx950 HIP kernel reached through the C ABI
+(include/fedicra_hip.h) -- no ATen conv/BN/pool kernels on the path.
+
+Layout: tensors carry the reference's logical NCHW shape, with channels_last strides (dense NHWC
+memory).  Sub-modules can therefore be chained or called individually exactly like the
+reference's, and the permutes are zero-copy views.  nn.Conv2d / nn.BatchNorm2d objects are used
+only as parameter containers (same default init, same state_dict keys); their ATen forward is
+never called.
+
+Reference quirks kept on purpose: UpBlock's dead ConvTranspose2d branch is
+never built because every decoder uses the default ``bilinear=True`` (unet.py:216-223);
+LCEncoder.pcs_list is a plain list (unregistered PCS weights, unet.py:172-177);
+``if not emb_idx`` (unet.py:186).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..flat import FlatStoreMixin
+
+FEATURE_CHNS = [16, 32, 64, 128, 256]
+DROPOUT = [0.05, 0.1, 0.2, 0.3, 0.5]
+
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def default_compute_dtype():
+    return _DTYPES[os.environ.get("FEDICRA_DTYPE", "fp32")]
+
+
+class _FiModule(nn.Module):
+    """Base: knows the compute dtype and converts NCHW-shaped tensors <-> dense NHWC."""
+
+    _fi_dtype = None   # set on the root by set_compute_dtype(); modules fall back to the default
+
+    def compute_dtype(self):
+        return self._fi_dtype if self._fi_dtype is not None else default_compute_dtype()
+
+    def _in(self, x):
+        """NCHW-shaped tensor (any strides / fp32 or compute dtype) -> dense NHWC compute-dtype tensor."""
+        dt = self.compute_dtype()
+        v = x.permute(0, 2, 3, 1)
+        if x.dtype == dt and v.is_contiguous():
+            return v
+        if x.requires_grad:                       # differentiable slow path (plumbing only)
+            return v.contiguous().to(dt)
+        return ops.to_nhwc(x, dt)
+
+    @staticmethod
+    def _out(y):
+        return y.permute(0, 3, 1, 2)
+
+
+def set_compute_dtype(model: nn.Module, dtype):
+    dt = _DTYPES[dtype] if isinstance(dtype, str) else dtype
+    for m in model.modules():
+        if isinstance(m, _FiModule):
+            m._fi_dtype = dt
+    for pcs in getattr(getattr(model, "encoder", None), "pcs_list", []):
+        for m in pcs.modules():
+            if isinstance(m, _FiModule):
+                m._fi_dtype = dt
+    return model
+
+
+class ConvBlock(_FiModule):
+    """two convolution layers with batch norm and leaky relu (unet.py:14-30)."""
+
+    def __init__(self, in_channels, out_channels, dropout_p):
+        super().__init__()
+        # indices 0,1,4,5 hold state exactly like the reference's nn.Sequential
+        self.conv_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels),
+            nn.LeakyReLU(), nn.Dropout(dropout_p),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels),
+            nn.LeakyReLU())
+        self.dropout_p = dropout_p
+
+    def _run(self, x0, x1=None):
+        s = self.conv_conv
+        z = ops.conv_bn_act(x0, x1, s[0], s[1], s[2].negative_slope, self.dropout_p, "elem")
+        return ops.conv_bn_act(z, None, s[4], s[5], s[6].negative_slope, 0.0)
+
+    def forward(self, x):
+        return self._out(self._run(self._in(x)))
+
+
+class DownBlock(_FiModule):
+    """Downsampling followed by ConvBlock (unet.py:34-46)."""
+
+    def __init__(self, in_channels, out_channels, dropout_p):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), ConvBlock(in_channels, out_channels, dropout_p))
+
+    def _run(self, x):
+        return self.maxpool_conv[1]._run(ops.maxpool2(x))
+
+    def forward(self, x):
+        return self._out(self._run(self._in(x)))
+
+
+class UpBlock(_FiModule):
+    """Upsampling followed by ConvBlock (unet.py:49-70).  The concat is folded into the conv gather."""
+
+    def __init__(self, in_channels1, in_channels2, out_channels, dropout_p, bilinear=True):
+        super().__init__()
+        self.bilinear = bilinear
+        if not bilinear:
+            raise NotImplementedError("ConvTranspose2d branch (unet.py:60-62) is dead code in the reference: "
+                                      "every decoder passes the default bilinear=True")
+        self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
+
+    def _run(self, x1, x2):
+        up = ops.upsample2x(ops.conv2d(x1, None, self.conv1x1))
+        return self.conv._run(x2, up)            # == ConvBlock(cat([x2, up], dim=1))
+
+    def forward(self, x1, x2):
+        return self._out(self._run(self._in(x1), self._in(x2)))
+
+
+class Encoder(_FiModule):
+    """unet.py:73-100."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.in_chns, self.ft_chns = params["in_chns"], params["feature_chns"]
+        self.n_class, self.bilinear, self.dropout = params["class_num"], params["bilinear"], params["dropout"]
+        assert len(self.ft_chns) == 5
+        c, p = self.ft_chns, self.dropout
+        self.in_conv = ConvBlock(self.in_chns, c[0], p[0])
+        self.down1 = DownBlock(c[0], c[1], p[1])
+        self.down2 = DownBlock(c[1], c[2], p[2])
+        self.down3 = DownBlock(c[2], c[3], p[3])
+        self.down4 = DownBlock(c[3], c[4], p[4])
+
+    def _run(self, x):
+        x0 = self.in_conv._run(x)
+        x1 = self.down1._run(x0)
+        x2 = self.down2._run(x1)
+        x3 = self.down3._run(x2)
+        x4 = self.down4._run(x3)
+        return [x0, x1, x2, x3, x4]
+
+    def forward(self, x):
+        return [self._out(f) for f in self._run(self._in(x))]
+
+
+class PersonalizedChannelSelection(_FiModule):
+    """unet.py:103-144.  fc layers are 1x1 convs on [B,C,1,1] vectors -> the same conv kernel."""
+
+    def __init__(self, f_dim, emb_dim):
+        super().__init__()
+        self.fc1 = nn.Sequential(nn.Conv2d(emb_dim, f_dim, 1, bias=False), nn.ReLU(),
+                                 nn.Conv2d(f_dim, f_dim, 1, bias=False))
+        self.fc2 = nn.Sequential(nn.Conv2d(f_dim * 2, f_dim // 16, 1, bias=False), nn.ReLU(),
+                                 nn.Conv2d(f_dim // 16, f_dim, 1, bias=False))
+
+    @staticmethod
+    def _mlp(seq, v0, v1=None):
+        """v*: fp32 [B,1,1,C] NHWC vectors (fc math stays fp32: it is ~100 kFLOP)."""
+        h = torch.relu(ops.conv2d(v0, v1, seq[0]))
+        return ops.conv2d(h, None, seq[2])
+
+    def forward_emb(self, emb):
+        return self._mlp(self.fc1, emb.reshape(emb.shape[0], 1, 1, -1).float())
+
+    def _run(self, x, emb):
+        B, H, W, C = x.shape
+        avg, mx = ops.global_avgmax(x)                       # [B,C] fp32 each
+        e = self.forward_emb(emb)                            # [B,1,1,C]
+        a = self._mlp(self.fc2, avg.reshape(B, 1, 1, C), e)  # cat([avg, emb], 1) folded into the gather
+        m = self._mlp(self.fc2, mx.reshape(B, 1, 1, C), e)
+        hmap = torch.sigmoid(a + m)                          # [B,1,1,C]
+        return ops.channel_gate(x, hmap.reshape(B, C)), hmap
+
+    def forward(self, x, emb):
+        y, h = self._run(self._in(x), emb)
+        return self._out(y), self._out(h)
+
+
+class LCEncoder(_FiModule):
+    """unet.py:146-203."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.in_chns, self.ft_chns = params["in_chns"], params["feature_chns"]
+        self.n_class, self.bilinear, self.dropout = params["class_num"], params["bilinear"], params["dropout"]
+        self.n_pcs, self.n_emb = params["pcs_num"], params["emb_num"]
+        self.n_client, self.cid = params["client_num"], params["client_id"]
+        assert len(self.ft_chns) == 5
+        c, p = self.ft_chns, self.dropout
+        self.in_conv = ConvBlock(self.in_chns, c[0], p[0])
+        self.down1 = DownBlock(c[0], c[1], p[1])
+        self.down2 = DownBlock(c[1], c[2], p[2])
+        self.down3 = DownBlock(c[2], c[3], p[3])
+        self.down4 = DownBlock(c[3], c[4], p[4])
+        self.conv_list = [self.in_conv, self.down1, self.down2, self.down3, self.down4]
+        # plain python list on purpose: unregistered like the reference (quirk 1)
+        self.pcs_list = [PersonalizedChannelSelection(c[5 - self.n_pcs + i], self.n_emb) for i in range(self.n_pcs)]
+        for pcs in self.pcs_list:                # never optimised / communicated in the reference: skip their wgrad
+            for q in pcs.parameters():
+                q.requires_grad_(False)
+
+    def _apply(self, fn, *a, **k):
+        for pcs in self.pcs_list:                # the reference moves them with an explicit .cuda() (unet.py:176)
+            pcs._apply(fn, *a, **k)
+        return super()._apply(fn, *a, **k)
+
+    def _run(self, x, emb_idx=None):
+        who = self.cid if not emb_idx else emb_idx           # unet.py:186 (quirk 2: 0 means "own")
+        emb = torch.zeros((x.shape[0], self.n_client), device=x.device)
+        emb[:, who] = 1
+        feats, hmaps = [], []
+        n = len(self.conv_list)
+        for i, blk in enumerate(self.conv_list):
+            x = blk._run(x)
+            h = None
+            if i >= n - self.n_pcs:
+                x, h = self.pcs_list[i - n + self.n_pcs]._run(x, emb)
+            feats.append(x)
+            hmaps.append(h)
+        return feats, hmaps
+
+    def forward(self, x, emb_idx=None):
+        f, h = self._run(self._in(x), emb_idx)
+        return [self._out(t) for t in f], [None if t is None else self._out(t) for t in h]
+
+
+def _dsn_head(cin, n_class):
+    return nn.Sequential(nn.Conv2d(cin, 512, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(512), nn.ReLU(),
+                         nn.Dropout2d(0.10), nn.Conv2d(512, n_class, kernel_size=1, stride=1, padding=0, bias=False))
+
+
+def _run_head(seq, x):
+    z = ops.conv_bn_act(x, None, seq[0], seq[1], 0.0, seq[3].p, "chan")      # ReLU = slope 0; Dropout2d
+    return ops.conv2d(z, None, seq[4], y_f32=True)
+
+
+class _DecoderBase(_FiModule):
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.in_chns, self.ft_chns = params["in_chns"], params["feature_chns"]
+        self.n_class, self.bilinear = params["class_num"], params["bilinear"]
+        assert len(self.ft_chns) == 5
+        c = self.ft_chns
+        self.up1 = UpBlock(c[4], c[3], c[3], dropout_p=0.0)
+        self.up2 = UpBlock(c[3], c[2], c[2], dropout_p=0.0)
+        self.up3 = UpBlock(c[2], c[1], c[1], dropout_p=0.0)
+        self.up4 = UpBlock(c[1], c[0], c[0], dropout_p=0.0)
+        self.out_conv = nn.Conv2d(c[0], self.n_class, kernel_size=3, padding=1)
+
+    def _trunk(self, f):
+        x_1 = self.up1._run(f[4], f[3])
+        x_2 = self.up2._run(x_1, f[2])
+        x_3 = self.up3._run(x_2, f[1])
+        x_4 = self.up4._run(x_3, f[0])
+        output = ops.conv2d(x_4, None, self.out_conv, y_f32=True)    # logits always fp32
+        return [output, x_1, x_2, x_3, x_4]
+
+    def _run(self, f):
+        return self._trunk(f)
+
+    def forward(self, feature):
+        return tuple(self._out(t) for t in self._run([self._in(t) for t in feature]))
+
+
+class Decoder(_DecoderBase):
+    """unet.py:206-240."""
+
+
+class Decoder_Head(_DecoderBase):
+    """unet.py:243-285."""
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.dsn_head = _dsn_head(self.ft_chns[2], self.n_class)
+
+    def _run(self, f):
+        o = self._trunk(f)
+        return o + [_run_head(self.dsn_head, o[2])]
+
+
+class Decoder_MultiHead(_DecoderBase):
+    """unet.py:288-346."""
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.dsn_head1 = _dsn_head(self.ft_chns[2], self.n_class)
+        self.dsn_head2 = _dsn_head(self.ft_chns[1], self.n_class)
+        self.dsn_head3 = _dsn_head(self.ft_chns[0], self.n_class)
+
+    def _run(self, f):
+        o = self._trunk(f)
+        return o + [_run_head(self.dsn_head1, o[2]), _run_head(self.dsn_head2, o[3]), _run_head(self.dsn_head3, o[4])]
+
+
+def _params(in_chns, class_num, **extra):
+    p = {"in_chns": in_chns, "feature_chns": list(FEATURE_CHNS), "dropout": list(DROPOUT), "class_num": class_num,
+         "bilinear": False, "acti_func": "relu"}          # 'bilinear': False is stored but never forwarded (quirk)
+    p.update(extra)
+    return p
+
+
+class _UNetBase(FlatStoreMixin, _FiModule):
+    _decoder_cls = Decoder
+
+    def __init__(self, in_chns, class_num):
+        super().__init__()
+        params = _params(in_chns, class_num)
+        self.encoder = Encoder(params)
+        self.decoder = self._decoder_cls(params)
+        self._fi_finish_init()
+
+    def forward(self, x):
+        self._fi_check_flat()
+        f = self.encoder._run(self._in(x))
+        o = self.decoder._run(f)
+        return [self._out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:]]
+
+
+class UNet(_UNetBase):
+    """unet.py:549-566: returns [output, feature, de1, de2, de3, de4]."""
+
+
+class UNet_Head(_UNetBase):
+    """unet.py:640-656: + aux_output."""
+    _decoder_cls = Decoder_Head
+
+
+class UNet_MultiHead(_UNetBase):
+    """unet.py:659-675: + aux_output1..3."""
+    _decoder_cls = Decoder_MultiHead
+
+
+class _UNetLCBase(FlatStoreMixin, _FiModule):
+    _decoder_cls = Decoder_Head
+
+    def __init__(self, in_chns, class_num, pcs_num, emb_num, client_num, client_id):
+        super().__init__()
+        params = _params(in_chns, class_num, pcs_num=pcs_num, emb_num=emb_num, client_num=client_num,
+                         client_id=client_id)
+        self.encoder = LCEncoder(params)
+        self.decoder = self._decoder_cls(params)
+        self._fi_finish_init()
+
+    def forward(self, x, emb_idx=None):
+        self._fi_check_flat()
+        f, h = self.encoder._run(self._in(x), emb_idx)
+        o = self.decoder._run(f)
+        hm = [None if t is None else self._out(t) for t in h]
+        return [self._out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + \
+               [self._out(t) for t in o[5:]]
+
+
+class UNet_LC(_UNetLCBase):
+    """unet.py:678-699: [output, feature, de1..de4, heatmap, aux_output]."""
+
+
+class UNet_LC_MultiHead(_UNetLCBase):
+    """unet.py:701-722: [output, feature, de1..de4, heatmap, aux_output1..3]."""
+    _decoder_cls = Decoder_MultiHead

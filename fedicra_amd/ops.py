@@ -1,0 +1,353 @@
+"""torch.autograd.Function wrappers over the C ABI (include/fedicra_hip.h).
+
+Internal tensor convention: activations are dense NHWC tensors ``[N,H,W,C]`` in the compute
+dtype (float32 = exact-fp32 parity mode, bfloat16 = performance mode); parameters are always
+fp32, conv weights logically ``[Cout,Cin,k,k]`` with channels_last strides (memory
+``[Cout][k][k][Cin]``).  The nn.Modules in fedicra_amd/networks present the reference's NCHW
+surface as zero-copy permuted views.
+
+Weight gradients use a *grad sink*: parameters created by ``FlatStore`` carry ``_fi_gview`` (a
+view into one flat fp32 gradient buffer).  backward() accumulates straight into it (the wgrad
+kernel adds atomically, i.e. autograd's ``+=`` semantics), sets ``p.grad`` to that view and
+returns None for the parameter, so that the fused AdamW and the RCCL aggregation run over
+flat buffers.  Parameters without a sink get an ordinary returned gradient.
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+# ----------------------------------------------------------------------------- dropout control
+_drop_seed = itertools.count(0x5EED)
+_mask_provider = None          # parity mode: callable(shape_nchw, p) -> uint8/bool/float keep mask (NCHW, any device)
+_seed_offset = None            # device int32[1] added to every RNG seed (training-iteration counter)
+
+
+def set_dropout_mask_provider(fn):
+    """Parity mode: dropout masks come from ``fn(shape_nchw, p)`` instead of the device RNG."""
+    global _mask_provider
+    _mask_provider = fn
+
+
+def set_dropout_seed_offset(t):
+    """Device int32[1] mixed into every dropout seed; lets a replayed hipGraph draw fresh masks."""
+    global _seed_offset
+    _seed_offset = t
+
+
+def manual_seed(seed: int):
+    global _drop_seed
+    _drop_seed = itertools.count(int(seed) * 0x9E3779B1 + 0x5EED)
+
+
+def _drop_spec(p, kind, N, H, W, Cc, device):
+    """kind: 'elem' (nn.Dropout) or 'chan' (nn.Dropout2d).  Returns the tuple _lib._bnact expects."""
+    if p <= 0.0:
+        return None
+    if _mask_provider is not None:
+        shape = (N, Cc, H, W) if kind == "elem" else (N, Cc, 1, 1)
+        m = _mask_provider(shape, p)
+        m = (m != 0).to(torch.uint8)
+        m = m.permute(0, 2, 3, 1).contiguous().to(device) if kind == "elem" else m.reshape(N, Cc).contiguous().to(device)
+        return (L.DROP_MASK_ELEM if kind == "elem" else L.DROP_MASK_CHAN, float(p), 0, m, None)
+    return (L.DROP_RNG_ELEM if kind == "elem" else L.DROP_RNG_CHAN, float(p), next(_drop_seed), None, _seed_offset)
+
+
+# ----------------------------------------------------------------------------- helpers
+def _krsc(w):
+    """[Cout,Cin,k,k] parameter -> dense [Cout,k,k,Cin] view (copy only if not channels_last)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _grad_target(p, like=None):
+    """Returns (dense fp32 tensor to accumulate into, fresh: bool, returned_grad or None)."""
+    sink = getattr(p, "_fi_gview", None)
+    if sink is None:
+        g = torch.zeros_like(p if like is None else like, dtype=torch.float32, memory_format=torch.preserve_format)
+        return g, True, g
+    if p.grad is None:
+        if not getattr(p, "_fi_zeroed", False):     # FlatStoreMixin.zero_grad() zeroes all sinks in one memset
+            sink.zero_()
+        p._fi_zeroed = False
+        p.grad = sink
+        return sink, True, None
+    if p.grad.data_ptr() != sink.data_ptr():
+        g = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+        return g, True, g
+    return sink, False, None
+
+
+def _packed(wk, dtype, mode, cout, kk, cin):
+    """fp32 KRSC weight -> operand in `dtype` (mode 0) or flipped/transposed dgrad operand (mode 1)."""
+    if mode == 0 and dtype == torch.float32:
+        return wk
+    out = torch.empty(cout * kk * cin, dtype=dtype, device=wk.device)
+    L.pack_weights(wk, out, cout, kk, cin, mode)
+    return out
+
+
+def _conv_backward(ctx, dy, x0, x1, wk, mod):
+    """Shared by _Conv and _ConvBNAct: returns (dx0, dx1, gw, gb)."""
+    ksize, cout, cin = ctx.ksize, wk.shape[0], wk.shape[3]
+    kk = ksize * ksize
+    dx0 = dx1 = gw = gb = None
+    need_x0, need_x1 = ctx.need_x0, ctx.need_x1
+    if need_x0 or need_x1:
+        wt = _packed(wk, dy.dtype, 1, cout, kk, cin)
+        N, H, W, _ = dy.shape
+        # dgrad = conv of dy with the flipped/transposed filter; two destinations for a concat input
+        d0 = torch.empty((N, H, W, x0.shape[3]), dtype=dy.dtype, device=dy.device)
+        d1 = None if x1 is None else torch.empty((N, H, W, x1.shape[3]), dtype=dy.dtype, device=dy.device)
+        L.conv2d_fwd(dy, None, wt, None, d0, d1, None, ksize=ksize, tag="conv_dgrad")
+        dx0 = d0 if need_x0 else None
+        dx1 = d1 if need_x1 else None
+    if ctx.need_w or ctx.need_b:
+        if ctx.need_w:
+            wt_, fresh, gw = _grad_target(mod.weight)
+            dw = wt_.permute(0, 2, 3, 1)
+            if not dw.is_contiguous():            # foreign layout: accumulate in a KRSC scratch
+                scratch = torch.zeros(wk.shape, dtype=torch.float32, device=dy.device)
+                dw = scratch
+        else:
+            dw = torch.zeros(wk.shape, dtype=torch.float32, device=dy.device)   # kernel needs a dw target
+        db = None
+        if ctx.need_b:
+            db, _, gb = _grad_target(mod.bias)
+        L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=ksize)
+        if ctx.need_w and dw.data_ptr() != wt_.data_ptr():
+            wt_.add_(dw.permute(0, 3, 1, 2))
+    return dx0, dx1, gw, gb
+
+
+class _Conv(Function):
+    """y = conv(cat(x0,x1)) + bias  (out_conv, conv1x1, head 1x1, PCS fc layers)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, mod, y_f32):
+        wk = _krsc(weight)
+        cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+        N, H, W, _ = x0.shape
+        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin)
+        y = torch.empty((N, H, W, cout), dtype=torch.float32 if y_f32 else x0.dtype, device=x0.device)
+        L.conv2d_fwd(x0, x1, wp, bias, y, None, None, ksize=ksize, y_f32=y_f32)
+        ctx.save_for_backward(x0, x1, wk)
+        ctx.mod, ctx.ksize, ctx.y_f32 = mod, ksize, y_f32
+        ctx.need_x0 = ctx.needs_input_grad[0]
+        ctx.need_x1 = x1 is not None and ctx.needs_input_grad[1]
+        ctx.need_w = ctx.needs_input_grad[2]
+        ctx.need_b = bias is not None and ctx.needs_input_grad[3]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, wk = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x0.dtype:
+            t = torch.empty(dy.shape, dtype=x0.dtype, device=dy.device)
+            L.cast(dy, t)
+            dy = t
+        dx0, dx1, gw, gb = _conv_backward(ctx, dy, x0, x1, wk, ctx.mod)
+        return dx0, dx1, gw, gb, None, None
+
+
+class _ConvBNAct(Function):
+    """z = dropout(act(BN(conv(cat(x0,x1)) + bias)))  -- one ConvBlock half (unet.py:19-27)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, gamma, beta, mod, bn, slope, drop_p, drop_kind):
+        wk = _krsc(weight)
+        cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+        N, H, W, _ = x0.shape
+        dev = x0.device
+        training = bn.training
+        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin)
+        y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev)
+        stats = torch.zeros(cout * 2, dtype=torch.float64, device=dev) if training else None
+        L.conv2d_fwd(x0, x1, wp, bias, y, None, stats, ksize=ksize)
+        coef = torch.empty(4, cout, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
+        L.bn_finalize(stats, float(N * H * W), gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                      bn.momentum, bn.eps, training, coef[0], coef[1], coef[2], coef[3])
+        drop = _drop_spec(drop_p, drop_kind, N, H, W, cout, dev) if training else None
+        z = torch.empty_like(y)
+        L.bn_act_fwd(y, coef[0], coef[1], z, slope, drop)
+        ctx.save_for_backward(x0, x1, wk, y, coef)
+        ctx.mod, ctx.bn, ctx.ksize, ctx.slope, ctx.drop, ctx.training = mod, bn, ksize, slope, drop, training
+        ctx.need_x0 = ctx.needs_input_grad[0]
+        ctx.need_x1 = x1 is not None and ctx.needs_input_grad[1]
+        ctx.need_w = ctx.needs_input_grad[2]
+        ctx.need_b = bias is not None and ctx.needs_input_grad[3]
+        ctx.need_g, ctx.need_be = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, x1, wk, y, coef = ctx.saved_tensors
+        dz = dz.contiguous()
+        cout = y.shape[3]
+        sums = torch.zeros(cout * 2, dtype=torch.float64, device=y.device)
+        L.bn_act_bwd_reduce(dz, y, coef[0], coef[1], coef[2], coef[3], sums, ctx.slope, ctx.drop)
+        gg = gbeta = None
+        dgam = dbet = None
+        if ctx.need_g:
+            dgam, _, gg = _grad_target(ctx.bn.weight)       # fresh targets are zeroed -> always accumulate
+        if ctx.need_be:
+            dbet, _, gbeta = _grad_target(ctx.bn.bias)
+        need_dy = ctx.need_x0 or ctx.need_x1 or ctx.need_w or ctx.need_b
+        dy = torch.empty_like(y) if need_dy else None
+        L.bn_act_bwd_apply(dz, y, coef[0], coef[1], coef[2], coef[3], sums, ctx.training, dy, dgam, dbet, ctx.slope,
+                           ctx.drop, accumulate_param=True)
+        dx0 = dx1 = gw = gb = None
+        if need_dy:
+            dx0, dx1, gw, gb = _conv_backward(ctx, dy, x0, x1, wk, ctx.mod)
+        return dx0, dx1, gw, gb, gg, gbeta, None, None, None, None, None
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.maxpool2_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.maxpool2_bwd(x, dy.contiguous(), dx)
+        return dx
+
+
+class _Upsample(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, h, w, Cc = x.shape
+        y = torch.empty((N, 2 * h, 2 * w, Cc), dtype=x.dtype, device=x.device)
+        L.upsample2x_fwd(x, y)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        L.upsample2x_bwd(dy.contiguous(), dx)
+        return dx
+
+
+class _CELoss(Function):
+    """CrossEntropyLoss(ignore_index) on fp32 NHWC logits [N,H,W,C]; labels uint8 [N,H,W]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, grad_dtype):
+        acc = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        L.ce_fwd(logits, labels, ignore_index, acc)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        L.ce_finalize(acc, loss)
+        ctx.save_for_backward(logits, labels, acc)
+        ctx.ignore, ctx.grad_dtype = ignore_index, grad_dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, acc = ctx.saved_tensors
+        dl = torch.empty(logits.shape, dtype=ctx.grad_dtype, device=logits.device)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        L.ce_bwd(logits, labels, ctx.ignore, acc, gs, dl)
+        return dl, None, None, None
+
+
+class _ChannelGate(Function):
+    """PersonalizedChannelSelection tail (unet.py:142): y = x*h + x, h [N,C] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, h, amax, davg_src):
+        y = torch.empty_like(x)
+        L.channel_gate_fwd(x, h, y)
+        ctx.save_for_backward(x, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        dh = torch.empty_like(h)
+        L.channel_gate_bwd(x, dy.contiguous(), h, None, None, None, dx, dh)
+        return dx, dh, None, None
+
+
+class _GlobalAvgMax(Function):
+    """AdaptiveAvgPool2d(1) and AdaptiveMaxPool2d(1) in one pass (unet.py:125-126) -> ([N,C], [N,C]) fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, Cc = x.shape
+        avg = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        mx = torch.empty_like(avg)
+        amax = torch.empty((N, Cc), dtype=torch.int32, device=x.device)
+        L.global_avgmax(x, avg, mx, amax)
+        ctx.save_for_backward(amax)
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        return avg, mx
+
+    @staticmethod
+    def backward(ctx, davg, dmx):
+        (amax,) = ctx.saved_tensors
+        N, H, W, Cc = ctx.xshape
+        # dx = davg/HW everywhere + dmx at the arg-max pixel: channel_gate_bwd with dy = 0, h = -1
+        zero = torch.zeros(ctx.xshape, dtype=ctx.xdtype, device=davg.device)
+        hneg = torch.full((N, Cc), -1.0, dtype=torch.float32, device=davg.device)
+        dx = torch.empty_like(zero)
+        L.channel_gate_bwd(zero, zero, hneg, amax, davg.contiguous(), dmx.contiguous(), dx, None)
+        return dx
+
+
+# ----------------------------------------------------------------------------- functional API
+def conv2d(x0, x1, mod, y_f32=False):
+    return _Conv.apply(x0, x1, mod.weight, mod.bias, mod, y_f32)
+
+
+def conv_bn_act(x0, x1, conv, bn, slope, drop_p=0.0, drop_kind="elem"):
+    return _ConvBNAct.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, conv, bn, float(slope),
+                            float(drop_p), drop_kind)
+
+
+def maxpool2(x):
+    return _MaxPool.apply(x)
+
+
+def upsample2x(x):
+    return _Upsample.apply(x)
+
+
+def ce_loss(logits_nhwc, labels, ignore_index):
+    """logits: fp32 dense NHWC [N,H,W,C]; labels [N,H,W] (any integer dtype, values <= 255)."""
+    grad_dtype = torch.float32
+    if labels.dtype != torch.uint8:
+        labels = labels.to(torch.uint8)
+    return _CELoss.apply(logits_nhwc, labels.contiguous(), int(ignore_index), grad_dtype)
+
+
+def global_avgmax(x):
+    return _GlobalAvgMax.apply(x)
+
+
+def channel_gate(x, h):
+    return _ChannelGate.apply(x, h, None, None)
+
+
+def to_nhwc(x_nchw, dtype):
+    """Reference-layout fp32 [N,C,H,W] (any strides) -> dense NHWC in `dtype` (no grad)."""
+    x = x_nchw.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, H, W, Cc), dtype=dtype, device=x.device)
+    L.nchw_to_nhwc(x, out)
+    return out

@@ -1,0 +1,92 @@
+"""Fused AdamW over the model's flat parameter buffer, with every scalar on the device.
+
+Semantics: ``torch.optim.AdamW(params, lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2,
+amsgrad=False)`` exactly as the reference creates it at the start of every round
+(/root/reference/code/flower_pCE_2D.py:55), plus the poly learning-rate schedule applied after
+each iteration (:154-157).  Parameters whose ``.grad`` is None are skipped entirely (torch 2.x
+``zero_grad(set_to_none=True)`` semantics -- SURVEY.md section 0 item 10), which is what makes
+FedICRA's freeze schedule (:84-101) work: the first ``iters - rep_iters`` iterations only touch
+``decoder.out_conv``.
+
+torch keeps one step counter per parameter; here parameters are grouped by *freeze pattern*
+(the set of parameters that received a gradient), each pattern owning one device-side step
+counter.  That is exact as long as the patterns seen within one round are disjoint, which holds
+for FedAvg (one pattern) and FedICRA (out_conv, then everything else).
+
+lr, the iteration counter, the per-pattern step counters and the derived AdamW scalars all live
+in device memory and are advanced by one-thread kernels, so a captured hipGraph of the whole
+training step can be replayed without host involvement.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdamW:
+    MAX_GROUPS = 8
+
+    def __init__(self, model, lr, base_lr=None, max_iterations=None, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2, bf16_shadow=False):
+        self.model = model
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.base_lr = lr if base_lr is None else base_lr
+        self.max_iterations = max_iterations
+        dev = model.flat_params.device
+        n = model.flat_params.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.lr_state = torch.tensor([lr], dtype=torch.float64, device=dev)
+        self.iter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps = torch.zeros(self.MAX_GROUPS, dtype=torch.int32, device=dev)
+        self.hyper = torch.zeros(self.MAX_GROUPS, 4, dtype=torch.float32, device=dev)
+        self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
+        self._groups = {}
+        self._names = [n_ for n_, _ in model.named_parameters()]
+
+    # -- host-visible scalars -------------------------------------------------------------------
+    def set_lr(self, lr: float, current_iter: int = 0):
+        self.lr_state.fill_(lr)
+        self.iter.fill_(int(current_iter))
+
+    def reset_round(self):
+        """The reference builds a fresh AdamW every round: moments and step counts restart."""
+        self.m.zero_()
+        self.v.zero_()
+        self.steps.zero_()
+        self._groups = {}
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.model.zero_grad(set_to_none)
+
+    # -- the step -------------------------------------------------------------------------------
+    def _group_for(self, active):
+        key = tuple(active)
+        g = self._groups.get(key)
+        if g is None:
+            if len(self._groups) >= self.MAX_GROUPS:
+                raise RuntimeError("FusedAdamW: too many distinct freeze patterns in one round")
+            seen = set().union(*[set(k) for k in self._groups]) if self._groups else set()
+            if seen & set(key):
+                raise RuntimeError("FusedAdamW: overlapping freeze patterns within a round are not supported "
+                                   "(per-parameter step counts would diverge from torch.optim.AdamW)")
+            g = (len(self._groups), self.model.param_ranges(key))
+            self._groups[key] = g
+        return g
+
+    def step(self):
+        params = dict(self.model.named_parameters())
+        active = [n for n in self._names if params[n].grad is not None]
+        if not active:
+            return
+        gi, ranges = self._group_for(active)
+        P, G = self.model.flat_params, self.model.flat_grads
+        L.adamw_hyper(self.steps[gi:gi + 1], self.hyper[gi], self.lr_state, self.betas[0], self.betas[1], self.wd)
+        for s, e in ranges:
+            L.adamw_step(P[s:e], G[s:e], self.m[s:e], self.v[s:e], self.hyper[gi], self.betas[0], self.betas[1],
+                         self.eps, None if self.shadow is None else self.shadow[s:e])
+
+    def advance_lr(self):
+        """lr <- base_lr * (1 - iter/max_iterations)^0.9 with iter incremented first (flower_pCE_2D.py:150-157)."""
+        L.lr_poly_advance(self.iter, self.lr_state, self.base_lr, float(self.max_iterations))

@@ -1,0 +1,196 @@
+/* fedicra_hip.h -- C ABI of libfedicra_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (llmir/FedICRA) has NO native boundary on this path: every op below is an
+ * ATen call made from Python.  This header is therefore the boundary
+ * the *build* defines; each entry point cites the reference line whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  Every pointer is DEVICE memory owned by the
+ *     caller (incl. workspaces); nothing is allocated, freed or synchronised inside.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*, 0 = default stream);
+ *     calls are stream-ordered, re-entrant, and hipGraph-capturable.
+ *   - activations are dense NHWC ("channels_last"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c.
+ *     conv weights are [Cout][kh][kw][Cin] (= torch channels_last of [Cout,Cin,kh,kw]).
+ *   - dtype: FI_F32 = exact-fp32 path (v_mfma_f32_16x16x4_f32), FI_BF16 = bf16 storage with
+ *     fp32 accumulate (v_mfma_f32_16x16x32_bf16).  Statistics, losses, optimizer: fp32/fp64.
+ *   - return value: 0 = ok; FI_ERR_* (negative) = bad argument; positive = hipError_t.
+ *     Nothing throws across the ABI.
+ */
+#ifndef FEDICRA_HIP_H
+#define FEDICRA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FI_F32 0
+#define FI_BF16 1
+
+#define FI_OK 0
+#define FI_ERR_DTYPE (-1)
+#define FI_ERR_SHAPE (-2)
+#define FI_ERR_UNSUPPORTED (-3)
+#define FI_ERR_NULL (-4)
+
+/* dropout specification shared by fi_bn_act_fwd / _bwd_* */
+#define FI_DROP_NONE 0
+#define FI_DROP_MASK_ELEM 1 /* explicit uint8 keep-mask, one per element [N,H,W,C] (parity mode)      */
+#define FI_DROP_RNG_ELEM 2  /* counter RNG keyed (seed, element index) -- nn.Dropout                   */
+#define FI_DROP_MASK_CHAN 3 /* explicit uint8 keep-mask per (n,c) [N,C] -- nn.Dropout2d (parity mode) */
+#define FI_DROP_RNG_CHAN 4  /* counter RNG keyed (seed, n*C+c) -- nn.Dropout2d                        */
+
+int fi_abi_version(void);
+
+/* ---------------------------------------------------------------- convolution ------------
+ * Implicit-GEMM Conv2d, stride 1, kernel 1x1 or 3x3 with "same" zero padding.
+ * Replaces nn.Conv2d in ConvBlock / UpBlock.conv1x1 / out_conv / dsn_head
+ * (/root/reference/code/networks/unet.py:19-27, 57, 225-226, 261-267).
+ * The input may be the channel-concatenation of two tensors (x0: c0 channels, x1: c1 channels;
+ * x1 == NULL, c1 == 0 for a plain conv): this folds torch.cat([skip, up], dim=1) (unet.py:69)
+ * into the gather.  The output may likewise be split over two tensors (dgrad w.r.t. a concat).
+ */
+typedef struct FiConv {
+  int dtype;          /* FI_F32 / FI_BF16: storage type of x, w, y                                  */
+  int N, H, W;        /* batch, height, width (output == input size)                                 */
+  int ksize;          /* 1 or 3                                                                      */
+  int c0, c1;         /* input channels from x0 / x1                                                 */
+  int co0, co1;       /* output channels to y0 / y1 (co1 == 0 for a single destination)              */
+  int accumulate0;    /* y0 += result instead of y0 = result                                         */
+  int accumulate1;    /* same for y1                                                                 */
+  int y_f32;          /* store the output as fp32 even when dtype == FI_BF16 (logits)                */
+} FiConv;
+
+/* y = conv(cat(x0,x1), w) + bias.  w: [co0+co1][k*k][c0+c1] in `dtype` (see fi_pack_weights).
+ * bias: fp32 [co0+co1] or NULL.  stats: fp64 [co0+co1][2], or NULL; when given, per-channel
+ * (sum, sum of squares) of the stored output are ATOMICALLY ADDED (caller zeroes it) -- the
+ * batch statistics BatchNorm2d (unet.py:21) needs, produced in the conv epilogue. */
+int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
+                  void* y0, void* y1, double* stats, void* stream);
+
+/* dw[co][k*k][ci] += sum_pixels dy * x  (fp32, ATOMICALLY ADDED; caller zeroes);
+ * dbias[co] += sum_pixels dy (fp32, may be NULL).  d->co0 = Cout, co1 ignored; dy is [N,H,W,Cout]. */
+int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
+                    float* dbias, void* stream);
+
+/* weight repack from the fp32 master [Cout][k*k][Cin]:
+ *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)
+ *   mode 1: dst[ci][k*k-1-t][co]    = (dtype) src[co][t][ci]          (dgrad operand: conv of dy
+ *           with the flipped, transposed filter -- run through fi_conv2d_fwd with Cin<->Cout)   */
+int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm + activation --
+ * nn.BatchNorm2d (eps 1e-5, momentum 0.1) -> LeakyReLU(0.01)/ReLU -> Dropout, unet.py:21-24, 263-265. */
+
+/* training: from stats (fi_conv2d_fwd) and count = N*H*W compute batch mean / biased var,
+ * scale = gamma*invstd, shift = beta - mean*scale; update running_mean/var (unbiased var) and
+ * ++num_batches_tracked (all in place, fp32 / int64).  eval (training == 0): scale/shift from the
+ * running statistics; mean/invstd outputs hold the running values; stats may be NULL. */
+int fi_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
+                   float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+
+typedef struct FiBnAct {
+  int dtype;
+  long pixels;        /* N*H*W */
+  int C;
+  int hw;             /* H*W (to find n for the per-(n,c) dropout forms) */
+  float slope;        /* LeakyReLU negative slope; 0 = ReLU; 1 = identity */
+  int drop_mode;      /* FI_DROP_* */
+  float drop_p;
+  uint64_t seed;      /* RNG forms */
+  const uint8_t* mask;/* MASK forms */
+  const int32_t* seed_offset; /* RNG forms, may be NULL: device int32 added to the seed stream (e.g. the
+                                 training-iteration counter) so a replayed hipGraph draws fresh masks */
+} FiBnAct;
+
+/* z = dropout(act(y*scale[c] + shift[c])) */
+int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z, void* stream);
+/* sums[c][0] += sum g, sums[c][1] += sum g*xhat   (g = dz through dropout and activation,
+ * xhat = (y-mean)*invstd); fp64, atomically added, caller zeroes. */
+int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void* y, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, double* sums, void* stream);
+/* dy = scale*(g - sum_g/M - xhat*sum_gx/M) (training) or scale*g (eval);
+ * dgamma[c] (+)= sum_gx, dbeta[c] (+)= sum_g  (written by block 0; accumulate_param selects += ). */
+int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void* y, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const double* sums, int training, void* dy,
+                        float* dgamma, float* dbeta, int accumulate_param, void* stream);
+
+/* ---------------------------------------------------------------- pooling / resampling ---- */
+/* nn.MaxPool2d(2) (unet.py:40): y[N,H/2,W/2,C]; H, W even. */
+int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+/* dx = route dy to the first maximum of each window (scan order, strict >), zeros elsewhere. */
+int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate,
+                    void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet.py:58-59): [N,h,w,C]->[N,2h,2w,C] */
+int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream);
+int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- losses ------------------
+ * CrossEntropyLoss(ignore_index) (/root/reference/code/flower_pCE_2D.py:57,124): logits fp32 NHWC
+ * [M][C], labels uint8 [M].  acc[0] += sum of -log p[label], acc[1] += #non-ignored (fp64, caller zeroes). */
+int fi_ce_fwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index, double* acc, void* stream);
+/* loss[0] = acc[0]/acc[1] (fp32; NaN when nothing is labeled, as torch) */
+int fi_ce_finalize(const double* acc, float* loss, void* stream);
+/* dlogits = gscale * (softmax - onehot) / count for labeled pixels, 0 otherwise; written in `dtype`.
+ * gscale: device fp32 scalar (upstream gradient) or NULL for 1. */
+int fi_ce_bwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index, const double* acc,
+              const float* gscale, void* dlogits, int dtype, void* stream);
+
+/* Dice bookkeeping of val_2D.py:9-22,66-74: pred = argmax_c logits (first max wins, as torch.argmax);
+ * for class i in 1..C-1: region = (lbl == 1) if i == 1 else (lbl >= 1); counts[(i-1)*3 + {0,1,2}] +=
+ * {|P & G|, |P|, |G|}  (int64, atomically added, caller zeroes). */
+int fi_dice_counts(const float* logits, const uint8_t* gt, long M, int C, long long* counts, void* stream);
+
+/* ---------------------------------------------------------------- optimizer ----------------
+ * torch.optim.AdamW(betas, eps, weight_decay, amsgrad=False) as created at flower_pCE_2D.py:55.
+ * All scalars live on the device so that a captured hipGraph can be replayed:
+ *   lr_state (fp64[1])  current learning rate
+ *   step     (int32[1]) this parameter group's AdamW step count t (the reference re-creates the
+ *                       optimizer every round, and FedICRA's freeze schedule gives out_conv and
+ *                       the rest different t -- SURVEY.md 8-a6/a15)
+ *   hyper    (fp32[4])  { lr, 1 - lr*wd, lr / (1 - beta1^t), sqrt(1 - beta2^t) }
+ * fi_adamw_hyper: ++step[0]; hyper <- f(lr_state[0], step[0]).
+ * fi_lr_poly_advance: ++iter[0]; lr_state[0] = base_lr*(1 - iter/max_iter)^0.9 (flower_pCE_2D.py:154-157). */
+int fi_adamw_hyper(int* step, float* hyper, const double* lr_state, float beta1, float beta2, float wd, void* stream);
+int fi_lr_poly_advance(int* iter, double* lr_state, double base_lr, double max_iter, void* stream);
+/* p, m, v updated in place over [0,n); g read.  shadow (bf16, may be NULL) receives a bf16 copy of p. */
+int fi_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
+                  float eps, void* shadow_bf16, void* stream);
+
+/* ---------------------------------------------------------------- aggregation helpers ------
+ * flwr `aggregate`: w = reduce(add, [w_k * n_k]) / total.
+ * fi_scale: y = divide ? x / a : x * a   (pre-scale by n_k before, divide by total after the RCCL sum)
+ * fi_axpy : acc = acc + a * x with the product rounded to fp32 BEFORE the add (no FMA contraction),
+ *           i.e. numpy's  acc + (x * n_k)  bit for bit -- used by the single-process aggregator. */
+int fi_scale(const float* x, float* y, long n, float a, int divide, void* stream);
+int fi_axpy(float* acc, const float* x, long n, float a, void* stream);
+/* FedICRA ALA element-wise step (/root/reference/code/flower_common.py:590-602):
+ *   w    = clamp(w - eta * grad * (local - global), 0, 1)
+ *   temp = global + (local - global) * w                                                   */
+int fi_ala_update(float* w, float* temp, const float* grad, const float* local, const float* global, long n,
+                  float eta, void* stream);
+
+/* ---------------------------------------------------------------- PCS helpers --------------
+ * PersonalizedChannelSelection (unet.py:103-144): global avg / max pool over H*W per (n,c);
+ * amax (int32 [N,C], may be NULL) = pixel index of the first maximum (AdaptiveMaxPool2d backward). */
+int fi_global_avgmax(int dtype, const void* x, float* avg, float* mx, int* amax, int N, int HW, int C, void* stream);
+/* y = x * (1 + h[n][c])   (x*h + x) */
+int fi_channel_gate_fwd(int dtype, const void* x, const float* h, void* y, int N, int HW, int C, void* stream);
+/* dx = dy*(1+h) + davg[n][c]/HW + (pixel == amax[n][c] ? dmx[n][c] : 0);
+ * dh[n][c] = sum_hw dy*x.  amax/davg/dmx may be NULL. */
+int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, const float* h, const int* amax, const float* davg,
+                        const float* dmx, void* dx, float* dh, int N, int HW, int C, void* stream);
+
+/* misc elementwise */
+int fi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* NCHW fp32 (reference layout) <-> NHWC `dtype` */
+int fi_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, void* stream);
+int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDICRA_HIP_H */

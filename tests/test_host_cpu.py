@@ -1,0 +1,194 @@
+"""CPU-side checks: C-ABI library loads and exports every declared symbol (no compute), module surface /
+flat state / wire format, strategy arithmetic vs the oracle, 2-process gloo aggregation."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fedicra_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "fedicra_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(fi_\w+)\s*\(", hdr, flags=re.M)))
+    assert len(declared) >= 27
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fedicra_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+    lib.fi_abi_version.restype = ctypes.c_int
+    assert lib.fi_abi_version() == 1                  # host-only call: no GPU needed
+
+
+def test_product_has_no_cpu_fallback_and_no_oracle_import():
+    """The product path must fail loudly without a device and must never import the oracle."""
+    from fedicra_amd import _lib
+    with pytest.raises(_lib.FiError):
+        _lib.maxpool2_fwd(torch.zeros(1, 2, 2, 8), torch.zeros(1, 1, 1, 8))
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fedicra_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_module_surface_matches_oracle_and_reference_layout():
+    from fedicra_amd.networks.unet import UNet, UNet_Head, UNet_LC, UNet_LC_MultiHead, UNet_MultiHead
+    from oracle.unet_ref import RefUNet, RefUNetLC
+    pairs = [(lambda: UNet(1, 2), lambda: RefUNet(1, 2), 136), (lambda: UNet_Head(3, 3), lambda: RefUNet(3, 3, 1), 144),
+             (lambda: UNet_MultiHead(1, 2), lambda: RefUNet(1, 2, 3), 160),
+             (lambda: UNet_LC(1, 2, 1, 8, 8, 3), lambda: RefUNetLC(1, 2, 1, 8, 8, 3, 1), 144),
+             (lambda: UNet_LC_MultiHead(1, 2, 1, 8, 8, 3), lambda: RefUNetLC(1, 2, 1, 8, 8, 3, 3), 160)]
+    for mk, mkref, n in pairs:
+        torch.manual_seed(2022)
+        m = mk()
+        torch.manual_seed(2022)
+        r = mkref()
+        sm, sr = m.state_dict(), r.state_dict()
+        assert list(sm.keys()) == list(sr.keys()) and len(sm) == n
+        for k in sm:
+            assert sm[k].shape == sr[k].shape and sm[k].dtype == sr[k].dtype, k
+            assert torch.equal(sm[k], sr[k]), f"default init differs at {k}"     # same seed -> same init
+    torch.manual_seed(2022)
+    m = UNet_LC(1, 2, 1, 8, 8, 3)
+    assert not any("pcs" in k for k in m.state_dict())             # quirk 1 reproduced
+    assert sum(p.numel() for p in m.encoder.pcs_list[0].parameters()) == 8 * 256 + 256 * 256 + 512 * 16 + 16 * 256
+
+
+def test_flat_state_views_and_wire_format():
+    import copy
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.networks.unet import UNet
+    from oracle import fed_ref
+    from oracle.unet_ref import RefUNet, seeded_state
+    import argparse
+    m = UNet(1, 2)
+    seeded_state(m, 7)
+    r = RefUNet(1, 2)
+    seeded_state(r, 7)
+    flat = m.flat_state
+    w = m.encoder.down1.maxpool_conv[1].conv_conv[0].weight
+    assert w.shape == (32, 16, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()      # [Cout][kh][kw][Cin] memory
+    assert flat.data_ptr() <= w.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    rm = m.encoder.in_conv.conv_conv[1].running_mean
+    assert flat.data_ptr() <= rm.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    args = argparse.Namespace(strategy="FedAvg", amp=0, cid=0, num_classes=2, img_class="faz")
+    mm = MyModel(args, m, [], [])
+    ws, wr = [a.copy() for a in mm.get_weights(None)], fed_ref.get_weights(r)   # .numpy() aliases CPU storage
+    assert len(ws) == 136 and sum(a.size for a in ws if a.dtype == np.float32) == 1816418
+    for a, b in zip(ws, wr):
+        assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+    # set_weights (plain) incl. the int64 <- float64 truncation (quirk 6)
+    ws2 = [a * 2 if a.dtype == np.float32 else np.float64(7.9) for a in ws]
+    mm.set_weights(ws2, {})
+    assert int(m.encoder.in_conv.conv_conv[1].num_batches_tracked) == 7
+    assert torch.equal(m.flat_counters, torch.full((18,), 7, dtype=torch.int64))
+    np.testing.assert_array_equal(mm.get_weights(None)[0], ws[0] * 2)
+    m2 = copy.deepcopy(m)
+    assert m2.flat_state.data_ptr() != flat.data_ptr() and torch.equal(m2.flat_state, m.flat_state)
+    names = [n for n, _ in m.named_parameters()]
+    body = [n for n in names if "out_conv" not in n]
+    assert len(m.param_ranges(names)) == 1 and len(m.param_ranges(["decoder.out_conv.weight", "decoder.out_conv.bias"])) == 1
+    assert len(m.param_ranges(body)) == 1                       # out_conv is the last parameter of UNet
+    dec = [n for n in names if any(k in n for k in ("out_conv", "up4", "up3", "up2", "up1"))]
+    assert len(dec) == 42 and len(m.param_ranges(dec)) == 1    # ALA range is contiguous
+
+
+def test_host_aggregate_matches_oracle_and_fl_roundtrip():
+    from fedicra_amd import fl
+    from fedicra_amd.flower_common import FedAvg, FedICRA, aggregate, fit_metrics_aggregation_fn, get_strategy
+    from oracle import fed_ref
+    rng = np.random.default_rng(1)
+    n = [21, 13, 17, 59, 3]
+    ws = [[rng.normal(size=(4, 3, 3, 3)).astype(np.float32), rng.normal(size=(4,)).astype(np.float32),
+           np.array(5 + k, dtype=np.int64)] for k in range(5)]
+    a, b = aggregate(list(zip(ws, n))), fed_ref.fedavg_aggregate(list(zip(ws, n)))
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    p = fl.ndarrays_to_parameters(ws[0])
+    back = fl.parameters_to_ndarrays(p)
+    assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(back, ws[0]))
+    strat = get_strategy("FedICRA", fit_metrics_aggregation_fn=fit_metrics_aggregation_fn, accept_failures=False)
+    assert isinstance(strat, FedICRA) and isinstance(strat, FedAvg) and repr(strat) == "FedICRA(accept_failures=False)"
+    res = [(None, fl.FitRes(fl.Status("OK", "Success"), fl.ndarrays_to_parameters(w), k, {f"client_{i}_lr": 0.1}))
+           for i, (w, k) in enumerate(zip(ws, n))]
+    params, metrics = strat.aggregate_fit(10, res, [])
+    for x, y in zip(fl.parameters_to_ndarrays(params), b):
+        assert np.array_equal(x, y)
+    assert set(metrics) == {f"client_{i}_lr" for i in range(5)}
+    assert strat.aggregate_fit(10, res, [RuntimeError()]) == (None, {})      # accept_failures=False
+
+
+def test_evaluate_metrics_aggregation_fn():
+    import argparse
+    from fedicra_amd.flower_common import VAL_METRICS, get_evaluate_metrics_aggregation_fn
+    args = argparse.Namespace(min_num_clients=2, num_classes=2)
+    fn = get_evaluate_metrics_aggregation_fn(args, VAL_METRICS)
+    em = []
+    for c, (n, d) in enumerate([(10, 0.5), (30, 0.9)]):
+        m = {}
+        for name in VAL_METRICS:
+            m[f"client_{c}_val_1_{name}"] = d
+            m[f"client_{c}_val_mean_{name}"] = d
+        em.append((n, m))
+    out = fn(em)
+    assert abs(out["val_mean_dice"] - (10 * 0.5 + 30 * 0.9) / 40) < 1e-12
+    assert abs(out["val_avg_mean_dice"] - 0.7) < 1e-12 and abs(out["val_1_jc"] - 0.8) < 1e-12
+
+
+def test_metrics_from_counts_against_oracle_dice():
+    from fedicra_amd.flower_common import metrics_from_counts
+    from oracle.losses_ref import dice_percase
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        p, g = rng.random((16, 16)) < 0.3, rng.random((16, 16)) < 0.4
+        tp, npred, ngt = int((p & g).sum()), int(p.sum()), int(g.sum())
+        m = metrics_from_counts(tp, npred, ngt, 256)
+        assert m[0] == dice_percase(p.copy(), g.copy())
+    assert metrics_from_counts(0, 0, 5, 256) == [0.0] * 7          # empty prediction (val_2D.py:21-22)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from fedicra_amd.comm import WeightedAllReduce
+from fedicra_amd.flower_common import DeviceWeights
+n = [21, 13, 17][:world]
+g = torch.Generator().manual_seed(100 + rank)
+state = torch.randn(1000, generator=g)
+cnt = torch.tensor([10 * (rank + 1) + 3, 7], dtype=torch.int64)
+agg = WeightedAllReduce(n[rank], device=None)
+out = agg.aggregate(DeviceWeights(state, cnt))
+states = [torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+ref = sum(s.double() * k for s, k in zip(states, n)) / sum(n)
+assert agg.all_n == n and agg.total == sum(n)
+assert torch.allclose(out.state.double(), ref, atol=1e-6), (out.state.double() - ref).abs().max()
+ci = [int(sum((10 * (r + 1) + 3) * n[r] for r in range(world)) / sum(n)), 7]
+assert out.counters.tolist() == ci, (out.counters.tolist(), ci)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_weighted_allreduce_gloo_multiprocess(tmp_path, world):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 1000 + world)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -1,0 +1,304 @@
+"""GPU parity of the HIP-backed U-Net family and training loop against (a) the golden vectors the
+reference itself produced (tests/golden) and (b) the CPU oracle run side by side on the same
+seeded inputs.  Tolerances: fp32 mode -- logits / Dice inputs within 1e-4 (north_star); bf16 mode --
+reported, loose."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mask_provider():
+    """Dropout keep-masks drawn exactly like nn.Dropout on the CPU (same generator stream as the oracle)."""
+    return lambda shape, p: torch.empty(shape).bernoulli_(1 - p)
+
+
+def _mk(cls, *a, dtype="fp32", seed=2022, lc=False):
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from oracle.unet_ref import seeded_state
+    m = cls(*a)
+    extra = None
+    if lc:
+        extra = {f"encoder.pcs_list.{i}.{k}": v for i, p in enumerate(m.encoder.pcs_list)
+                 for k, v in p.state_dict().items()}
+    seeded_state(m, seed, extra=extra)
+    m = m.cuda()
+    set_compute_dtype(m, dtype)
+    return m
+
+
+def test_unet_eval_logits_match_reference_golden(golden):
+    from fedicra_amd.networks.unet import UNet
+    from helpers import assert_ck
+    g = golden("g2_unet_fwd.npz")
+    m = _mk(UNet, 1, 2).eval()
+    x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
+    with torch.no_grad():
+        o = m(x)
+    assert len(o) == 6 and len(o[1]) == 5
+    err = (o[0].cpu() - torch.from_numpy(g["eval_logits"])).abs().max().item()
+    assert err < 1e-4, f"eval logits max err {err:.3e}"
+    assert o[0].shape == (4, 2, 64, 64) and o[1][4].shape == (4, 256, 4, 4)
+    for i, f in enumerate(o[1]):
+        assert_ck(f.float().cpu(), g[f"eval_feat{i}_ck"], rtol=2e-5, atol=1e-5, what=f"feat{i}")
+    for i in range(2, 6):
+        assert_ck(o[i].float().cpu(), g[f"eval_de{i-1}_ck"], rtol=2e-5, atol=1e-5, what=f"de{i-1}")
+    m3 = _mk(UNet, 3, 3, seed=2023).eval()
+    with torch.no_grad():
+        l3 = m3(torch.from_numpy(g["x3"]).to(DEV))[0]
+    assert (l3.cpu() - torch.from_numpy(g["eval_logits3"])).abs().max().item() < 1e-4
+
+
+def test_unet_train_forward_with_reference_masks(golden):
+    from fedicra_amd import ops
+    from fedicra_amd.networks.unet import UNet
+    from helpers import assert_ck
+    g = golden("g2_unet_fwd.npz")
+    m = _mk(UNet, 1, 2).train()
+    x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(7)
+        o = m(x)
+    finally:
+        ops.set_dropout_mask_provider(None)
+    err = (o[0].detach().cpu() - torch.from_numpy(g["train_logits_seed7"])).abs().max().item()
+    assert err < 1e-4, f"train-mode logits max err {err:.3e}"
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert_ck(v.double().cpu(), g["after_train_fwd/" + k], rtol=1e-5, atol=1e-6, what=k)
+
+
+def test_unet_lc_forward_and_quirks(golden):
+    from fedicra_amd.networks.unet import UNet_LC, UNet_LC_MultiHead
+    from helpers import assert_ck
+    g = golden("g2_unet_lc_fwd.npz")
+    m = _mk(UNet_LC, 1, 2, 1, 8, 8, 3, lc=True).eval()
+    assert not any("pcs" in k for k in m.state_dict()) and len(m.state_dict()) == 144
+    x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
+    with torch.no_grad():
+        for e in (None, 0, 5):
+            o = m(x, e)
+            assert len(o) == 8
+            assert (o[0].cpu() - torch.from_numpy(g[f"eval_logits_e{e}"])).abs().max().item() < 1e-4
+            assert (o[6][-1].cpu() - torch.from_numpy(g[f"eval_hmap_e{e}"])).abs().max().item() < 1e-5
+            assert (o[7].cpu() - torch.from_numpy(g[f"eval_aux_e{e}"])).abs().max().item() < 1e-4
+            assert o[6][:4] == [None] * 4 and o[6][-1].shape == (4, 256, 1, 1)
+    mh = _mk(UNet_LC_MultiHead, 1, 2, 1, 8, 8, 2, seed=2024, lc=True).eval()
+    with torch.no_grad():
+        o = mh(x)
+    assert len(o) == 10 and len(mh.state_dict()) == 160
+    assert (o[0].cpu() - torch.from_numpy(g["mh_eval_logits"])).abs().max().item() < 1e-4
+    for i in (7, 8, 9):
+        assert_ck(o[i].float().cpu(), g[f"mh_eval_aux{i-6}_ck"], rtol=2e-5, atol=1e-5, what=f"aux{i-6}")
+
+
+def test_unet_bf16_mode_close_to_fp32(golden):
+    from fedicra_amd.networks.unet import UNet
+    g = golden("g2_unet_fwd.npz")
+    m = _mk(UNet, 1, 2, dtype="bf16").eval()
+    x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
+    with torch.no_grad():
+        lg = m(x)[0]
+    ref = torch.from_numpy(g["eval_logits"])
+    assert lg.dtype == torch.float32
+    err = (lg.cpu() - ref).abs().max().item()
+    agree = (lg.cpu().argmax(1) == ref.argmax(1)).float().mean().item()
+    print(f"bf16 eval logits: max err {err:.3e}, argmax agreement {agree:.5f}")
+    assert err < 0.15 and agree > 0.99
+
+
+def _args(**kw):
+    a = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=0, min_num_clients=1, num_classes=2,
+                           img_class="faz", base_lr=0.01, max_iterations=30000, iters=5, rep_iters=3, alpha=0.5,
+                           snapshot_path=None, use_graph=False)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_backward_matches_oracle_grads():
+    """One fwd+bwd, dropout masks pinned: every parameter gradient vs the CPU oracle."""
+    from fedicra_amd import ops
+    from fedicra_amd.networks.unet import UNet
+    from oracle.losses_ref import pce_loss
+    from oracle.unet_ref import RefUNet, seeded_state
+    from helpers import loader
+    b = loader(1, 4, 64, cid=0)[0]
+    ref = RefUNet(1, 2)
+    seeded_state(ref, 2022)
+    ref.train()
+    torch.manual_seed(3)
+    pce_loss(ref(b["image"].unsqueeze(1))[0], b["label"], 2).backward()
+    m = _mk(UNet, 1, 2).train()
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(3)
+        out = m(b["image"].unsqueeze(1).to(DEV))
+        loss = ops.ce_loss(out[0].permute(0, 2, 3, 1), b["label"].to(DEV), 2)
+        loss.backward()
+    finally:
+        ops.set_dropout_mask_provider(None)
+    worst = 0.0
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        gq = q.grad
+        scale = max(gq.abs().max().item(), 1e-6)
+        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias"):
+            continue        # conv bias before BN: true gradient is 0, both sides hold only round-off
+        e = (p.grad.cpu() - gq).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e < 2e-3, f"{n}: rel grad err {e:.3e}"
+    print(f"worst relative parameter-gradient error {worst:.3e}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_local_train_matches_reference_trajectory(golden, use_graph):
+    """MyClient._train, 5 iterations + a second round of 2, vs the reference's own _train (golden g4)."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from helpers import assert_ck, loader
+    g = golden("g4_train_unet.npz")
+    args = _args(use_graph=use_graph)
+    batches = loader(3, 4, 64, cid=0)
+    net = _mk(UNet, 1, 2)
+    client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+    if use_graph:
+        # graph replay cannot call a host mask provider: use masks recorded per iteration instead
+        pytest.skip("dropout masks come from a host callback in parity mode; graph path is covered by "
+                    "test_graph_replay_equals_eager")
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(2022)
+        last, met = client._train({"iter_global": 5, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+        errs = np.abs(np.array(client.last_losses) - g["losses_6dp"])
+        print("loss trajectory", client.last_losses, "ref", g["losses_6dp"].tolist())
+        assert errs.max() < 1e-4, f"loss trajectory err {errs}"
+        assert abs(client.current_lr - float(g["lr_after"])) < 1e-15
+        sd = net.state_dict()
+        ow = torch.from_numpy(g["out_conv_weight"])
+        assert (sd["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 5e-4
+        args.iters = 2
+        last2, _ = client._train({"iter_global": 7, "iters": 2, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+        errs2 = np.abs(np.array(client.last_losses) - g["losses_round2_6dp"])
+        assert errs2.max() < 2e-4, f"round-2 loss err {errs2}"
+    finally:
+        ops.set_dropout_mask_provider(None)
+    nbt = [v for k, v in sd.items() if k.endswith("num_batches_tracked")]
+    assert all(int(v) == 7 for v in nbt)
+
+
+def test_graph_replay_equals_eager():
+    """The captured-hipGraph iteration must produce the same parameters as eager launches (dropout RNG is
+    device-side and keyed by the device iteration counter, so both paths draw identical masks)."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from helpers import loader
+    batches = loader(3, 4, 64, cid=0)
+    finals, losses = [], []
+    for use_graph in (False, True):
+        args = _args(use_graph=use_graph, iters=6)
+        ops.manual_seed(1)
+        net = _mk(UNet, 1, 2)
+        client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+        client._train({"iter_global": 6, "iters": 6, "eval_iters": 12, "batch_size": 4, "stage": "fit"})
+        finals.append(net.flat_state.clone())
+        losses.append(list(client.last_losses))
+    print("eager", losses[0], "graph", losses[1])
+    assert np.allclose(losses[0], losses[1], atol=2e-4)
+    assert (finals[0] - finals[1]).abs().max().item() < 2e-3
+
+
+def test_fedicra_local_train_matches_reference(golden):
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet_LC
+    from helpers import loader
+    g = golden("g5_fedicra_train.npz")
+    K, cid = 3, 1
+    args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K, iters=5, rep_iters=2, alpha=1.0)
+    batches = loader(2, 4, 64, cid=cid)
+    net = _mk(UNet_LC, 1, 2, 1, K, K, cid, lc=True)
+    client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(2022)
+        last, met = client._train({"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    finally:
+        ops.set_dropout_mask_provider(None)
+    print("fedicra losses", client.last_losses, "ref", g["losses_6dp"].tolist())
+    assert np.abs(np.array(client.last_losses) - g["losses_6dp"]).max() < 2e-4
+    assert abs(met[f"client_{cid}_loss_lc"] - float(g["loss_lc_last"])) < 1e-4
+    ow = torch.from_numpy(g["out_conv_weight"])
+    assert (net.state_dict()["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 5e-4
+
+
+def test_ala_set_weights_matches_reference(golden):
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.networks.unet import UNet_LC
+    from oracle.unet_ref import RefUNetLC, seeded_state
+    from oracle import fed_ref
+    from helpers import assert_ck, loader
+    g = golden("g7_ala.npz")
+    K, cid = 3, 1
+    args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K)
+    batches = loader(3, 4, 64, cid=cid)
+    net = _mk(UNet_LC, 1, 2, 1, K, K, cid, seed=100, lc=True).eval()     # eval mode: deterministic
+    donor = RefUNetLC(1, 2, 1, K, K, cid)
+    seeded_state(donor, 200)
+    glob = fed_ref.get_weights(donor)
+    model = MyModel(args, net, batches, batches)
+    model.eval()
+    model.set_weights(glob, {"iter_global": 50})
+    assert model.start_phase is True
+    assert_ck(net.state_dict()["decoder.out_conv.weight"].cpu(), g["eval/skip50_out_conv_ck"], rtol=1e-6, atol=1e-7)
+    net2 = _mk(UNet_LC, 1, 2, 1, K, K, cid, seed=100, lc=True).eval()
+    model = MyModel(args, net2, batches, batches)
+    model.eval()
+    model.set_weights(glob, {"iter_global": 60})
+    assert model.start_phase is False
+    assert len(model.ala_epoch_losses) == int(g["eval/first_epochs"])
+    ow = torch.from_numpy(g["eval/first_out_conv_weight"])
+    err = (net2.state_dict()["decoder.out_conv.weight"].cpu() - ow).abs().max().item()
+    assert err < 1e-4, f"ALA-mixed out_conv err {err:.3e}"
+    for k, v in net2.state_dict().items():
+        assert_ck(v.double().cpu(), g["eval/first/" + k], rtol=2e-4, atol=2e-5, what=k)
+    seeded_state(donor, 300)
+    glob2 = fed_ref.get_weights(donor)
+    model.set_weights(glob2, {"iter_global": 70})
+    assert len(model.ala_epoch_losses) == 1
+    for k, v in net2.state_dict().items():
+        assert_ck(v.double().cpu(), g["eval/second/" + k], rtol=2e-4, atol=2e-5, what=k)
+    model.set_weights(glob2, {"iter_global": 80})            # identical global again -> early-out, all global
+    assert_ck(net2.state_dict()["decoder.out_conv.weight"].cpu(), g["eval/third_out_conv_ck"], rtol=1e-6, atol=1e-7)
+
+
+def test_evaluate_dice_matches_oracle():
+    from fedicra_amd.flower_common import evaluate
+    from fedicra_amd.networks.unet import UNet
+    from fedicra_amd.synth import phantom_batch
+    from oracle.losses_ref import eval_case
+    from oracle.unet_ref import RefUNet, seeded_state
+    args = _args()
+    imgs, _, dense = phantom_batch(6, 64, 1, 2, cid=2, dense=True)
+    val = [{"image": torch.from_numpy(imgs[i:i + 1]), "label": torch.from_numpy(dense[i:i + 1])} for i in range(6)]
+    net = _mk(UNet, 1, 2, seed=5)
+    met = evaluate(args, net, val)
+    ref = RefUNet(1, 2)
+    seeded_state(ref, 5)
+    ref.eval()
+    tot = 0.0
+    with torch.no_grad():
+        for b in val:
+            pred = ref(b["image"].unsqueeze(1))[0].argmax(1)[0].numpy()
+            tot += eval_case(pred, b["label"][0].numpy(), 2)[0]
+    assert abs(met["val_mean_dice"] - tot / 6) < 1e-4, (met["val_mean_dice"], tot / 6)
+    assert abs(met["val_1_dice"] - tot / 6) < 1e-4
