@@ -65,7 +65,9 @@ def cpu_baseline(a):
     from oracle import fed_ref
     from oracle.unet_ref import RefUNet
     from fedicra_amd.synth import phantom_batch
-    cores = os.cpu_count() or 1
+    # torch's CPU conv path stops scaling (and collapses from oversubscription) far below the 256 hardware
+    # threads of the GPU box's host: use at most 32 threads and report that number as `cores`.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("FEDICRA_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
     torch.manual_seed(2022)
     m = RefUNet(1, 2)
@@ -76,7 +78,7 @@ def cpu_baseline(a):
     st = fed_ref.TrainState(0.01)
     fed_ref.local_train(m, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)   # warm-up
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):
+    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 40):
         fed_ref.local_train(m, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)
         n += 1
     dt = time.perf_counter() - t0
@@ -115,6 +117,13 @@ def roofline_pass(client, a, dtype_name):
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
             "share_of_gpu_time": round(dom["ms"] / total_ms, 4),
             "kernel_time_breakdown_ms_per_iter": {k: round(v / 3.0, 4) for k, v in sorted(breakdown.items())}}
+    if os.environ.get("FEDICRA_BENCH_VERBOSE"):
+        top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:40]
+        for k, v in top:
+            us = v["ms"] / v["calls"] * 1e3
+            print(f"# {'/'.join(map(str, k)):60s} calls {v['calls']:3d} avg {us:8.1f} us  "
+                  f"{v['flops'] / v['calls'] / (us * 1e-6) / 1e12:7.2f} TF/s  "
+                  f"{v['bytes'] / v['calls'] / (us * 1e-6) / 1e9:8.1f} GB/s", file=sys.stderr)
     client.use_graph = not a.no_graph
     return roof
 

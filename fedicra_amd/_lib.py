@@ -21,7 +21,7 @@ EXPORTS = [
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
-    "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw",
+    "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
 
 
@@ -330,3 +330,7 @@ def nchw_to_nhwc(src, dst):
 def nhwc_to_nchw(src, dst):
     N, Cc, H, W = dst.shape
     _chk(lib().fi_nhwc_to_nchw(ptr(_dev(src)), dt(src.dtype), ptr(dst), N, Cc, H, W, stream()), "fi_nhwc_to_nchw")
+
+
+def probe_tr16(inp, offs, out):
+    _chk(lib().fi_probe_tr16(ptr(_dev(inp)), ptr(offs), ptr(out), stream()), "fi_probe_tr16")

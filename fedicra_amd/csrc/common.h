@@ -51,14 +51,18 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// counter-based RNG for dropout: one 32-bit draw per (seed, element index).
-// splitmix64 finaliser -- stateless, so backward regenerates the identical mask.
+// counter-based RNG for dropout: one 32-bit draw per (seed, element index), stateless, so backward
+// regenerates the identical mask.  lowbias32 finaliser (2 multiplies) keyed by both seed halves -- cheap
+// enough (~10 VALU ops per element) to stay under the HBM roofline of the fused BN+act+dropout pass.
 __device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  x ^= (uint32_t)(idx >> 32) * 0x85EBCA6Bu;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x ^ (uint32_t)(seed >> 32);
 }
 // keep with probability (1-p): threshold on a 32-bit uniform
 __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t drop_thresh) {

@@ -300,26 +300,57 @@ struct WgradArgs {
   int tilesX, tilesY, nco, nci, spatialBlocks;
 };
 
-template <typename T>
-__device__ __forceinline__ typename DT<T>::frag_t gather_k(const T* base, int stride);
-template <>
-__device__ __forceinline__ float gather_k<float>(const float* base, int) {
-  return base[0];
-}
-template <>
-__device__ __forceinline__ bf16x8 gather_k<bf16_t>(const bf16_t* base, int stride) {
-  bf16x8 v;
+// Fragment loaders for the wgrad contraction (K = pixels).  `tile` is a row-major [pixel][stride] LDS
+// image (pixel = row*rowlen + col); the fragment covers 16 channels starting at `chan` and the KSTEP
+// pixels of k-step `ks`, displaced by the filter tap (r, s).
+template <typename T> struct WgFrag;
+template <> struct WgFrag<float> {
+  // v_mfma_f32_16x16x4_f32: lane (li, kg) feeds channel chan+li of pixel ks*4+kg -- a plain 4-byte read.
+  static __device__ __forceinline__ float load(const float* tile, int rowlen, int stride, int ks, int r, int s,
+                                               int chan, int kg, int li) {
+    const int p = ks * 4 + kg;
+    return tile[(((p >> 4) + r) * rowlen + (p & 15) + s) * stride + chan + li];
+  }
+  static __device__ __forceinline__ float ones() { return 1.0f; }
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+template <> struct WgFrag<bf16_t> {
+  // v_mfma_f32_16x16x32_bf16 wants 8 contraction (pixel) values per lane, but the tile is pixel-major.
+  // ds_read_b64_tr_b16 is the gfx950 transpose read for exactly this: inside each 16-lane group every
+  // lane fetches 8 bytes (4 channels of ONE pixel) and receives 4 PIXELS of ONE channel:
+  //   out[lane i][j] = in[lane 4*j + (i>>2)][i&3]
+  // so lane i addresses pixel (4*kg + (i>>2)), channels chan + 4*(i&3) .. +3, and gets channel chan+i at
+  // pixels 4*kg .. 4*kg+3 (tests/test_ops_gpu.py::test_tr16_semantics pins this on hardware).
+  // KSTEP = 32 pixels = tile rows 2ks and 2ks+1: two transpose reads (A and B use the same pixel order,
+  // which is all the contraction needs).  Tap shifts are row/column offsets of 8-byte aligned addresses.
+  static __device__ __forceinline__ bf16x8 load(const bf16_t* tile, int rowlen, int stride, int ks, int r, int s,
+                                                int chan, int kg, int li) {
+    const bf16_t* p0 = tile + ((2 * ks + r) * rowlen + 4 * kg + (li >> 2) + s) * stride + chan + 4 * (li & 3);
+    const bf16_t* p1 = p0 + rowlen * stride;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    union {
+      s16x4_t h[2];
+      bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+  }
+  static __device__ __forceinline__ bf16x8 ones() {
+    bf16x8 v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = base[e * stride];
-  return v;
-}
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)1.0f;
+    return v;
+  }
+};
 
 template <typename T, int KS, int TH, int NFO, int NFI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
   constexpr int BCI = NFI * 16, BCO = NFO * 16;
-  constexpr int XP = BCI + VG, DP = BCO + VG;  // padded LDS pixel strides
+  constexpr int XP = BCI + VG, DP = BCO + VG;  // padded LDS pixel strides (16-byte multiples)
   constexpr int VPX = BCI / VG, VPD = BCO / VG;
   constexpr int NKS = TH * 16 / KSTEP;         // k-steps per spatial tile
   typedef typename DT<T>::vec_t vec_t;
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xs = reinterpret_cast<T*>(smem);           // [XH*XW][XP]
   T* ds = xs + XH * XW * XP;                    // [TH*16][DP]
-  float* red = reinterpret_cast<float*>(smem);  // reused at the end: [KK][BCO][BCI] (+ [BCO] bias)
+  float* red = reinterpret_cast<float*>(smem);  // reused at the end: [KK][BCO][BCI] then [BCO] (bias)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
@@ -344,15 +375,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const T* dyg = reinterpret_cast<const T*>(a.dy);
   const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
   const bool dvec_ok = (cout % VG == 0);
+  const bool want_bias = a.dbias != nullptr && cit == 0;
 
   f32x4 acc[KK][NFO][NFI];
+  f32x4 accb[NFO];                              // dbias via a ones operand: D[co][*] = sum_pix dy[pix][co]
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
     for (int o = 0; o < NFO; ++o)
 #pragma unroll
       for (int i = 0; i < NFI; ++i) acc[t][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;  // thread tid < BCO accumulates dbias for channel tid (cit == 0 blocks only)
+#pragma unroll
+  for (int o = 0; o < NFO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const frag_t onesv = WgFrag<T>::ones();
 
   const int ntiles = a.N * a.tilesX * a.tilesY;
   for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
@@ -381,40 +416,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     __syncthreads();
 
     for (int ks = wave; ks < NKS; ks += 4) {
-      // this lane's first contraction pixel inside the tile, and how its KV pixels are strided
-      int prow, pcol;
-      if constexpr (KSTEP == 4) {
-        const int p = ks * 4 + kg;
-        prow = p / 16;
-        pcol = p % 16;
-      } else {
-        prow = ks * 2 + (kg >> 1);
-        pcol = (kg & 1) * 8;
-      }
       frag_t av[NFO];
 #pragma unroll
-      for (int o = 0; o < NFO; ++o) av[o] = gather_k<T>(&ds[(prow * 16 + pcol) * DP + o * 16 + li], DP);
+      for (int o = 0; o < NFO; ++o) {
+        av[o] = WgFrag<T>::load(ds, 16, DP, ks, 0, 0, o * 16, kg, li);
+        if (want_bias) accb[o] = mfma16(av[o], onesv, accb[o]);
+      }
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const int r = t / KS, s = t % KS;
 #pragma unroll
         for (int i = 0; i < NFI; ++i) {
-          const frag_t bv = gather_k<T>(&xs[((prow + r) * XW + pcol + s) * XP + i * 16 + li], XP);
+          const frag_t bv = WgFrag<T>::load(xs, XW, XP, ks, r, s, i * 16, kg, li);
 #pragma unroll
           for (int o = 0; o < NFO; ++o) acc[t][o][i] = mfma16(av[o], bv, acc[t][o][i]);
         }
       }
     }
-    if (a.dbias && cit == 0 && tid < BCO) {
-      float s = 0.f;
-      for (int p = 0; p < TH * 16; ++p) s += to_f32(ds[p * DP + tid]);
-      bsum += s;
-    }
   }
 
   // ---- combine the 4 waves through LDS, then one global atomic per dw element
   __syncthreads();
-  for (int i = tid; i < KK * BCO * BCI; i += 256) red[i] = 0.f;
+  for (int i = tid; i < KK * BCO * BCI + BCO; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < KK; ++t)
@@ -428,6 +451,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
           const int co = o * 16 + kg * 4 + r, ci = i * 16 + li;
           atomicAdd(&red[(t * BCO + co) * BCI + ci], acc[t][o][i][r]);
         }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int o = 0; o < NFO; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[KK * BCO * BCI + o * 16 + kg * 4 + r], accb[o][r]);
+  }
   __syncthreads();
   for (int i = tid; i < KK * BCO * BCI; i += 256) {
     const int ci = i % BCI, co = (i / BCI) % BCO, t = i / (BCI * BCO);
@@ -437,9 +466,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       if (v != 0.f) atomicAdd(&a.dw[((size_t)gco * KK + t) * cin + gci], v);
     }
   }
-  if (a.dbias && cit == 0 && tid < BCO) {
+  if (want_bias && tid < BCO) {
     const int gco = cot * BCO + tid;
-    if (gco < cout) atomicAdd(&a.dbias[gco], bsum);
+    if (gco < cout) atomicAdd(&a.dbias[gco], red[KK * BCO * BCI + tid]);
   }
 }
 
@@ -449,7 +478,7 @@ static int launch_conv_wgrad(const WgradArgs& a, hipStream_t st) {
   constexpr int VG = DT<T>::VG;
   constexpr int BCI = NFI * 16, BCO = NFO * 16, XP = BCI + VG, DP = BCO + VG;
   size_t lds = (size_t)(XH * XW * XP + TH * 16 * DP) * sizeof(T);
-  const size_t red = (size_t)KK * BCO * BCI * sizeof(float);
+  const size_t red = (size_t)(KK * BCO * BCI + BCO) * sizeof(float);
   if (lds < red) lds = red;
   const long blocks = (long)a.spatialBlocks * a.nco * a.nci;
   hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI>), dim3((unsigned)blocks), dim3(256), lds, st, a);

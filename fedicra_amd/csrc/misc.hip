@@ -416,4 +416,24 @@ extern "C" int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, con
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// hardware probe: ds_read_b64_tr_b16 (gfx950 LDS transpose read) with caller-chosen per-lane addresses
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short probe_s16x4;
+__global__ void probe_tr16_kernel(const short* in, const int* offs, short* out) {
+  __shared__ __attribute__((aligned(16))) short lds[1024];
+  const int l = threadIdx.x;
+  for (int i = l; i < 1024; i += 64) lds[i] = in[i];
+  __syncthreads();
+  const probe_s16x4 v =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) probe_s16x4*)(lds + offs[l]));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = v[j];
+}
+extern "C" int fi_probe_tr16(const short* in, const int* offs, short* out, void* stream) {
+  if (!in || !offs || !out) return FI_ERR_NULL;
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, offs, out);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int fi_abi_version(void) { return 1; }

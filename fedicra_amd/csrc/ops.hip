@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   const int CV = C / VG;
   const uint64_t seed = drop_seed(dr);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * VG;
-    const size_t pixel = (size_t)(i / CV);
+    const int c0 = (int)((unsigned)i % (unsigned)CV) * VG;   // nvec < 2^32 (checked on the host): 32-bit udiv
+    const size_t pixel = (size_t)((unsigned)i / (unsigned)CV);
     float f[VG];
     load_vec<T>(y + i * VG, f);
 #pragma unroll
@@ -160,11 +160,13 @@ extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale
   if (d->dtype == FI_F32) {
     if (d->C % 4) return FI_ERR_SHAPE;
     const long nvec = d->pixels * (d->C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const float*)y,
                        scale, shift, (float*)z, nvec, d->C, d->slope, dr);
   } else if (d->dtype == FI_BF16) {
     if (d->C % 8) return FI_ERR_SHAPE;
     const long nvec = d->pixels * (d->C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const bf16_t*)y,
                        scale, shift, (bf16_t*)z, nvec, d->C, d->slope, dr);
   } else {
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   const uint64_t seed = drop_seed(dr);
   const float invM = (float)(1.0 / (double)pixels);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * VG;
-    const size_t pixel = (size_t)(i / CV);
+    const int c0 = (int)((unsigned)i % (unsigned)CV) * VG;   // nvec < 2^32 (checked on the host): 32-bit udiv
+    const size_t pixel = (size_t)((unsigned)i / (unsigned)CV);
     float dzv[VG], yv[VG], g[VG], out[VG];
     load_vec<T>(dz + i * VG, dzv);
     load_vec<T>(y + i * VG, yv);
@@ -315,12 +317,14 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
   if (d->dtype == FI_F32) {
     if (d->C % 4) return FI_ERR_SHAPE;
     const long nvec = d->pixels * (d->C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
                        (const float*)dz, (const float*)y, scale, shift, mean, invstd, sums, training, (float*)dy,
                        dgamma, dbeta, accumulate_param, nvec, d->pixels, d->C, d->slope, dr);
   } else if (d->dtype == FI_BF16) {
     if (d->C % 8) return FI_ERR_SHAPE;
     const long nvec = d->pixels * (d->C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
                        (const bf16_t*)dz, (const bf16_t*)y, scale, shift, mean, invstd, sums, training, (bf16_t*)dy,
                        dgamma, dbeta, accumulate_param, nvec, d->pixels, d->C, d->slope, dr);
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   const int CV = C / VG, Ho = H / 2, Wo = W / 2;
   const long nvec = (long)N * Ho * Wo * CV;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
+    const int cv = (int)((unsigned)i % (unsigned)CV);
+    unsigned p = (unsigned)i / (unsigned)CV;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
@@ -373,8 +377,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   const int CV = C / VG, Ho = H / 2, Wo = W / 2;
   const long nvec = (long)N * Ho * Wo * CV;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
+    const int cv = (int)((unsigned)i % (unsigned)CV);
+    unsigned p = (unsigned)i / (unsigned)CV;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
@@ -418,11 +422,13 @@ extern "C" int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, 
   if (dtype == FI_F32) {
     if (C % 4) return FI_ERR_SHAPE;
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
                        (float*)y, N, H, W, C);
   } else if (dtype == FI_BF16) {
     if (C % 8) return FI_ERR_SHAPE;
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const bf16_t*)x,
                        (bf16_t*)y, N, H, W, C);
   } else {
@@ -440,11 +446,13 @@ extern "C" int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* d
   if (dtype == FI_F32) {
     if (C % 4) return FI_ERR_SHAPE;
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
                        (const float*)dy, (float*)dx, N, H, W, C, accumulate);
   } else if (dtype == FI_BF16) {
     if (C % 8) return FI_ERR_SHAPE;
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
                        (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
   } else {
@@ -476,8 +484,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
   const int CV = C / VG, Ho = 2 * h, Wo = 2 * w;
   const long nvec = (long)N * Ho * Wo * CV;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
+    const int cv = (int)((unsigned)i % (unsigned)CV);
+    unsigned p = (unsigned)i / (unsigned)CV;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
@@ -507,8 +515,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   const int CV = C / VG, Ho = 2 * h, Wo = 2 * w;
   const long nvec = (long)N * h * w * CV;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
+    const int cv = (int)((unsigned)i % (unsigned)CV);
+    unsigned p = (unsigned)i / (unsigned)CV;
     const int ix = (int)(p % w);
     p /= w;
     const int iy = (int)(p % h);
@@ -572,11 +580,13 @@ extern "C" int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h
   if (dtype == FI_F32) {
     if (C % 4) return FI_ERR_SHAPE;
     const long nvec = (long)N * 4 * h * w * (C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
                        (float*)y, N, h, w, C, up_scale(h), up_scale(w));
   } else if (dtype == FI_BF16) {
     if (C % 8) return FI_ERR_SHAPE;
     const long nvec = (long)N * 4 * h * w * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
                        (const bf16_t*)x, (bf16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
   } else {
@@ -593,11 +603,13 @@ extern "C" int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int
   if (dtype == FI_F32) {
     if (C % 4) return FI_ERR_SHAPE;
     const long nvec = (long)N * h * w * (C / 4);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const float*)dy,
                        (float*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
   } else if (dtype == FI_BF16) {
     if (C % 8) return FI_ERR_SHAPE;
     const long nvec = (long)N * h * w * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const bf16_t*)dy,
                        (bf16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
   } else {

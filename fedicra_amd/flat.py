@@ -36,6 +36,9 @@ class FlatStoreMixin:
 
     def _fi_finish_init(self):
         self._fi_flat_ready = False
+        for i, m in enumerate(self.modules()):     # stable per-layer ids for the dropout seed stream (ops._drop_spec)
+            if isinstance(m, nn.BatchNorm2d):
+                m._fi_uid = i + 1
         self._fi_reflatten()
 
     # -- construction ---------------------------------------------------------------------------

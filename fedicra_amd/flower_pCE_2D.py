@@ -87,6 +87,7 @@ class MyClient(BaseClient):
         """zero-grad, forward, loss, backward, optimizer step, LR update -- all device work."""
         args = self.args
         opt = self.optimizer
+        ops.begin_iteration()
         opt.zero_grad()
         out = self.model(x)
         logits = out[0]

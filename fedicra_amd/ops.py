@@ -40,11 +40,25 @@ def set_dropout_seed_offset(t):
 
 
 def manual_seed(seed: int):
-    global _drop_seed
+    global _drop_seed, _base_seed
     _drop_seed = itertools.count(int(seed) * 0x9E3779B1 + 0x5EED)
+    _base_seed = int(seed) * 0x9E3779B1 + 0x5EED
 
 
-def _drop_spec(p, kind, N, H, W, Cc, device):
+_base_seed = 0x5EED
+_layer_uid = {}                # id(bn module) -> small stable integer (order of first use)
+_call_idx = {}                 # uid -> how many times this layer drew a mask in the current iteration
+
+
+def begin_iteration():
+    """Call at the start of every training iteration: dropout seeds are then a pure function of
+    (manual_seed, layer, n-th call of that layer within the iteration, device iteration counter), so an
+    eager run and a replayed hipGraph draw identical masks, while repeated forwards inside one iteration
+    (FedICRA's no-grad forwards with other clients' embeddings) still get independent masks."""
+    _call_idx.clear()
+
+
+def _drop_spec(p, kind, N, H, W, Cc, device, owner=None):
     """kind: 'elem' (nn.Dropout) or 'chan' (nn.Dropout2d).  Returns the tuple _lib._bnact expects."""
     if p <= 0.0:
         return None
@@ -54,7 +68,15 @@ def _drop_spec(p, kind, N, H, W, Cc, device):
         m = (m != 0).to(torch.uint8)
         m = m.permute(0, 2, 3, 1).contiguous().to(device) if kind == "elem" else m.reshape(N, Cc).contiguous().to(device)
         return (L.DROP_MASK_ELEM if kind == "elem" else L.DROP_MASK_CHAN, float(p), 0, m, None)
-    return (L.DROP_RNG_ELEM if kind == "elem" else L.DROP_RNG_CHAN, float(p), next(_drop_seed), None, _seed_offset)
+    mode = L.DROP_RNG_ELEM if kind == "elem" else L.DROP_RNG_CHAN
+    if _seed_offset is None or owner is None:
+        return (mode, float(p), next(_drop_seed), None, _seed_offset)
+    uid = getattr(owner, "_fi_uid", None)         # FlatStoreMixin numbers the BN modules of a model in order
+    if uid is None:
+        uid = _layer_uid.setdefault(id(owner), 1000 + len(_layer_uid))
+    k = _call_idx.get(uid, 0)
+    _call_idx[uid] = k + 1
+    return (mode, float(p), _base_seed + (uid << 24) + k * 0x10001, None, _seed_offset)
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -172,7 +194,7 @@ class _ConvBNAct(Function):
         coef = torch.empty(4, cout, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
         L.bn_finalize(stats, float(N * H * W), gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                       bn.momentum, bn.eps, training, coef[0], coef[1], coef[2], coef[3])
-        drop = _drop_spec(drop_p, drop_kind, N, H, W, cout, dev) if training else None
+        drop = _drop_spec(drop_p, drop_kind, N, H, W, cout, dev, owner=bn) if training else None
         z = torch.empty_like(y)
         L.bn_act_fwd(y, coef[0], coef[1], z, slope, drop)
         ctx.save_for_backward(x0, x1, wk, y, coef)

@@ -184,6 +184,11 @@ int fi_channel_gate_fwd(int dtype, const void* x, const float* h, void* y, int N
 int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, const float* h, const int* amax, const float* davg,
                         const float* dmx, void* dx, float* dh, int N, int HW, int C, void* stream);
 
+/* Diagnostic: one wavefront executes ds_read_b64_tr_b16 on a 1024-element int16 LDS image of `in`; lane l
+ * addresses element offs[l] (multiple of 4); out[l*4+j] = j-th returned element.  Pins the transpose-read
+ * semantics the bf16 wgrad kernel relies on (tests/test_ops_gpu.py::test_tr16_semantics). */
+int fi_probe_tr16(const short* in, const int* offs, short* out, void* stream);
+
 /* misc elementwise */
 int fi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* NCHW fp32 (reference layout) <-> NHWC `dtype` */

