@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfedicra_hip.so")
 
 FI_F32, FI_BF16 = 0, 1
+STATS_SLOTS = 32               # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_pack_weights", "fi_bn_finalize", "fi_bn_act_fwd",
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_pack_weights", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
@@ -53,6 +54,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
+        _lib.fi_conv2d_wgrad_workspace.restype = C.c_long
     return _lib
 
 
@@ -172,16 +174,23 @@ def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False,
                                  stream()), "fi_conv2d_fwd")
 
 
-def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize):
+def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize, deterministic=True):
     _dev(x0)
     N, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[3], 0, 0, 0, 0)
     cin, cout, px = c0 + c1, dy.shape[3], N * H * W
+    ws = None
+    nbytes = 0
+    if deterministic:
+        nbytes = lib().fi_conv2d_wgrad_workspace(C.byref(d))
+        if nbytes < 0:
+            _chk(int(nbytes), "fi_conv2d_wgrad_workspace")
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)     # caller-owned workspace
     with _timed("conv_wgrad", (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
                 px * cin * _esz(x0) + px * cout * _esz(dy) + cin * cout * ksize * ksize * 4):
-        _chk(lib().fi_conv2d_wgrad(C.byref(d), ptr(x0), ptr(x1), ptr(dy), ptr(dw), ptr(dbias), stream()),
-             "fi_conv2d_wgrad")
+        _chk(lib().fi_conv2d_wgrad(C.byref(d), ptr(x0), ptr(x1), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
+                                   C.c_long(nbytes), stream()), "fi_conv2d_wgrad")
 
 
 def pack_weights(src, dst, cout, kk, cin, mode):

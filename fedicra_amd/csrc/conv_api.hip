@@ -66,40 +66,82 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
   return d->ksize == 3 ? fi_conv_fwd_bf16_k3(th, nf, ck, a, st) : fi_conv_fwd_bf16_k1(th, nf, ck, a, st);
 }
 
-extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
-                               float* dbias, void* stream) {
-  if (!d || !x0 || !dy || !dw) return FI_ERR_NULL;
+// Work decomposition of wgrad: channel tiles (16*nfo couts x 16*nfi cins) x `sb` spatial workgroups, each
+// walking ntiles/sb pixel tiles with register accumulators (~4 workgroups per CU in total).
+struct WgradPlan {
+  int nfo, nfi, nco, nci, th, tilesX, tilesY, sb;
+  size_t part_stride;
+};
+static int plan_wgrad(const FiConv* d, WgradPlan* p) {
+  if (!d) return FI_ERR_NULL;
   if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1) return FI_ERR_SHAPE;
+  const int cin = d->c0 + d->c1, cout = d->co0;
+  p->nfo = 1;
+  p->nfi = cin > 16 ? 2 : 1;
+  p->nco = fi_cdiv(cout, p->nfo * 16);
+  p->nci = fi_cdiv(cin, p->nfi * 16);
+  p->th = pick_th(d->N, d->H, d->W, (long)p->nco * p->nci);
+  p->tilesX = fi_cdiv(d->W, 16);
+  p->tilesY = fi_cdiv(d->H, p->th);
+  const long ntiles = (long)d->N * p->tilesX * p->tilesY;
+  long sb = (256L * 4) / ((long)p->nco * p->nci);
+  if (sb < 1) sb = 1;
+  if (sb > ntiles) sb = ntiles;
+  p->sb = (int)sb;
+  p->part_stride = (size_t)cout * d->ksize * d->ksize * cin + cout;
+  return 0;
+}
+
+extern "C" long fi_conv2d_wgrad_workspace(const FiConv* d) {
+  WgradPlan p;
+  const int rc = plan_wgrad(d, &p);
+  if (rc) return rc;
+  return (long)(p.part_stride * p.sb * sizeof(float));
+}
+
+extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
+                               float* dbias, void* workspace, long workspace_bytes, void* stream) {
+  if (!d || !x0 || !dy || !dw) return FI_ERR_NULL;
+  WgradPlan p;
+  const int rc = plan_wgrad(d, &p);
+  if (rc) return rc;
   if (d->c1 > 0 && !x1) return FI_ERR_NULL;
   const int cin = d->c0 + d->c1, cout = d->co0;
-  const int nfo = 1, nfi = cin > 16 ? 2 : 1;
-  const int nco = fi_cdiv(cout, nfo * 16), nci = fi_cdiv(cin, nfi * 16);
-  const int th = pick_th(d->N, d->H, d->W, (long)nco * nci);
+  if (workspace && workspace_bytes < (long)(p.part_stride * p.sb * sizeof(float))) return FI_ERR_SHAPE;
   WgradArgs a;
   a.x0 = x0;
   a.x1 = x1 ? x1 : x0;
   a.dy = dy;
   a.dw = dw;
   a.dbias = dbias;
+  a.part = (float*)workspace;
+  a.part_stride = p.part_stride;
   a.N = d->N;
   a.H = d->H;
   a.W = d->W;
   a.c0 = d->c0;
   a.c1 = d->c1;
   a.cout = cout;
-  a.tilesX = fi_cdiv(d->W, 16);
-  a.tilesY = fi_cdiv(d->H, th);
-  a.nco = nco;
-  a.nci = nci;
-  const long ntiles = (long)a.N * a.tilesX * a.tilesY;
-  long sb = (256L * 4) / ((long)nco * nci);  // ~4 workgroups per CU in total
-  if (sb < 1) sb = 1;
-  if (sb > ntiles) sb = ntiles;
-  a.spatialBlocks = (int)sb;
+  a.tilesX = p.tilesX;
+  a.tilesY = p.tilesY;
+  a.nco = p.nco;
+  a.nci = p.nci;
+  a.spatialBlocks = p.sb;
   hipStream_t st = (hipStream_t)stream;
+  int r;
   if (d->dtype == FI_F32)
-    return d->ksize == 3 ? fi_conv_wgrad_f32_k3(th, nfo, nfi, a, st) : fi_conv_wgrad_f32_k1(th, nfo, nfi, a, st);
-  return d->ksize == 3 ? fi_conv_wgrad_bf16_k3(th, nfo, nfi, a, st) : fi_conv_wgrad_bf16_k1(th, nfo, nfi, a, st);
+    r = d->ksize == 3 ? fi_conv_wgrad_f32_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_f32_k1(p.th, p.nfo, p.nfi, a, st);
+  else
+    r = d->ksize == 3 ? fi_conv_wgrad_bf16_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_bf16_k1(p.th, p.nfo, p.nfi, a, st);
+  if (r || !workspace) return r;
+  const size_t n_dw = (size_t)cout * d->ksize * d->ksize * cin;
+  const size_t n = n_dw + (dbias ? cout : 0);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, p.part_stride, p.sb,
+                     dw, n_dw, dbias, cout);
+  FI_CHECK_LAUNCH();
+  return 0;
 }

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         double tot = 0.0;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) tot += (double)red[(wv * BN + c) * 2 + which];
-        atomicAdd(&a.stats[(size_t)co * 2 + which], tot);
+        // FI_STATS_SLOTS copies of the accumulator: thousands of workgroups adding to the same 2*C
+        // addresses serialise in L2; spreading them over 32 slots (summed by fi_bn_finalize) removes that.
+        const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
+        atomicAdd(&a.stats[((size_t)slot * cout + co) * 2 + which], tot);
       }
     }
   }
@@ -295,6 +298,8 @@ struct WgradArgs {
   const void* dy;
   float* dw;
   float* dbias;
+  float* part;          // workspace [spatialBlocks][part_stride] for the two-stage reduction, or NULL (atomics)
+  size_t part_stride;   // cout*KK*cin + cout (bias), in floats
   int N, H, W;
   int c0, c1, cout;
   int tilesX, tilesY, nco, nci, spatialBlocks;
@@ -458,6 +463,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) atomicAdd(&red[KK * BCO * BCI + o * 16 + kg * 4 + r], accb[o][r]);
   }
   __syncthreads();
+  if (a.part) {
+    // two-stage, deterministic: this workgroup's partial sums go to its own slice of the caller's
+    // workspace with plain stores; wgrad_reduce_kernel then adds the slices in a fixed order.
+    float* slice = a.part + (size_t)sb * a.part_stride;
+    for (int i = tid; i < KK * BCO * BCI; i += 256) {
+      const int ci = i % BCI, co = (i / BCI) % BCO, t = i / (BCI * BCO);
+      const int gco = cot * BCO + co, gci = cit * BCI + ci;
+      if (gco < cout && gci < cin) slice[((size_t)gco * KK + t) * cin + gci] = red[i];
+    }
+    if (a.dbias && cit == 0 && tid < BCO) {
+      const int gco = cot * BCO + tid;
+      if (gco < cout) slice[(size_t)cout * KK * cin + gco] = red[KK * BCO * BCI + tid];
+    }
+    return;
+  }
   for (int i = tid; i < KK * BCO * BCI; i += 256) {
     const int ci = i % BCI, co = (i / BCI) % BCO, t = i / (BCI * BCO);
     const int gco = cot * BCO + co, gci = cit * BCI + ci;
@@ -469,6 +489,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (want_bias && tid < BCO) {
     const int gco = cot * BCO + tid;
     if (gco < cout) atomicAdd(&a.dbias[gco], red[KK * BCO * BCI + tid]);
+  }
+}
+
+// second stage of the deterministic wgrad: dw[i] += sum_s part[s][i]  (i < n_dw), dbias likewise
+static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, size_t stride, int slices,
+                                                           float* __restrict__ dw, size_t n_dw,
+                                                           float* __restrict__ dbias, int cout) {
+  const size_t n = n_dw + (dbias ? (size_t)cout : 0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)k * stride + i];
+    if (i < n_dw)
+      dw[i] += s;
+    else
+      dbias[i - n_dw] += s;
   }
 }
 

@@ -49,8 +49,13 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
   if (c >= C) return;
   float mu, istd;
   if (training) {
-    const double m = stats[2 * c] / count;
-    double var = stats[2 * c + 1] / count - m * m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) {   // fixed order: deterministic given the slot contents
+      s1 += stats[((size_t)slot * C + c) * 2];
+      s2 += stats[((size_t)slot * C + c) * 2 + 1];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     mu = (float)m;
     istd = (float)(1.0 / sqrt(var + (double)eps));
@@ -134,16 +139,27 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                                                          const float* __restrict__ shift, T* __restrict__ z,
                                                          long nvec, int C, float slope, DropSpec dr) {
   constexpr int VG = DT<T>::VG;
-  const int CV = C / VG;
+  // CV = C/VG divides the 256-thread block (host-checked): a thread keeps the SAME channel vector for its
+  // whole grid-stride walk, so the per-channel coefficients are loaded once into registers and the loop
+  // body is pure streaming (no per-element coefficient loads, no integer division).
+  const unsigned CV = C / VG;
+  const int c0 = (int)(threadIdx.x % CV) * VG;
+  float sc[VG], sh[VG];
+#pragma unroll
+  for (int j = 0; j < VG; ++j) {
+    sc[j] = scale[c0 + j];
+    sh[j] = shift[c0 + j];
+  }
   const uint64_t seed = drop_seed(dr);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)((unsigned)i % (unsigned)CV) * VG;   // nvec < 2^32 (checked on the host): 32-bit udiv
-    const size_t pixel = (size_t)((unsigned)i / (unsigned)CV);
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x, istep = gridDim.x * 256u;
+  unsigned pixel = i0 / CV;
+  const unsigned pstep = istep / CV;
+  for (long i = i0; i < nvec; i += istep, pixel += pstep) {
     float f[VG];
     load_vec<T>(y + i * VG, f);
 #pragma unroll
     for (int j = 0; j < VG; ++j) {
-      float v = f[j] * scale[c0 + j] + shift[c0 + j];
+      float v = f[j] * sc[j] + sh[j];
       v = v > 0.f ? v : v * slope;
       if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel, c0 + j);
       f[j] = v;
@@ -155,6 +171,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z,
                              void* stream) {
   if (!d || !y || !scale || !shift || !z) return FI_ERR_NULL;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  {
+    const int vg = d->dtype == FI_F32 ? 4 : 8;
+    if (d->C % vg || d->C / vg > 256 || 256 % (d->C / vg)) return FI_ERR_SHAPE;   // CV must divide the block
+  }
   const DropSpec dr = make_drop(d);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == FI_F32) {
@@ -179,11 +200,12 @@ extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale
 // g = dz through dropout and the activation, evaluated from the saved conv output y
 template <typename T>
 __device__ __forceinline__ void act_grad(const float (&dzv)[DT<T>::VG], const float (&yv)[DT<T>::VG],
-                                         const float* scale, const float* shift, int c0, size_t pixel, float slope,
-                                         const DropSpec& dr, uint64_t seed, float (&g)[DT<T>::VG]) {
+                                         const float (&scale)[DT<T>::VG], const float (&shift)[DT<T>::VG], int c0,
+                                         size_t pixel, float slope, const DropSpec& dr, uint64_t seed,
+                                         float (&g)[DT<T>::VG]) {
 #pragma unroll
   for (int j = 0; j < DT<T>::VG; ++j) {
-    const float v = yv[j] * scale[c0 + j] + shift[c0 + j];
+    const float v = yv[j] * scale[j] + shift[j];
     float gg = dzv[j];
     if (dr.mode != FI_DROP_NONE) gg *= drop_factor(dr, seed, pixel, c0 + j);
     g[j] = v > 0.f ? gg : gg * slope;
@@ -203,18 +225,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
   const int c0 = cv * VG;
   const uint64_t seed = drop_seed(dr);
-  float sg[VG], sgx[VG];
+  float sg[VG], sgx[VG], sc[VG], sh[VG], mu[VG], is[VG];
 #pragma unroll
-  for (int j = 0; j < VG; ++j) sg[j] = sgx[j] = 0.f;
+  for (int j = 0; j < VG; ++j) {
+    sg[j] = sgx[j] = 0.f;
+    sc[j] = scale[c0 + j];
+    sh[j] = shift[c0 + j];
+    mu[j] = mean[c0 + j];
+    is[j] = invstd[c0 + j];
+  }
   for (long p = (long)blockIdx.x * PS + pl; p < pixels; p += (long)gridDim.x * PS) {
     float dzv[VG], yv[VG], g[VG];
     load_vec<T>(dz + (p * CV + cv) * VG, dzv);
     load_vec<T>(y + (p * CV + cv) * VG, yv);
-    act_grad<T>(dzv, yv, scale, shift, c0, (size_t)p, slope, dr, seed, g);
+    act_grad<T>(dzv, yv, sc, sh, c0, (size_t)p, slope, dr, seed, g);
 #pragma unroll
     for (int j = 0; j < VG; ++j) {
       sg[j] += g[j];
-      sgx[j] += g[j] * (yv[j] - mean[c0 + j]) * invstd[c0 + j];
+      sgx[j] += g[j] * (yv[j] - mu[j]) * is[j];
     }
   }
   __shared__ float red[256][2 * VG + 1];
@@ -229,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     const int tcv = c / VG, j = c % VG;
     double tot = 0.0;
     for (int q = 0; q < PS; ++q) tot += (double)red[q * CV + tcv][which * VG + j];
-    atomicAdd(&sums[2 * c + which], tot);
+    atomicAdd(&sums[((size_t)(blockIdx.x & (FI_STATS_SLOTS - 1)) * C + c) * 2 + which], tot);   // slot: see conv epilogue
   }
   // C*2 can exceed 256 (C up to 512): remaining channels in further strides
   for (int t = threadIdx.x + 256; t < C * 2; t += 256) {
@@ -237,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     const int tcv = c / VG, j = c % VG;
     double tot = 0.0;
     for (int q = 0; q < PS; ++q) tot += (double)red[q * CV + tcv][which * VG + j];
-    atomicAdd(&sums[2 * c + which], tot);
+    atomicAdd(&sums[((size_t)(blockIdx.x & (FI_STATS_SLOTS - 1)) * C + c) * 2 + which], tot);
   }
 }
 
@@ -276,9 +304,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                float slope, DropSpec dr) {
   constexpr int VG = DT<T>::VG;
   const int CV = C / VG;
+  // sums arrives as FI_STATS_SLOTS partial accumulators: fold them once per workgroup into LDS
+  __shared__ float ssum[2 * 512];
+  for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
+    double tot = 0.0;
+    for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) tot += sums[(size_t)slot * 2 * C + t];
+    ssum[t] = (float)tot;
+  }
+  __syncthreads();
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const float dg = (float)sums[2 * c + 1], db = (float)sums[2 * c];
+      const float dg = ssum[2 * c + 1], db = ssum[2 * c];
       if (dgamma) dgamma[c] = accumulate_param ? dgamma[c] + dg : dg;
       if (dbeta) dbeta[c] = accumulate_param ? dbeta[c] + db : db;
     }
@@ -286,23 +322,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   if (!dy) return;
   const uint64_t seed = drop_seed(dr);
   const float invM = (float)(1.0 / (double)pixels);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)((unsigned)i % (unsigned)CV) * VG;   // nvec < 2^32 (checked on the host): 32-bit udiv
-    const size_t pixel = (size_t)((unsigned)i / (unsigned)CV);
+  // per-thread channel constants (CV divides 256, see bn_act_fwd_kernel):
+  //   dy = sc*g - k0 - (y - mu)*k1   with k0 = sc*sum_g/M, k1 = sc*invstd*sum_gx/M   (training)
+  const unsigned CVu = CV;
+  const int c0 = (int)(threadIdx.x % CVu) * VG;
+  float sc[VG], sh[VG], mu[VG], k0[VG], k1[VG];
+#pragma unroll
+  for (int j = 0; j < VG; ++j) {
+    const int c = c0 + j;
+    sc[j] = scale[c];
+    sh[j] = shift[c];
+    mu[j] = mean[c];
+    k0[j] = training ? sc[j] * (ssum[2 * c] * invM) : 0.f;
+    k1[j] = training ? sc[j] * invstd[c] * (ssum[2 * c + 1] * invM) : 0.f;
+  }
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x, istep = gridDim.x * 256u;
+  unsigned pixel = i0 / CVu;
+  const unsigned pstep = istep / CVu;
+  for (long i = i0; i < nvec; i += istep, pixel += pstep) {
     float dzv[VG], yv[VG], g[VG], out[VG];
     load_vec<T>(dz + i * VG, dzv);
     load_vec<T>(y + i * VG, yv);
-    act_grad<T>(dzv, yv, scale, shift, c0, pixel, slope, dr, seed, g);
+    act_grad<T>(dzv, yv, sc, sh, c0, pixel, slope, dr, seed, g);
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      const int c = c0 + j;
-      if (training) {
-        const float xh = (yv[j] - mean[c]) * invstd[c];
-        out[j] = scale[c] * (g[j] - (float)sums[2 * c] * invM - xh * (float)sums[2 * c + 1] * invM);
-      } else {
-        out[j] = scale[c] * g[j];
-      }
-    }
+    for (int j = 0; j < VG; ++j) out[j] = sc[j] * g[j] - k0[j] - (yv[j] - mu[j]) * k1[j];
     store_vec<T>(dy + i * VG, out);
   }
 }
@@ -312,6 +355,11 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
                                    int training, void* dy, float* dgamma, float* dbeta, int accumulate_param,
                                    void* stream) {
   if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  {
+    const int vg = d->dtype == FI_F32 ? 4 : 8;
+    if (d->C % vg || d->C / vg > 256 || 256 % (d->C / vg) || d->C > 512) return FI_ERR_SHAPE;   // CV divides the block; LDS fold holds 512 channels
+  }
   const DropSpec dr = make_drop(d);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == FI_F32) {

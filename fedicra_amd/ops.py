@@ -189,7 +189,7 @@ class _ConvBNAct(Function):
         training = bn.training
         wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin)
         y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev)
-        stats = torch.zeros(cout * 2, dtype=torch.float64, device=dev) if training else None
+        stats = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=dev) if training else None
         L.conv2d_fwd(x0, x1, wp, bias, y, None, stats, ksize=ksize)
         coef = torch.empty(4, cout, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
         L.bn_finalize(stats, float(N * H * W), gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -211,7 +211,7 @@ class _ConvBNAct(Function):
         x0, x1, wk, y, coef = ctx.saved_tensors
         dz = dz.contiguous()
         cout = y.shape[3]
-        sums = torch.zeros(cout * 2, dtype=torch.float64, device=y.device)
+        sums = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=y.device)
         L.bn_act_bwd_reduce(dz, y, coef[0], coef[1], coef[2], coef[3], sums, ctx.slope, ctx.drop)
         gg = gbeta = None
         dgam = dbet = None

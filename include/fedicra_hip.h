@@ -64,16 +64,22 @@ typedef struct FiConv {
 } FiConv;
 
 /* y = conv(cat(x0,x1), w) + bias.  w: [co0+co1][k*k][c0+c1] in `dtype` (see fi_pack_weights).
- * bias: fp32 [co0+co1] or NULL.  stats: fp64 [co0+co1][2], or NULL; when given, per-channel
- * (sum, sum of squares) of the stored output are ATOMICALLY ADDED (caller zeroes it) -- the
- * batch statistics BatchNorm2d (unet.py:21) needs, produced in the conv epilogue. */
+ * bias: fp32 [co0+co1] or NULL.  stats: fp64 [FI_STATS_SLOTS][co0+co1][2], or NULL; when given,
+ * per-channel (sum, sum of squares) of the stored output are ATOMICALLY ADDED to one of the slots
+ * (caller zeroes the whole buffer; fi_bn_finalize sums the slots) -- the batch statistics
+ * BatchNorm2d (unet.py:21) needs, produced in the conv epilogue. */
+#define FI_STATS_SLOTS 32
 int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                   void* y0, void* y1, double* stats, void* stream);
 
-/* dw[co][k*k][ci] += sum_pixels dy * x  (fp32, ATOMICALLY ADDED; caller zeroes);
- * dbias[co] += sum_pixels dy (fp32, may be NULL).  d->co0 = Cout, co1 ignored; dy is [N,H,W,Cout]. */
+/* dw[co][k*k][ci] += sum_pixels dy * x  (fp32);  dbias[co] += sum_pixels dy (fp32, may be NULL).
+ * d->co0 = Cout, co1 ignored; dy is [N,H,W,Cout].  With a caller-owned `workspace` of at least
+ * fi_conv2d_wgrad_workspace(d) bytes the reduction is two-stage and DETERMINISTIC (per-workgroup partial
+ * sums -> plain stores -> fixed-order sum); with workspace == NULL partial sums are added with fp32
+ * atomics (order-dependent rounding).  Either way the result is ADDED to dw / dbias (caller zeroes). */
+long fi_conv2d_wgrad_workspace(const FiConv* d);
 int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
-                    float* dbias, void* stream);
+                    float* dbias, void* workspace, long workspace_bytes, void* stream);
 
 /* weight repack from the fp32 master [Cout][k*k][Cin]:
  *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)
@@ -108,8 +114,9 @@ typedef struct FiBnAct {
 
 /* z = dropout(act(y*scale[c] + shift[c])) */
 int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z, void* stream);
-/* sums[c][0] += sum g, sums[c][1] += sum g*xhat   (g = dz through dropout and activation,
- * xhat = (y-mean)*invstd); fp64, atomically added, caller zeroes. */
+/* sums[slot][c][0] += sum g, sums[slot][c][1] += sum g*xhat   (g = dz through dropout and activation,
+ * xhat = (y-mean)*invstd); fp64 [FI_STATS_SLOTS][C][2], atomically added to one slot per workgroup, caller
+ * zeroes; fi_bn_act_bwd_apply folds the slots.  C <= 512 and C/vec must divide 256. */
 int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void* y, const float* scale, const float* shift,
                          const float* mean, const float* invstd, double* sums, void* stream);
 /* dy = scale*(g - sum_g/M - xhat*sum_gx/M) (training) or scale*g (eval);

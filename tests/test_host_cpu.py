@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
         g.build()
     lib = ctypes.CDLL(_lib.LIB_PATH)
     hdr = open(os.path.join(ROOT, "include", "fedicra_hip.h")).read()
-    declared = sorted(set(re.findall(r"^int\s+(fi_\w+)\s*\(", hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|long)\s+(fi_\w+)\s*\(", hdr, flags=re.M)))
     assert len(declared) >= 27
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fedicra_hip.h but not exported"

