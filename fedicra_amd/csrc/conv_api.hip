@@ -9,6 +9,10 @@ int fi_conv_wgrad_f32_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream
 int fi_conv_wgrad_f32_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_bf16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_bf16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_bf16_k1(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_bf16_k3(int th, const WgradArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -69,6 +73,7 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
 // Work decomposition of wgrad: channel tiles (16*nfo couts x 16*nfi cins) x `sb` spatial workgroups, each
 // walking ntiles/sb pixel tiles with register accumulators (~4 workgroups per CU in total).
 struct WgradPlan {
+  int quad;             // 1: 32x32 channel tile, one 16x16 quadrant per wave (Cin, Cout >= 32)
   int nfo, nfi, nco, nci, th, tilesX, tilesY, sb;
   size_t part_stride;
 };
@@ -78,15 +83,22 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p) {
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1) return FI_ERR_SHAPE;
   const int cin = d->c0 + d->c1, cout = d->co0;
-  p->nfo = 1;
-  p->nfi = cin > 16 ? 2 : 1;
+  p->quad = (cin >= 32 && cout >= 32) ? 1 : 0;
+  if (p->quad) {
+    p->nfo = p->nfi = 2;
+  } else {
+    p->nfo = 1;
+    p->nfi = cin > 16 ? 2 : 1;
+  }
   p->nco = fi_cdiv(cout, p->nfo * 16);
   p->nci = fi_cdiv(cin, p->nfi * 16);
   p->th = pick_th(d->N, d->H, d->W, (long)p->nco * p->nci);
+  if (p->quad && d->dtype == FI_F32 && p->th > 8) p->th = 8;   // fp32 quad tiles: 16 rows would exceed 64 KB LDS
   p->tilesX = fi_cdiv(d->W, 16);
   p->tilesY = fi_cdiv(d->H, p->th);
   const long ntiles = (long)d->N * p->tilesX * p->tilesY;
-  long sb = (256L * 4) / ((long)p->nco * p->nci);
+  // ~2 workgroups per CU in total; every spatial workgroup costs one |dw| slice of workspace traffic
+  long sb = (256L * 2) / ((long)p->nco * p->nci);
   if (sb < 1) sb = 1;
   if (sb > ntiles) sb = ntiles;
   p->sb = (int)sb;
@@ -131,15 +143,22 @@ extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, 
   a.spatialBlocks = p.sb;
   hipStream_t st = (hipStream_t)stream;
   int r;
-  if (d->dtype == FI_F32)
+  if (p.quad) {
+    if (d->dtype == FI_F32)
+      r = d->ksize == 3 ? fi_conv_wgrad_quad_f32_k3(p.th, a, st) : fi_conv_wgrad_quad_f32_k1(p.th, a, st);
+    else
+      r = d->ksize == 3 ? fi_conv_wgrad_quad_bf16_k3(p.th, a, st) : fi_conv_wgrad_quad_bf16_k1(p.th, a, st);
+  } else if (d->dtype == FI_F32) {
     r = d->ksize == 3 ? fi_conv_wgrad_f32_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_f32_k1(p.th, p.nfo, p.nfi, a, st);
-  else
-    r = d->ksize == 3 ? fi_conv_wgrad_bf16_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_bf16_k1(p.th, p.nfo, p.nfi, a, st);
+  } else {
+    r = d->ksize == 3 ? fi_conv_wgrad_bf16_k3(p.th, p.nfo, p.nfi, a, st)
+                      : fi_conv_wgrad_bf16_k1(p.th, p.nfo, p.nfi, a, st);
+  }
   if (r || !workspace) return r;
   const size_t n_dw = (size_t)cout * d->ksize * d->ksize * cin;
   const size_t n = n_dw + (dbias ? cout : 0);
-  int grid = (int)((n + 255) / 256);
-  if (grid > 2048) grid = 2048;
+  int grid = (int)((n + 31) / 32);
+  if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, p.part_stride, p.sb,
                      dw, n_dw, dbias, cout);
   FI_CHECK_LAUNCH();

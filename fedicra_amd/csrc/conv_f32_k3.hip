@@ -19,3 +19,10 @@ int fi_conv_wgrad_f32_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream
   WG_TH(4) WG_TH(8) WG_TH(16)
   return FI_ERR_UNSUPPORTED;
 }
+
+#define QUAD_CASE(TH_) if (th == TH_) return launch_conv_wgrad_quad<float, 3, TH_>(a, st);
+
+int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st) {
+  QUAD_CASE(4) QUAD_CASE(8)
+  return FI_ERR_UNSUPPORTED;
+}

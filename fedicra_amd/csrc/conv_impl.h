@@ -493,18 +493,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // second stage of the deterministic wgrad: dw[i] += sum_s part[s][i]  (i < n_dw), dbias likewise
+// 256 threads = 32 consecutive elements x 8 slice groups: group g sums slices g, g+8, ... (independent
+// loads in flight), the 8 group sums are then added in a fixed order through LDS -> deterministic.
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, size_t stride, int slices,
                                                            float* __restrict__ dw, size_t n_dw,
                                                            float* __restrict__ dbias, int cout) {
+  __shared__ float sm[8][32];
   const size_t n = n_dw + (dbias ? (size_t)cout : 0);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(size_t)k * stride + i];
-    if (i < n_dw)
-      dw[i] += s;
-    else
-      dbias[i - n_dw] += s;
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
+    const size_t i = base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int k = g;
+      for (; k + 24 < slices; k += 32) {
+        s0 += part[(size_t)k * stride + i];
+        s1 += part[(size_t)(k + 8) * stride + i];
+        s2 += part[(size_t)(k + 16) * stride + i];
+        s3 += part[(size_t)(k + 24) * stride + i];
+      }
+      for (; k < slices; k += 8) s0 += part[(size_t)k * stride + i];
+    }
+    __syncthreads();
+    sm[g][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n) {
+      float s = sm[0][e];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) s += sm[q][e];
+      if (i < n_dw)
+        dw[i] += s;
+      else
+        dbias[i - n_dw] += s;
+    }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad for the channel-rich layers (Cin, Cout >= 32): a workgroup owns a 32 x 32 channel tile and
+// each of its 4 waves one 16 x 16 quadrant of it (all k*k taps, all pixels of the tile).  Compared
+// with the pixel-split kernel above this doubles the MFMAs per staged tile, needs no cross-wave LDS
+// reduction, and writes 4x fewer partial slices per channel for the same number of workgroups.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KS, int TH>
+__global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
+  constexpr int BC = 32, XP = BC + VG, VPX = BC / VG;
+  constexpr int NKS = TH * 16 / KSTEP;
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);           // [XH*XW][XP]
+  T* ds = xs + XH * XW * XP;                    // [TH*16][XP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const int qo = wave >> 1, qi = wave & 1;
+  const int cin = a.c0 + a.c1, cout = a.cout;
+  int bid = blockIdx.x;
+  const int cit = bid % a.nci;
+  bid /= a.nci;
+  const int cot = bid % a.nco;
+  const int sb = bid / a.nco;
+  const int H = a.H, W = a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0);
+  const T* x1 = reinterpret_cast<const T*>(a.x1);
+  const T* dyg = reinterpret_cast<const T*>(a.dy);
+  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
+  const bool dvec_ok = (cout % VG == 0);
+  const bool want_bias = a.dbias != nullptr && cit == 0 && qi == 0;
+
+  f32x4 acc[KK];
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const frag_t onesv = WgFrag<T>::ones();
+
+  const int ntiles = a.N * a.tilesX * a.tilesY;
+  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
+    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
+    __syncthreads();
+    for (int i = tid; i < XH * XW * VPX; i += 256) {
+      const int v = i % VPX, pix = i / VPX;
+      const int py = pix / XW, px = pix % XW;
+      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+      vec_t val;
+      memset(&val, 0, sizeof(val));
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BC + v * VG, vec_ok);
+      *reinterpret_cast<vec_t*>(&xs[pix * XP + v * VG]) = val;
+    }
+    for (int i = tid; i < TH * 16 * VPX; i += 256) {
+      const int v = i % VPX, pix = i / VPX;
+      const int py = pix / 16, px = pix % 16;
+      const int gy = ty * TH + py, gx = tx * 16 + px;
+      vec_t val;
+      memset(&val, 0, sizeof(val));
+      if (gy < H && gx < W)
+        val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BC + v * VG, dvec_ok);
+      *reinterpret_cast<vec_t*>(&ds[pix * XP + v * VG]) = val;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < NKS; ++ks) {
+      const frag_t av = WgFrag<T>::load(ds, 16, XP, ks, 0, 0, qo * 16, kg, li);
+      if (want_bias) accb = mfma16(av, onesv, accb);
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const frag_t bv = WgFrag<T>::load(xs, XW, XP, ks, t / KS, t % KS, qi * 16, kg, li);
+        acc[t] = mfma16(av, bv, acc[t]);
+      }
+    }
+  }
+
+  // ---- flush: D[row = co = kg*4+r][col = ci = li] of this wave's quadrant
+  const size_t n_dw = (size_t)cout * KK * cin;
+  float* slice = a.part ? a.part + (size_t)sb * a.part_stride : nullptr;
+  const int gci = cit * BC + qi * 16 + li;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gco = cot * BC + qo * 16 + kg * 4 + r;
+      if (gco < cout && gci < cin) {
+        const size_t o = ((size_t)gco * KK + t) * cin + gci;
+        if (slice)
+          slice[o] = acc[t][r];
+        else
+          atomicAdd(&a.dw[o], acc[t][r]);
+      }
+    }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gco = cot * BC + qo * 16 + kg * 4 + r;
+      if (gco < cout) {
+        if (slice)
+          slice[n_dw + gco] = accb[r];
+        else
+          atomicAdd(&a.dbias[gco], accb[r]);
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TH>
+static int launch_conv_wgrad_quad(const WgradArgs& a, hipStream_t st) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO;
+  constexpr int XP = 32 + DT<T>::VG;
+  const size_t lds = (size_t)(XH * XW * XP + TH * 16 * XP) * sizeof(T);
+  const long blocks = (long)a.spatialBlocks * a.nco * a.nci;
+  hipLaunchKernelGGL((conv_wgrad_quad_kernel<T, KS, TH>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
 }
 
 template <typename T, int KS, int TH, int NFO, int NFI>

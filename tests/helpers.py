@@ -25,3 +25,26 @@ def loader(n_batches, B, S, cid, in_chns=1, ncls=2, device="cpu"):
         img, weak, _ = phantom_batch(B, S, in_chns, ncls, cid=cid, index=i, labeled_frac=0.1)
         out.append({"image": torch.from_numpy(img).to(device), "label": torch.from_numpy(weak).to(device)})
     return out
+
+
+def clean_seed(make_ref, x, seeds=range(3, 40), margin=3e-6):
+    """First seed for which no BatchNorm output of the (train-mode) oracle lies within `margin` of 0.
+
+    LeakyReLU'(v) jumps between 0.01 and 1 at v == 0: a pre-activation at round-off distance from zero gets a
+    different derivative on two correct fp32 implementations, which changes every upstream gradient by ~1e-3
+    relative.  Gradient-parity tests therefore pick a batch/mask draw without such an element (the reference has
+    the same sensitivity against itself -- DESIGN.md "parity bar")."""
+    for s in seeds:
+        ref = make_ref()
+        ref.train()
+        mins = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: mins.append(o.detach().abs().min().item()))
+                 for m in ref.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        torch.manual_seed(s)
+        with torch.no_grad():
+            ref(x)
+        for h in hooks:
+            h.remove()
+        if min(mins) > margin:
+            return s
+    raise RuntimeError("no clean seed found")

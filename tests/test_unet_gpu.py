@@ -203,12 +203,18 @@ def test_lc_backward_matches_oracle_grads(phase):
             acc = acc + torch.nn.functional.mse_loss(out[6][-1], ho.detach())
         return ce + 1.0 * (-acc / (K - 1))
 
-    ref = RefUNetLC(1, 2, 1, K, K, cid)
-    seeded_state(ref, 2022, extra=pcs_named_tensors(ref))
+    def mkref():
+        r = RefUNetLC(1, 2, 1, K, K, cid)
+        seeded_state(r, 2022, extra=pcs_named_tensors(r))
+        return r
+
+    from helpers import clean_seed
+    seed = clean_seed(mkref, b["image"].unsqueeze(1))
+    ref = mkref()
     ref.train()
     for n, p in ref.named_parameters():
         p.requires_grad = (n in head) == (phase == "head")
-    torch.manual_seed(3)
+    torch.manual_seed(seed)
     lr_ = fed_loss(ref, b["image"].unsqueeze(1), b["label"], lambda lg, y: pce_loss(lg, y, 2))
     lr_.backward()
     m = _mk(UNet_LC, 1, 2, 1, K, K, cid, lc=True).train()
@@ -216,7 +222,7 @@ def test_lc_backward_matches_oracle_grads(phase):
         p.requires_grad = (n in head) == (phase == "head")
     ops.set_dropout_mask_provider(_mask_provider())
     try:
-        torch.manual_seed(3)
+        torch.manual_seed(seed)
         ld = fed_loss(m, b["image"].unsqueeze(1).to(DEV), b["label"].to(DEV),
                       lambda lg, y: ops.ce_loss(lg.permute(0, 2, 3, 1), y, 2))
         ld.backward()
@@ -239,9 +245,8 @@ def test_lc_backward_matches_oracle_grads(phase):
             worst, worst_n = e, n
     errs = np.array(errs)
     print(f"[{phase}] parameter-gradient rel err: median {np.median(errs):.3e}, worst {worst:.3e} at {worst_n}")
-    # A pre-activation within round-off of 0 flips LeakyReLU's derivative (0.01 <-> 1) for that one element on
-    # either side; a handful of tensors may therefore carry a visible but bounded difference.
-    assert np.median(errs) < 2e-5 and (errs > 1e-3).sum() <= 4 and worst < 5e-2, (worst, worst_n)
+    # clean_seed() excluded draws with a pre-activation at round-off distance from 0 (LeakyReLU' jumps there)
+    assert np.median(errs) < 2e-5 and worst < 1e-3, (worst, worst_n, seed)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -297,17 +302,24 @@ def test_single_adamw_step_matches_oracle_elementwise():
     from oracle.unet_ref import RefUNet, seeded_state
     from helpers import loader
     batches = loader(1, 4, 64, cid=0)
-    ref = RefUNet(1, 2)
-    seeded_state(ref, 2022)
+
+    def mkref():
+        r = RefUNet(1, 2)
+        seeded_state(r, 2022)
+        return r
+
+    from helpers import clean_seed
+    seed = clean_seed(mkref, batches[0]["image"].unsqueeze(1))
+    ref = mkref()
     st = fed_ref.TrainState(0.01)
-    torch.manual_seed(5)
+    torch.manual_seed(seed)
     fed_ref.local_train(ref, st, batches, iters=1, num_classes=2, base_lr=0.01, max_iterations=30000)
     args = _args(iters=1)
     net = _mk(UNet, 1, 2)
     client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
     ops.set_dropout_mask_provider(_mask_provider())
     try:
-        torch.manual_seed(5)
+        torch.manual_seed(seed)
         client._train({"iter_global": 1, "iters": 1, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
     finally:
         ops.set_dropout_mask_provider(None)
