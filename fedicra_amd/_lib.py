@@ -18,7 +18,8 @@ STATS_SLOTS = 32               # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_pack_weights", "fi_bn_finalize", "fi_bn_act_fwd",
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_pack_weights",
+    "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
@@ -196,6 +197,18 @@ def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize, deterministic=True):
 def pack_weights(src, dst, cout, kk, cin, mode):
     _chk(lib().fi_pack_weights(ptr(_dev(src)), ptr(dst), cout, kk, cin, mode, dt(dst.dtype), stream()),
          "fi_pack_weights")
+
+
+def pack_weights_multi(table, ntensors, dtype):
+    _chk(lib().fi_pack_weights_multi(ptr(_dev(table)), int(ntensors), dt(dtype), stream()), "fi_pack_weights_multi")
+
+
+def bn_fused_fwd(y, z, stats, gamma, beta, rmean, rvar, nbt, momentum, eps, training, coef, slope, drop=None):
+    d = _bnact(_dev(y), slope, drop)
+    with _timed("bn_act_fwd", (str(y.dtype)[6:],) + tuple(y.shape), 0, 2 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_fused_fwd(C.byref(d), ptr(y), ptr(z), ptr(stats), ptr(gamma), ptr(beta), ptr(rmean),
+                                   ptr(rvar), ptr(nbt), C.c_float(momentum), C.c_float(eps), int(training),
+                                   ptr(coef), stream()), "fi_bn_fused_fwd")
 
 
 def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training, scale, shift, mean, invstd):

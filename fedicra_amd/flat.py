@@ -70,6 +70,8 @@ class FlatStoreMixin:
                 p.grad = None
                 p._fi_gview = _as_view(grads, offs[n], p)
                 p._fi_off = offs[n]
+                if hasattr(p, "_fi_packs"):          # operand packs belong to the storage we just left
+                    del p._fi_packs
             mods = dict(self.named_modules())
             for n, b in fbufs:
                 v = _as_view(flat, offs[n], b)
@@ -88,6 +90,8 @@ class FlatStoreMixin:
         self._fi_param_names = [n for n, _ in params]
         self.__dict__["_fi_first"] = params[0][1]      # not via setattr: must not register as a parameter
         self._fi_flat_ready = True
+        self._fi_pack_key = None
+        self._fi_pack_sig = None
 
     def _fi_check_flat(self):
         """deepcopy / foreign .data assignment break the views; detect cheaply and repair."""
@@ -112,6 +116,47 @@ class FlatStoreMixin:
         new._fi_flat_ready = False
         new._fi_reflatten()
         return new
+
+    # -- conv operand packs ---------------------------------------------------------------------
+    def _fi_pack_signature(self, dtype):
+        from . import ops
+        return (self._fi_state.data_ptr(), self._fi_state._version, ops.weights_epoch(), dtype)
+
+    def _fi_packs_current(self, dtype):
+        return getattr(self, "_fi_pack_sig", None) == self._fi_pack_signature(dtype)
+
+    def _fi_refresh_packs(self, dtype):
+        """(Re)build the forward (cast) and dgrad (flipped, transposed) operands of EVERY conv weight with one
+        multi-tensor launch, iff the weights changed since the last refresh.  Called by the root forward."""
+        self._fi_check_flat()
+        if self._fi_packs_current(dtype):
+            return
+        import weakref
+        from . import _lib as L
+        key = (self._fi_state.data_ptr(), dtype)
+        if getattr(self, "_fi_pack_key", None) != key:
+            convs = [p for p in self.parameters() if p.dim() == 4]
+            total = sum(p.numel() for p in convs)
+            dev = self._fi_state.device
+            need_fwd = dtype != torch.float32          # fp32 forward consumes the master weights directly
+            buf0 = torch.empty(total if need_fwd else 0, dtype=dtype, device=dev)
+            buf1 = torch.empty(total, dtype=dtype, device=dev)
+            rows, off = [], 0
+            ref = weakref.ref(self)
+            for p in convs:
+                n = p.numel()
+                co, ci, kh, kw = p.shape
+                v0 = buf0[off:off + n] if need_fwd else None
+                v1 = buf1[off:off + n]
+                rows.append([p.data_ptr(), v0.data_ptr() if need_fwd else 0, v1.data_ptr(), co, kh * kw, ci])
+                p._fi_packs = (ref, v0, v1)
+                off += n
+            self._fi_pack_bufs = (buf0, buf1)
+            self._fi_pack_table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._fi_pack_n = len(rows)
+            self._fi_pack_key = key
+        L.pack_weights_multi(self._fi_pack_table, self._fi_pack_n, dtype)
+        self._fi_pack_sig = self._fi_pack_signature(dtype)
 
     # -- accessors ------------------------------------------------------------------------------
     @property

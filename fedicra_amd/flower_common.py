@@ -192,12 +192,14 @@ class MyModel(nn.Module):
             loss = None
             for sampled_batch in self.trainloader:            # :566-602
                 x, y = self._batch(sampled_batch)
+                ops.begin_iteration(x.device)
                 temp.zero_grad()
                 out = temp(x)[0]
                 loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
                 loss.backward()
                 # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel)
                 L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta)
+                ops.bump_weights_epoch()                  # temp's weights were rewritten through raw pointers
             losses.append(float(loss.item()))
             count += 1
             print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,

@@ -87,7 +87,7 @@ class MyClient(BaseClient):
         """zero-grad, forward, loss, backward, optimizer step, LR update -- all device work."""
         args = self.args
         opt = self.optimizer
-        ops.begin_iteration()
+        ops.begin_iteration(x.device)
         opt.zero_grad()
         out = self.model(x)
         logits = out[0]
@@ -144,8 +144,10 @@ class MyClient(BaseClient):
                         self._iteration(x, y, rec)
                     rec.graph = g
                     g.replay()
+                    ops.bump_weights_epoch()                 # the replayed AdamW moved the weights
                 else:
                     rec.graph.replay()
+                    ops.bump_weights_epoch()
             else:
                 rec = _GraphStep()
                 self._iteration(x, y, rec)

@@ -325,7 +325,7 @@ class _UNetBase(FlatStoreMixin, _FiModule):
         self._fi_finish_init()
 
     def forward(self, x):
-        self._fi_check_flat()
+        self._fi_refresh_packs(self.compute_dtype())     # all conv operands in one launch, only if weights changed
         f = self.encoder._run(self._in(x))
         o = self.decoder._run(f)
         return [self._out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:]]
@@ -357,7 +357,7 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         self._fi_finish_init()
 
     def forward(self, x, emb_idx=None):
-        self._fi_check_flat()
+        self._fi_refresh_packs(self.compute_dtype())     # all conv operands in one launch, only if weights changed
         f, h = self.encoder._run(self._in(x), emb_idx)
         o = self.decoder._run(f)
         hm = [None if t is None else self._out(t) for t in h]

@@ -50,12 +50,62 @@ _layer_uid = {}                # id(bn module) -> small stable integer (order of
 _call_idx = {}                 # uid -> how many times this layer drew a mask in the current iteration
 
 
-def begin_iteration():
+class _ZeroArena:
+    """fp64 scratch for the BatchNorm statistic / gradient-sum accumulators of one iteration.  The kernels add
+    into zero-initialised buffers; handing those out of ONE arena that begin_iteration() clears with a single
+    memset replaces ~37 `torch.zeros` fill launches per training step.  take() never returns dirty memory: the
+    offset only rewinds together with the memset, and requests beyond the arena fall back to torch.zeros."""
+
+    SIZE = 1 << 22          # doubles (32 MB)
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.hwm = 0
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(self.SIZE, dtype=torch.float64, device=device)
+            self.off = self.hwm = 0
+            return
+        n = max(self.hwm, self.off)
+        self.hwm = n
+        if n:
+            self.buf[:n].zero_()
+        self.off = 0
+
+    def take(self, n, device):
+        n = (n + 15) // 16 * 16
+        if self.buf is not None and self.buf.device == device and self.off + n <= self.SIZE:
+            v = self.buf[self.off:self.off + n]
+            self.off += n
+            return v
+        return torch.zeros(n, dtype=torch.float64, device=device)
+
+
+_arena = _ZeroArena()
+_raw_epoch = 0                 # bumped whenever a kernel writes model weights through raw pointers
+
+
+def bump_weights_epoch():
+    """Tell the pack cache that weights changed behind torch's back (fused AdamW, ALA kernel, graph replay)."""
+    global _raw_epoch
+    _raw_epoch += 1
+
+
+def weights_epoch():
+    return _raw_epoch
+
+
+def begin_iteration(device=None):
     """Call at the start of every training iteration: dropout seeds are then a pure function of
     (manual_seed, layer, n-th call of that layer within the iteration, device iteration counter), so an
     eager run and a replayed hipGraph draw identical masks, while repeated forwards inside one iteration
-    (FedICRA's no-grad forwards with other clients' embeddings) still get independent masks."""
+    (FedICRA's no-grad forwards with other clients' embeddings) still get independent masks.  Also rewinds
+    and clears the accumulator arena (one memset)."""
     _call_idx.clear()
+    if device is not None:
+        _arena.begin(torch.device(device))
 
 
 def _drop_spec(p, kind, N, H, W, Cc, device, owner=None):
@@ -104,10 +154,18 @@ def _grad_target(p, like=None):
     return sink, False, None
 
 
-def _packed(wk, dtype, mode, cout, kk, cin):
-    """fp32 KRSC weight -> operand in `dtype` (mode 0) or flipped/transposed dgrad operand (mode 1)."""
+def _packed(wk, dtype, mode, cout, kk, cin, param=None):
+    """fp32 KRSC weight -> operand in `dtype` (mode 0) or flipped/transposed dgrad operand (mode 1).
+    Parameters owned by a FlatStoreMixin model are served from the model's multi-tensor pack buffers when those
+    are current (the root module's forward refreshes all of them in ONE launch); otherwise a per-tensor repack."""
     if mode == 0 and dtype == torch.float32:
         return wk
+    if param is not None:
+        packs = getattr(param, "_fi_packs", None)
+        if packs is not None:
+            owner = packs[0]()
+            if owner is not None and owner._fi_packs_current(dtype):
+                return packs[1 + mode]
     out = torch.empty(cout * kk * cin, dtype=dtype, device=wk.device)
     L.pack_weights(wk, out, cout, kk, cin, mode)
     return out
@@ -120,7 +178,7 @@ def _conv_backward(ctx, dy, x0, x1, wk, mod):
     dx0 = dx1 = gw = gb = None
     need_x0, need_x1 = ctx.need_x0, ctx.need_x1
     if need_x0 or need_x1:
-        wt = _packed(wk, dy.dtype, 1, cout, kk, cin)
+        wt = _packed(wk, dy.dtype, 1, cout, kk, cin, param=mod.weight)
         N, H, W, _ = dy.shape
         # dgrad = conv of dy with the flipped/transposed filter; two destinations for a concat input
         d0 = torch.empty((N, H, W, x0.shape[3]), dtype=dy.dtype, device=dy.device)
@@ -154,7 +212,7 @@ class _Conv(Function):
         wk = _krsc(weight)
         cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
         N, H, W, _ = x0.shape
-        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin)
+        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=weight)
         y = torch.empty((N, H, W, cout), dtype=torch.float32 if y_f32 else x0.dtype, device=x0.device)
         L.conv2d_fwd(x0, x1, wp, bias, y, None, None, ksize=ksize, y_f32=y_f32)
         ctx.save_for_backward(x0, x1, wk)
@@ -187,16 +245,16 @@ class _ConvBNAct(Function):
         N, H, W, _ = x0.shape
         dev = x0.device
         training = bn.training
-        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin)
+        wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=weight)
         y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev)
-        stats = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=dev) if training else None
+        stats = _arena.take(L.STATS_SLOTS * cout * 2, dev) if training else None
         L.conv2d_fwd(x0, x1, wp, bias, y, None, stats, ksize=ksize)
         coef = torch.empty(4, cout, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
-        L.bn_finalize(stats, float(N * H * W), gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                      bn.momentum, bn.eps, training, coef[0], coef[1], coef[2], coef[3])
         drop = _drop_spec(drop_p, drop_kind, N, H, W, cout, dev, owner=bn) if training else None
         z = torch.empty_like(y)
-        L.bn_act_fwd(y, coef[0], coef[1], z, slope, drop)
+        # BN finalize (batch statistics -> scale/shift, running-stat update) + apply + activation + dropout: 1 launch
+        L.bn_fused_fwd(y, z, stats, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                       bn.eps, training, coef, slope, drop)
         ctx.save_for_backward(x0, x1, wk, y, coef)
         ctx.mod, ctx.bn, ctx.ksize, ctx.slope, ctx.drop, ctx.training = mod, bn, ksize, slope, drop, training
         ctx.need_x0 = ctx.needs_input_grad[0]
@@ -211,7 +269,7 @@ class _ConvBNAct(Function):
         x0, x1, wk, y, coef = ctx.saved_tensors
         dz = dz.contiguous()
         cout = y.shape[3]
-        sums = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=y.device)
+        sums = _arena.take(L.STATS_SLOTS * cout * 2, y.device)
         L.bn_act_bwd_reduce(dz, y, coef[0], coef[1], coef[2], coef[3], sums, ctx.slope, ctx.drop)
         gg = gbeta = None
         dgam = dbet = None

@@ -86,6 +86,8 @@ class FusedAdamW:
         for s, e in ranges:
             L.adamw_step(P[s:e], G[s:e], self.m[s:e], self.v[s:e], self.hyper[gi], self.betas[0], self.betas[1],
                          self.eps, None if self.shadow is None else self.shadow[s:e])
+        from . import ops
+        ops.bump_weights_epoch()            # raw-pointer write: invalidate the conv operand packs
 
     def advance_lr(self):
         """lr <- base_lr * (1 - iter/max_iterations)^0.9 with iter incremented first (flower_pCE_2D.py:150-157)."""

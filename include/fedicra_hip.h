@@ -87,6 +87,10 @@ int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void*
  *           with the flipped, transposed filter -- run through fi_conv2d_fwd with Cin<->Cout)   */
 int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype, void* stream);
 
+/* The same repack for MANY weights in one launch.  table (device, int64[ntensors][6]) rows:
+ * { src fp32 master ptr, dst forward operand ptr or 0, dst dgrad operand ptr or 0, cout, k*k, cin }. */
+int fi_pack_weights_multi(const long long* table, int ntensors, int dtype, void* stream);
+
 /* ---------------------------------------------------------------- BatchNorm + activation --
  * nn.BatchNorm2d (eps 1e-5, momentum 0.1) -> LeakyReLU(0.01)/ReLU -> Dropout, unet.py:21-24, 263-265. */
 
@@ -111,6 +115,12 @@ typedef struct FiBnAct {
   const int32_t* seed_offset; /* RNG forms, may be NULL: device int32 added to the seed stream (e.g. the
                                  training-iteration counter) so a replayed hipGraph draws fresh masks */
 } FiBnAct;
+
+/* fi_bn_finalize + fi_bn_act_fwd in ONE launch: every workgroup folds the statistic slots itself; coef
+ * (fp32 [4][C] = scale, shift, mean, invstd) is published for the backward kernels. */
+int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const double* stats, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, int training, float* coef, void* stream);
 
 /* z = dropout(act(y*scale[c] + shift[c])) */
 int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z, void* stream);
