@@ -15,6 +15,8 @@
 //   The two-source loader folds torch.cat([skip, up], 1) into the gather; the two-destination
 //   epilogue is its adjoint for dgrad.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -79,6 +81,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int BN = NF * 16;
   constexpr int MF = TH / 4;
   constexpr int VPP = CK / VG;                                  // 16-byte vectors per pixel
+  constexpr int NXV = XH * XW * VPP, NWV = BN * KK * VPP;       // vectors per staged chunk
+  constexpr int NX = (NXV + 255) / 256, NW = (NWV + 255) / 256; // ... per thread
   typedef typename DT<T>::vec_t vec_t;
   typedef typename DT<T>::frag_t frag_t;
 
@@ -103,55 +107,88 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
   const bool wvec_ok = (cin % VG == 0);
 
+  // acc[m][f][r] = out(channel ct*BN + f*16 + kg*4 + r ; pixel row wave*MF+m, col li): the weights are the
+  // MFMA "A" operand and the pixels the "B" operand, so a lane ends up with 4 CONSECUTIVE channels of one
+  // pixel -> one 8/16-byte NHWC store per fragment instead of four 2/4-byte ones.
   f32x4 acc[MF][NF];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int cb = 0; cb < cin; cb += CK) {
-    __syncthreads();  // everyone finished reading the previous chunk
-    // ---- stage the input halo tile
-    for (int i = tid; i < XH * XW * VPP; i += 256) {
-      const int v = i % VPP, pix = i / VPP;
-      const int py = pix / XW, px = pix % XW;
-      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+  // ---- register-staged chunk: all global loads of a chunk are issued back to back (latency overlaps), and
+  //      the NEXT chunk's loads are in flight while the MFMAs of the current one run.
+  vec_t xr[NX], wr[NW];
+  auto fetch = [&](int cb) {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
       vec_t val;
       memset(&val, 0, sizeof(val));
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cb + v * VG, vec_ok);
-      *reinterpret_cast<vec_t*>(&xs[pix * CKP + v * VG]) = val;
+      if (i < NXV) {
+        const int v = i % VPP, pix = i / VPP;
+        const int py = pix / XW, px = pix % XW;
+        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cb + v * VG, vec_ok);
+      }
+      xr[it] = val;
     }
-    // ---- stage the weight slab  ws[co][t*CK + ci]
-    for (int i = tid; i < BN * KK * VPP; i += 256) {
-      const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
-      const int gco = ct * BN + co, ci = cb + v * VG;
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int i = tid + it * 256;
       union {
         vec_t vv;
         T e[VG];
       } u;
       memset(&u, 0, sizeof(u));
-      if (gco < cout) {
-        const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
-        if (wvec_ok) {
-          if (ci < cin) u.vv = *reinterpret_cast<const vec_t*>(src);
-        } else {
+      if (i < NWV) {
+        const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
+        const int gco = ct * BN + co, ci = cb + v * VG;
+        if (gco < cout) {
+          const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
+          if (wvec_ok) {
+            if (ci < cin) u.vv = *reinterpret_cast<const vec_t*>(src);
+          } else {
 #pragma unroll
-          for (int j = 0; j < VG; ++j)
-            if (ci + j < cin) u.e[j] = src[j];
+            for (int j = 0; j < VG; ++j)
+              if (ci + j < cin) u.e[j] = src[j];
+          }
         }
       }
-      *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = u.vv;
+      wr[it] = u.vv;
     }
-    if (KCP > KC) {  // zero the K padding so that clamped A reads multiply by 0
-      constexpr int PV = (KCP - KC) / VG;
-      for (int i = tid; i < BN * PV; i += 256) {
-        vec_t z;
-        memset(&z, 0, sizeof(z));
-        *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
+      if (i < NXV) *reinterpret_cast<vec_t*>(&xs[(i / VPP) * CKP + (i % VPP) * VG]) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int i = tid + it * 256;
+      if (i < NWV) {
+        const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
+        *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = wr[it];
       }
     }
+  };
+
+  if (KCP > KC) {  // zero the K padding once: clamped A reads then multiply by 0 (never overwritten by commit)
+    constexpr int PV = (KCP - KC) / VG;
+    for (int i = tid; i < BN * PV; i += 256) {
+      vec_t z;
+      memset(&z, 0, sizeof(z));
+      *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
+    }
+  }
+  fetch(0);
+  for (int cb = 0; cb < cin; cb += CK) {
+    __syncthreads();  // everyone finished reading the previous chunk
+    commit();
     __syncthreads();
+    if (cb + CK < cin) fetch(cb + CK);
 
     // ---- MFMA over this chunk
     if constexpr (CK >= KSTEP) {
@@ -170,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             const frag_t av =
                 *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + ks * KSTEP + kg * KV]);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(av, b[f], acc[m][f]);
+            for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(b[f], av, acc[m][f]);
           }
         }
       }
@@ -192,48 +229,101 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           const int row = wave * MF + m;
           const frag_t av = *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + cil]);
 #pragma unroll
-          for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(av, b[f], acc[m][f]);
+          for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(b[f], av, acc[m][f]);
         }
       }
     }
   }
 
-  // ---- epilogue.  acc[m][f][r] = output(pixel row wave*MF+m, col kg*4+r ; channel f*16+li)
-  float ssum[NF], ssq[NF];
+  // ---- epilogue
+  float ssum[NF][4], ssq[NF][4];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) ssum[f] = ssq[f] = 0.f;
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ssum[f][r] = ssq[f][r] = 0.f;
+  const int gx = tx * 16 + li;
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    const int co = ct * BN + f * 16 + li;
-    const bool cok = co < cout;
-    const float bv = (cok && a.bias) ? a.bias[co] : 0.f;
-    const bool second = co >= a.co0;
+    const int cg = ct * BN + f * 16 + kg * 4;  // first of this lane's 4 channels
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (a.bias && cg + r < cout) ? a.bias[cg + r] : 0.f;
+    const bool second = cg >= a.co0;
     const int cdst = second ? a.co1 : a.co0;
-    const int cofs = second ? co - a.co0 : co;
+    const int cofs = second ? cg - a.co0 : cg;
     void* ybase = second ? a.y1 : a.y0;
     const int accum = second ? a.acc1 : a.acc0;
+    // whole 4-channel group inside one destination and 4-aligned -> one vector store
+    const bool vec4 = (cg + 3 < cout) && (cdst % 4 == 0) && (cofs % 4 == 0) && (second || cg + 3 < a.co0);
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const int gy = ty * TH + wave * MF + m;
+      if (gy < H && gx < W && cg < cout) {
+        const size_t pixo = ((size_t)n * H + gy) * W + gx;
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gx = tx * 16 + kg * 4 + r;
-        if (cok && gy < H && gx < W) {
-          const size_t o = (((size_t)n * H + gy) * W + gx) * cdst + cofs;
-          float v = acc[m][f][r] + bv;
+        for (int r = 0; r < 4; ++r) v[r] = acc[m][f][r] + bv[r];
+        if (vec4) {
+          const size_t o = pixo * cdst + cofs;
           if (a.y_f32) {
-            float* yp = reinterpret_cast<float*>(ybase) + o;
-            if (accum) v += *yp;
-            *yp = v;
+            float4* yp = reinterpret_cast<float4*>(reinterpret_cast<float*>(ybase) + o);
+            if (accum) {
+              const float4 old = *yp;
+              v[0] += old.x;
+              v[1] += old.y;
+              v[2] += old.z;
+              v[3] += old.w;
+            }
+            *yp = make_float4(v[0], v[1], v[2], v[3]);
           } else {
+            union {
+              T e[4];
+              typename std::conditional<sizeof(T) == 2, uint2, float4>::type q;
+            } u;
             T* yp = reinterpret_cast<T*>(ybase) + o;
-            if (accum) v += to_f32(*yp);
-            const T q = from_f32<T>(v);
-            *yp = q;
-            v = to_f32(q);
+            if (accum) {
+              u.q = *reinterpret_cast<decltype(u.q)*>(yp);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += to_f32(u.e[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              u.e[r] = from_f32<T>(v[r]);
+              v[r] = to_f32(u.e[r]);
+            }
+            *reinterpret_cast<decltype(u.q)*>(yp) = u.q;
           }
-          ssum[f] += v;
-          ssq[f] += v * v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ssum[f][r] += v[r];
+            ssq[f][r] += v[r] * v[r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = cg + r;
+            if (co < cout) {
+              const bool sec = co >= a.co0;
+              const int cd = sec ? a.co1 : a.co0;
+              void* yb = sec ? a.y1 : a.y0;
+              const size_t o = pixo * cd + (sec ? co - a.co0 : co);
+              float vv = v[r];
+              const int ac = sec ? a.acc1 : a.acc0;
+              if (a.y_f32) {
+                float* yp = reinterpret_cast<float*>(yb) + o;
+                if (ac) vv += *yp;
+                *yp = vv;
+              } else {
+                T* yp = reinterpret_cast<T*>(yb) + o;
+                if (ac) vv += to_f32(*yp);
+                const T q = from_f32<T>(vv);
+                *yp = q;
+                vv = to_f32(q);
+              }
+              ssum[f][r] += vv;
+              ssq[f][r] += vv * vv;
+            }
+          }
         }
       }
     }
@@ -242,17 +332,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     __syncthreads();  // LDS reuse: all MFMA reads are done
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      float s = ssum[f], q = ssq[f];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (kg == 0) {
-        red[(wave * BN + f * 16 + li) * 2 + 0] = s;
-        red[(wave * BN + f * 16 + li) * 2 + 1] = q;
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = ssum[f][r], q = ssq[f][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // over the 16 pixel lanes of this kg group
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        if (li == 0) {
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = q;
+        }
       }
-    }
     __syncthreads();
     if (tid < BN * 2) {
       const int c = tid >> 1, which = tid & 1;
@@ -262,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) tot += (double)red[(wv * BN + c) * 2 + which];
         // FI_STATS_SLOTS copies of the accumulator: thousands of workgroups adding to the same 2*C
-        // addresses serialise in L2; spreading them over 32 slots (summed by fi_bn_finalize) removes that.
+        // addresses serialise at the fabric; spreading them over 32 slots (summed by the BN kernel) removes that.
         const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
         atomicAdd(&a.stats[((size_t)slot * cout + co) * 2 + which], tot);
       }
@@ -394,31 +487,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (int o = 0; o < NFO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
   const frag_t onesv = WgFrag<T>::ones();
 
-  const int ntiles = a.N * a.tilesX * a.tilesY;
-  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
+  // register-staged tiles: all loads of a tile are issued back to back, and the NEXT tile's loads are in
+  // flight while the MFMAs of the current one run (the staging loop used to expose one HBM latency per
+  // 256-vector round).
+  constexpr int NXV = XH * XW * VPX, NDV = TH * 16 * VPD;
+  constexpr int NX = (NXV + 255) / 256, ND = (NDV + 255) / 256;
+  vec_t xr[NX], dr[ND];
+  auto fetch = [&](int tile) {
     const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
-    __syncthreads();
-    for (int i = tid; i < XH * XW * VPX; i += 256) {
-      const int v = i % VPX, pix = i / VPX;
-      const int py = pix / XW, px = pix % XW;
-      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
       vec_t val;
       memset(&val, 0, sizeof(val));
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BCI + v * VG, vec_ok);
-      *reinterpret_cast<vec_t*>(&xs[pix * XP + v * VG]) = val;
+      if (i < NXV) {
+        const int v = i % VPX, pix = i / VPX;
+        const int py = pix / XW, px = pix % XW;
+        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BCI + v * VG, vec_ok);
+      }
+      xr[it] = val;
     }
-    for (int i = tid; i < TH * 16 * VPD; i += 256) {
-      const int v = i % VPD, pix = i / VPD;
-      const int py = pix / 16, px = pix % 16;
-      const int gy = ty * TH + py, gx = tx * 16 + px;
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = tid + it * 256;
       vec_t val;
       memset(&val, 0, sizeof(val));
-      if (gy < H && gx < W)
-        val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BCO + v * VG, dvec_ok);
-      *reinterpret_cast<vec_t*>(&ds[pix * DP + v * VG]) = val;
+      if (i < NDV) {
+        const int v = i % VPD, pix = i / VPD;
+        const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
+        if (gy < H && gx < W)
+          val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BCO + v * VG, dvec_ok);
+      }
+      dr[it] = val;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
+      if (i < NXV) *reinterpret_cast<vec_t*>(&xs[(i / VPX) * XP + (i % VPX) * VG]) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = tid + it * 256;
+      if (i < NDV) *reinterpret_cast<vec_t*>(&ds[(i / VPD) * DP + (i % VPD) * VG]) = dr[it];
+    }
+  };
+
+  const int ntiles = a.N * a.tilesX * a.tilesY;
+  if (sb < ntiles) fetch(sb);
+  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + a.spatialBlocks < ntiles) fetch(tile + a.spatialBlocks);
 
     for (int ks = wave; ks < NKS; ks += 4) {
       frag_t av[NFO];
@@ -571,31 +695,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const frag_t onesv = WgFrag<T>::ones();
 
-  const int ntiles = a.N * a.tilesX * a.tilesY;
-  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
+  constexpr int NXV = XH * XW * VPX, NDV = TH * 16 * VPX;
+  constexpr int NX = (NXV + 255) / 256, ND = (NDV + 255) / 256;
+  vec_t xr[NX], dr[ND];
+  auto fetch = [&](int tile) {   // register-staged, next tile prefetched during the MFMAs (see pixel-split kernel)
     const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
-    __syncthreads();
-    for (int i = tid; i < XH * XW * VPX; i += 256) {
-      const int v = i % VPX, pix = i / VPX;
-      const int py = pix / XW, px = pix % XW;
-      const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
       vec_t val;
       memset(&val, 0, sizeof(val));
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BC + v * VG, vec_ok);
-      *reinterpret_cast<vec_t*>(&xs[pix * XP + v * VG]) = val;
+      if (i < NXV) {
+        const int v = i % VPX, pix = i / VPX;
+        const int py = pix / XW, px = pix % XW;
+        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BC + v * VG, vec_ok);
+      }
+      xr[it] = val;
     }
-    for (int i = tid; i < TH * 16 * VPX; i += 256) {
-      const int v = i % VPX, pix = i / VPX;
-      const int py = pix / 16, px = pix % 16;
-      const int gy = ty * TH + py, gx = tx * 16 + px;
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = tid + it * 256;
       vec_t val;
       memset(&val, 0, sizeof(val));
-      if (gy < H && gx < W)
-        val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BC + v * VG, dvec_ok);
-      *reinterpret_cast<vec_t*>(&ds[pix * XP + v * VG]) = val;
+      if (i < NDV) {
+        const int v = i % VPX, pix = i / VPX;
+        const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
+        if (gy < H && gx < W)
+          val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BC + v * VG, dvec_ok);
+      }
+      dr[it] = val;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int i = tid + it * 256;
+      if (i < NXV) *reinterpret_cast<vec_t*>(&xs[(i / VPX) * XP + (i % VPX) * VG]) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = tid + it * 256;
+      if (i < NDV) *reinterpret_cast<vec_t*>(&ds[(i / VPX) * XP + (i % VPX) * VG]) = dr[it];
+    }
+  };
+
+  const int ntiles = a.N * a.tilesX * a.tilesY;
+  if (sb < ntiles) fetch(sb);
+  for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + a.spatialBlocks < ntiles) fetch(tile + a.spatialBlocks);
 #pragma unroll 2
     for (int ks = 0; ks < NKS; ++ks) {
       const frag_t av = WgFrag<T>::load(ds, 16, XP, ks, 0, 0, qo * 16, kg, li);
