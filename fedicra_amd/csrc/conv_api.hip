@@ -16,13 +16,29 @@ int fi_conv_wgrad_quad_bf16_k3(int th, const WgradArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
+#include <cstdlib>
+// tuning knobs (read once): FI_MIN_BLOCKS = workgroups a launch should reach before the tile height stops
+// shrinking; FI_WGRAD_BLOCKS = total workgroups of a wgrad launch (each spatial slice costs |dw| of workspace).
+static long env_long(const char* name, long dflt) {
+  const char* v = getenv(name);
+  return v ? atol(v) : dflt;
+}
+static long min_blocks() {
+  static long v = env_long("FI_MIN_BLOCKS", 512);
+  return v;
+}
+static long wgrad_blocks() {
+  static long v = env_long("FI_WGRAD_BLOCKS", 512);
+  return v;
+}
+
 static int pick_th(int N, int H, int W, long per_tile_mult) {
   const int cands[3] = {16, 8, 4};
   for (int i = 0; i < 3; ++i) {
     const int th = cands[i];
     if (th > 4 && th / 2 >= H) continue;  // tile would be mostly empty
     const long blocks = (long)N * fi_cdiv(H, th) * fi_cdiv(W, 16) * per_tile_mult;
-    if (blocks >= 512 || th == 4) return th;
+    if (blocks >= min_blocks() || th == 4) return th;
   }
   return 4;
 }
@@ -41,9 +57,18 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     ck = cin >= 16 ? 16 : (cin > 4 ? 8 : 4);
   else
     ck = cin >= 32 ? 32 : (cin > 8 ? 16 : 8);
-  const int nf = cout > 32 ? 4 : (cout > 16 ? 2 : 1);
-  const int nct = fi_cdiv(cout, nf * 16);
-  const int th = pick_th(d->N, d->H, d->W, nct);
+  // Output-channel slab per workgroup: as wide as possible (less re-staging of the input tile) as long as the
+  // launch still has FI_TARGET_BLOCKS workgroups.  The small feature maps are latency-bound with one workgroup
+  // per CU; narrower slabs put several workgroups on each CU, whose staging round trips then overlap.
+  static const long target_blocks = env_long("FI_TARGET_BLOCKS", 1024);
+  int nf = cout > 32 ? 4 : (cout > 16 ? 2 : 1);
+  int nct = fi_cdiv(cout, nf * 16);
+  int th = pick_th(d->N, d->H, d->W, nct);
+  while (nf > 1 && (long)d->N * fi_cdiv(d->H, th) * fi_cdiv(d->W, 16) * nct < target_blocks) {
+    nf /= 2;
+    nct = fi_cdiv(cout, nf * 16);
+    th = pick_th(d->N, d->H, d->W, nct);
+  }
   ConvArgs a;
   a.x0 = x0;
   a.x1 = x1 ? x1 : x0;
@@ -98,7 +123,7 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p) {
   p->tilesY = fi_cdiv(d->H, p->th);
   const long ntiles = (long)d->N * p->tilesX * p->tilesY;
   // ~2 workgroups per CU in total; every spatial workgroup costs one |dw| slice of workspace traffic
-  long sb = (256L * 2) / ((long)p->nco * p->nci);
+  long sb = wgrad_blocks() / ((long)p->nco * p->nci);
   if (sb < 1) sb = 1;
   if (sb > ntiles) sb = ntiles;
   p->sb = (int)sb;

@@ -116,66 +116,101 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- register-staged chunk: all global loads of a chunk are issued back to back (latency overlaps), and
-  //      the NEXT chunk's loads are in flight while the MFMAs of the current one run.
-  vec_t xr[NX], wr[NW];
-  auto fetch = [&](int cb) {
+  // ---- staging.  Loads are UNCONDITIONAL (out-of-image / out-of-range lanes read a clamped, valid address and
+  //      are zeroed when written to LDS): a load under a divergent branch forces the compiler to wait for it
+  //      at the merge point, which serialises one HBM round trip per vector.  Vectors are moved in groups of
+  //      SG so that SG loads per lane are in flight while only SG*4 VGPRs are held (occupancy stays high).
+  constexpr int SG = 4;
+  auto stage = [&](int cb) {
 #pragma unroll
-    for (int it = 0; it < NX; ++it) {
-      const int i = tid + it * 256;
-      vec_t val;
-      memset(&val, 0, sizeof(val));
-      if (i < NXV) {
-        const int v = i % VPP, pix = i / VPP;
-        const int py = pix / XW, px = pix % XW;
-        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cb + v * VG, vec_ok);
-      }
-      xr[it] = val;
-    }
+    for (int g0 = 0; g0 < NX; g0 += SG) {
+      vec_t r[SG];
+      bool ok[SG];
 #pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int i = tid + it * 256;
-      union {
-        vec_t vv;
-        T e[VG];
-      } u;
-      memset(&u, 0, sizeof(u));
-      if (i < NWV) {
-        const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
-        const int gco = ct * BN + co, ci = cb + v * VG;
-        if (gco < cout) {
-          const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
-          if (wvec_ok) {
-            if (ci < cin) u.vv = *reinterpret_cast<const vec_t*>(src);
+      for (int j = 0; j < SG; ++j) {
+        const int it = g0 + j;
+        if (it < NX) {
+          const int i = tid + it * 256;
+          const int ii = i < NXV ? i : 0;
+          const int v = ii % VPP, pix = ii / VPP;
+          const int py = pix / XW, px = pix % XW;
+          const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+          const int ci = cb + v * VG;
+          ok[j] = (i < NXV) && gy >= 0 && gy < H && gx >= 0 && gx < W && (vec_ok ? ci < cin : true);
+          const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+          const size_t gp = ((size_t)n * H + cy) * W + cx;
+          if (vec_ok) {
+            const int cc = ci < cin ? ci : 0;
+            const T* src = (cc < a.c0) ? x0 + gp * a.c0 + cc : x1 + gp * a.c1 + (cc - a.c0);
+            r[j] = *reinterpret_cast<const vec_t*>(src);
           } else {
-#pragma unroll
-            for (int j = 0; j < VG; ++j)
-              if (ci + j < cin) u.e[j] = src[j];
+            r[j] = load_cat<T>(x0, x1, a.c0, a.c1, gp, ci, false);   // narrow tensors (image, logits grad)
           }
         }
       }
-      wr[it] = u.vv;
-    }
-  };
-  auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < NX; ++it) {
-      const int i = tid + it * 256;
-      if (i < NXV) *reinterpret_cast<vec_t*>(&xs[(i / VPP) * CKP + (i % VPP) * VG]) = xr[it];
+      for (int j = 0; j < SG; ++j) {
+        const int it = g0 + j;
+        if (it < NX) {
+          const int i = tid + it * 256;
+          if (i < NXV) {
+            vec_t val = r[j];
+            if (!ok[j]) memset(&val, 0, sizeof(val));
+            *reinterpret_cast<vec_t*>(&xs[(i / VPP) * CKP + (i % VPP) * VG]) = val;
+          }
+        }
+      }
     }
 #pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int i = tid + it * 256;
-      if (i < NWV) {
-        const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
-        *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = wr[it];
+    for (int g0 = 0; g0 < NW; g0 += SG) {
+      vec_t r[SG];
+      bool ok[SG];
+#pragma unroll
+      for (int j = 0; j < SG; ++j) {
+        const int it = g0 + j;
+        if (it < NW) {
+          const int i = tid + it * 256;
+          const int ii = i < NWV ? i : 0;
+          const int v = ii % VPP, t = (ii / VPP) % KK, co = ii / (VPP * KK);
+          const int gco = ct * BN + co, ci = cb + v * VG;
+          if (wvec_ok) {
+            ok[j] = (i < NWV) && gco < cout && ci < cin;
+            const T* src = wg + ((size_t)(gco < cout ? gco : 0) * KK + t) * cin + (ci < cin ? ci : 0);
+            r[j] = *reinterpret_cast<const vec_t*>(src);
+          } else {
+            union {
+              vec_t vv;
+              T e[VG];
+            } u;
+            memset(&u, 0, sizeof(u));
+            ok[j] = (i < NWV) && gco < cout;
+            if (ok[j]) {
+              const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
+#pragma unroll
+              for (int q = 0; q < VG; ++q)
+                if (ci + q < cin) u.e[q] = src[q];
+            }
+            r[j] = u.vv;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SG; ++j) {
+        const int it = g0 + j;
+        if (it < NW) {
+          const int i = tid + it * 256;
+          if (i < NWV) {
+            const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
+            vec_t val = r[j];
+            if (!ok[j]) memset(&val, 0, sizeof(val));
+            *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = val;
+          }
+        }
       }
     }
   };
 
-  if (KCP > KC) {  // zero the K padding once: clamped A reads then multiply by 0 (never overwritten by commit)
+  if (KCP > KC) {  // zero the K padding once: clamped A reads then multiply by 0 (never overwritten by stage)
     constexpr int PV = (KCP - KC) / VG;
     for (int i = tid; i < BN * PV; i += 256) {
       vec_t z;
@@ -183,12 +218,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
     }
   }
-  fetch(0);
   for (int cb = 0; cb < cin; cb += CK) {
     __syncthreads();  // everyone finished reading the previous chunk
-    commit();
+    stage(cb);
     __syncthreads();
-    if (cb + CK < cin) fetch(cb + CK);
 
     // ---- MFMA over this chunk
     if constexpr (CK >= KSTEP) {
@@ -564,27 +597,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
-  // ---- combine the 4 waves through LDS, then one global atomic per dw element
-  __syncthreads();
-  for (int i = tid; i < KK * BCO * BCI + BCO; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // ---- combine the 4 waves through LDS: the waves take turns (plain ds_read/ds_write, fixed order ->
+  //      deterministic).  LDS float atomics cost ~220 cycles per wave-instruction here and made the kernel
+  //      LDS-bound (SQ_WAIT_INST_LDS 43 % of wave cycles); the turn-taking costs 4 barriers instead.
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+      for (int t = 0; t < KK; ++t)
 #pragma unroll
-    for (int o = 0; o < NFO; ++o)
+        for (int o = 0; o < NFO; ++o)
 #pragma unroll
-      for (int i = 0; i < NFI; ++i)
+          for (int i = 0; i < NFI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // D[row = co = kg*4+r][col = ci = li]
-          const int co = o * 16 + kg * 4 + r, ci = i * 16 + li;
-          atomicAdd(&red[(t * BCO + co) * BCI + ci], acc[t][o][i][r]);
-        }
-  if (want_bias && li == 0) {
+            for (int r = 0; r < 4; ++r) {
+              // D[row = co = kg*4+r][col = ci = li]
+              float* dst = &red[(t * BCO + o * 16 + kg * 4 + r) * BCI + i * 16 + li];
+              *dst = (w == 0) ? acc[t][o][i][r] : *dst + acc[t][o][i][r];
+            }
+      if (li == 0) {
 #pragma unroll
-    for (int o = 0; o < NFO; ++o)
+        for (int o = 0; o < NFO; ++o)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[KK * BCO * BCI + o * 16 + kg * 4 + r], accb[o][r]);
+          for (int r = 0; r < 4; ++r) {
+            float* dst = &red[KK * BCO * BCI + o * 16 + kg * 4 + r];
+            *dst = (w == 0) ? accb[o][r] : *dst + accb[o][r];
+          }
+      }
+    }
   }
   __syncthreads();
   if (a.part) {
