@@ -154,17 +154,29 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x, istep = gridDim.x * 256u;
   unsigned pixel = i0 / CV;
   const unsigned pstep = istep / CV;
-  for (long i = i0; i < nvec; i += istep, pixel += pstep) {
-    float f[VG];
-    load_vec<T>(y + i * VG, f);
+  // MLP: 4 independent 16-byte loads per thread are issued before any is consumed (the plain grid-stride
+  // loop exposed one HBM round trip per vector)
+  for (long i = i0; i < nvec; i += 4L * istep, pixel += 4 * pstep) {
+    float f[4][VG];
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      float v = f[j] * sc[j] + sh[j];
-      v = v > 0.f ? v : v * slope;
-      if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel, c0 + j);
-      f[j] = v;
+    for (int u = 0; u < 4; ++u) {
+      const long iu = i + (long)u * istep;
+      load_vec<T>(y + (iu < nvec ? iu : i) * VG, f[u]);
     }
-    store_vec<T>(z + i * VG, f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long iu = i + (long)u * istep;
+      if (iu < nvec) {
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          float v = f[u][j] * sc[j] + sh[j];
+          v = v > 0.f ? v : v * slope;
+          if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel + u * pstep, c0 + j);
+          f[u][j] = v;
+        }
+        store_vec<T>(z + iu * VG, f[u]);
+      }
+    }
   }
 }
 
@@ -234,15 +246,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     mu[j] = mean[c0 + j];
     is[j] = invstd[c0 + j];
   }
-  for (long p = (long)blockIdx.x * PS + pl; p < pixels; p += (long)gridDim.x * PS) {
-    float dzv[VG], yv[VG], g[VG];
-    load_vec<T>(dz + (p * CV + cv) * VG, dzv);
-    load_vec<T>(y + (p * CV + cv) * VG, yv);
-    act_grad<T>(dzv, yv, sc, sh, c0, (size_t)p, slope, dr, seed, g);
+  const long pstride = (long)gridDim.x * PS;
+  for (long p = (long)blockIdx.x * PS + pl; p < pixels; p += 2 * pstride) {   // 2 pixels x (dz, y) in flight
+    float dzv[2][VG], yv[2][VG];
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      sg[j] += g[j];
-      sgx[j] += g[j] * (yv[j] - mu[j]) * is[j];
+    for (int u = 0; u < 2; ++u) {
+      const long pu = p + u * pstride;
+      const long pq = pu < pixels ? pu : p;
+      load_vec<T>(dz + (pq * CV + cv) * VG, dzv[u]);
+      load_vec<T>(y + (pq * CV + cv) * VG, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long pu = p + u * pstride;
+      if (pu < pixels) {
+        float g[VG];
+        act_grad<T>(dzv[u], yv[u], sc, sh, c0, (size_t)pu, slope, dr, seed, g);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          sg[j] += g[j];
+          sgx[j] += g[j] * (yv[u][j] - mu[j]) * is[j];
+        }
+      }
     }
   }
   __shared__ float red[256][2 * VG + 1];
@@ -281,7 +306,7 @@ extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void
   const int CV = d->C / VG;
   if (CV > 256 || 256 % CV) return FI_ERR_SHAPE;
   const int PS = 256 / CV;
-  const int grid = grid_for(d->pixels, PS * 8);
+  const int grid = grid_for(d->pixels, PS * 4);
   if (d->dtype == FI_F32)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
                        (const float*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   __shared__ float ssum[2 * 512];
   for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
     double tot = 0.0;
+#pragma unroll 8
     for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) tot += sums[(size_t)slot * 2 * C + t];
     ssum[t] = (float)tot;
   }
@@ -339,14 +365,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x, istep = gridDim.x * 256u;
   unsigned pixel = i0 / CVu;
   const unsigned pstep = istep / CVu;
-  for (long i = i0; i < nvec; i += istep, pixel += pstep) {
-    float dzv[VG], yv[VG], g[VG], out[VG];
-    load_vec<T>(dz + i * VG, dzv);
-    load_vec<T>(y + i * VG, yv);
-    act_grad<T>(dzv, yv, sc, sh, c0, pixel, slope, dr, seed, g);
+  for (long i = i0; i < nvec; i += 2L * istep, pixel += 2 * pstep) {   // 2 x (dz, y) = 4 loads in flight
+    float dzv[2][VG], yv[2][VG];
 #pragma unroll
-    for (int j = 0; j < VG; ++j) out[j] = sc[j] * g[j] - k0[j] - (yv[j] - mu[j]) * k1[j];
-    store_vec<T>(dy + i * VG, out);
+    for (int u = 0; u < 2; ++u) {
+      const long iu = i + (long)u * istep;
+      const long il = iu < nvec ? iu : i;
+      load_vec<T>(dz + il * VG, dzv[u]);
+      load_vec<T>(y + il * VG, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long iu = i + (long)u * istep;
+      if (iu < nvec) {
+        float g[VG], out[VG];
+        act_grad<T>(dzv[u], yv[u], sc, sh, c0, pixel + u * pstep, slope, dr, seed, g);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) out[j] = sc[j] * g[j] - k0[j] - (yv[u][j] - mu[j]) * k1[j];
+        store_vec<T>(dy + iu * VG, out);
+      }
+    }
   }
 }
 
@@ -844,6 +882,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
     double unb = 0.0;
     if (training) {
       double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
       for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) {
         s1 += stats[((size_t)slot * C + c) * 2];
         s2 += stats[((size_t)slot * C + c) * 2 + 1];
@@ -886,17 +925,29 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x, istep = gridDim.x * 256u;
   unsigned pixel = i0 / CV;
   const unsigned pstep = istep / CV;
-  for (long i = i0; i < nvec; i += istep, pixel += pstep) {
-    float f[VG];
-    load_vec<T>(y + i * VG, f);
+  // MLP: 4 independent 16-byte loads per thread are issued before any is consumed (the plain grid-stride
+  // loop exposed one HBM round trip per vector)
+  for (long i = i0; i < nvec; i += 4L * istep, pixel += 4 * pstep) {
+    float f[4][VG];
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      float v = f[j] * sc[j] + sh[j];
-      v = v > 0.f ? v : v * slope;
-      if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel, c0 + j);
-      f[j] = v;
+    for (int u = 0; u < 4; ++u) {
+      const long iu = i + (long)u * istep;
+      load_vec<T>(y + (iu < nvec ? iu : i) * VG, f[u]);
     }
-    store_vec<T>(z + i * VG, f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long iu = i + (long)u * istep;
+      if (iu < nvec) {
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          float v = f[u][j] * sc[j] + sh[j];
+          v = v > 0.f ? v : v * slope;
+          if (dr.mode != FI_DROP_NONE) v *= drop_factor(dr, seed, pixel + u * pstep, c0 + j);
+          f[u][j] = v;
+        }
+        store_vec<T>(z + iu * VG, f[u]);
+      }
+    }
   }
 }
 
