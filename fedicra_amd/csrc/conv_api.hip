@@ -50,6 +50,7 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1 || d->co1 < 0) return FI_ERR_SHAPE;
   if ((d->c1 > 0 && !x1) || (d->co1 > 0 && !y1)) return FI_ERR_NULL;
+  if ((long)d->N * d->H * d->W >= (1L << 31)) return FI_ERR_UNSUPPORTED;   // kernels index pixels with 32 bits
   const int cin = d->c0 + d->c1, cout = d->co0 + d->co1;
   const bool f32 = d->dtype == FI_F32;
   int ck;

@@ -116,95 +116,95 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging.  Loads are UNCONDITIONAL (out-of-image / out-of-range lanes read a clamped, valid address and
-  //      are zeroed when written to LDS): a load under a divergent branch forces the compiler to wait for it
-  //      at the merge point, which serialises one HBM round trip per vector.  Vectors are moved in groups of
-  //      SG so that SG loads per lane are in flight while only SG*4 VGPRs are held (occupancy stays high).
-  constexpr int SG = 4;
+  // ---- staging.  A thread owns ONE vector column of the halo tile (pixel column px, channel vector v) and ONE
+  //      (tap, channel vector) column of the weight slab for the whole kernel and walks rows with constant
+  //      strides -- no div/mod, one bounds compare and one multiply-add per vector.  Loads are unconditional
+  //      (clamped address, zeroed at the LDS write): a load under a divergent branch makes the compiler wait for
+  //      it at the merge point, which serialises one HBM round trip per vector.
+  //      Tried and measured slower on MI355X (tools/kbench.py): prefetching the next chunk
+  //      into registers (VGPRs 100 -> 180-240, occupancy halves: 354 -> 499 us over the U-Net forward convs) and
+  //      persistent workgroups walking several tiles (354 -> 415 us): many independent workgroups hide the
+  //      staging round trips better.
+  constexpr int XCOLS = XW * VPP, XRPP = 256 / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
+  constexpr int WCOLS = KK * VPP, WRPP = 256 / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
+  static_assert(XRPP >= 1 && WRPP >= 1, "tile too wide for 256 threads");
+  const int xcol = tid % XCOLS, xrow0 = tid / XCOLS;
+  const int xpx = xcol / VPP, xv = xcol % VPP;
+  const int xgx = tx * 16 + xpx - HALO;
+  const bool xcolok = xrow0 < XRPP && xgx >= 0 && xgx < W;
+  const int xcx = min(max(xgx, 0), W - 1);
+  const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;
+  const int wcol = tid % WCOLS, wrow0 = tid / WCOLS;
+  const int wt = wcol / VPP, wv = wcol % VPP;
+  const int wlds0 = wrow0 * WKP + wt * CK + wv * VG;
   auto stage = [&](int cb) {
+    {
+      const int ci = cb + xv * VG;
+      const bool chok = ci < cin;
+      const int cc = chok ? ci : 0;
+      const bool first = cc < a.c0;
+      const T* colbase = first ? x0 + cc : x1 + (cc - a.c0);
+      const int cstride = first ? a.c0 : a.c1;
+      vec_t r[XPASS];
+      bool ok[XPASS];
 #pragma unroll
-    for (int g0 = 0; g0 < NX; g0 += SG) {
-      vec_t r[SG];
-      bool ok[SG];
-#pragma unroll
-      for (int j = 0; j < SG; ++j) {
-        const int it = g0 + j;
-        if (it < NX) {
-          const int i = tid + it * 256;
-          const int ii = i < NXV ? i : 0;
-          const int v = ii % VPP, pix = ii / VPP;
-          const int py = pix / XW, px = pix % XW;
-          const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
-          const int ci = cb + v * VG;
-          ok[j] = (i < NXV) && gy >= 0 && gy < H && gx >= 0 && gx < W && (vec_ok ? ci < cin : true);
-          const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-          const size_t gp = ((size_t)n * H + cy) * W + cx;
-          if (vec_ok) {
-            const int cc = ci < cin ? ci : 0;
-            const T* src = (cc < a.c0) ? x0 + gp * a.c0 + cc : x1 + gp * a.c1 + (cc - a.c0);
-            r[j] = *reinterpret_cast<const vec_t*>(src);
-          } else {
-            r[j] = load_cat<T>(x0, x1, a.c0, a.c1, gp, ci, false);   // narrow tensors (image, logits grad)
-          }
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        const int gy = ty * TH + py - HALO;
+        ok[p] = xcolok && chok && py < XH && gy >= 0 && gy < H;
+        const int cy = min(max(gy, 0), H - 1);
+        const int pix = (n * H + cy) * W + xcx;   // < 2^31 pixels per tensor (host-checked)
+        if (vec_ok) {
+          r[p] = *reinterpret_cast<const vec_t*>(colbase + (size_t)pix * cstride);
+        } else {
+          r[p] = load_cat<T>(x0, x1, a.c0, a.c1, (size_t)pix, ci, false);   // narrow tensors (image, logits grad)
         }
       }
 #pragma unroll
-      for (int j = 0; j < SG; ++j) {
-        const int it = g0 + j;
-        if (it < NX) {
-          const int i = tid + it * 256;
-          if (i < NXV) {
-            vec_t val = r[j];
-            if (!ok[j]) memset(&val, 0, sizeof(val));
-            *reinterpret_cast<vec_t*>(&xs[(i / VPP) * CKP + (i % VPP) * VG]) = val;
-          }
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        if (xrow0 < XRPP && py < XH) {
+          vec_t val = r[p];
+          if (!ok[p]) memset(&val, 0, sizeof(val));
+          *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
         }
       }
     }
+    {
+      const int ci = cb + wv * VG;
+      const bool chok = ci < cin && wrow0 < WRPP;
+      const T* colbase = wg + (size_t)wt * cin + (ci < cin ? ci : 0);
+      vec_t r[WPASS];
+      bool ok[WPASS];
 #pragma unroll
-    for (int g0 = 0; g0 < NW; g0 += SG) {
-      vec_t r[SG];
-      bool ok[SG];
+      for (int p = 0; p < WPASS; ++p) {
+        const int co = wrow0 + p * WRPP;
+        const int gco = ct * BN + co;
+        ok[p] = chok && co < BN && gco < cout;
+        const T* src = colbase + (size_t)(gco < cout ? gco : 0) * (KK * cin);
+        if (wvec_ok) {
+          r[p] = *reinterpret_cast<const vec_t*>(src);
+        } else {
+          union {
+            vec_t vv;
+            T e[VG];
+          } u;
+          memset(&u, 0, sizeof(u));
+          if (ok[p]) {
 #pragma unroll
-      for (int j = 0; j < SG; ++j) {
-        const int it = g0 + j;
-        if (it < NW) {
-          const int i = tid + it * 256;
-          const int ii = i < NWV ? i : 0;
-          const int v = ii % VPP, t = (ii / VPP) % KK, co = ii / (VPP * KK);
-          const int gco = ct * BN + co, ci = cb + v * VG;
-          if (wvec_ok) {
-            ok[j] = (i < NWV) && gco < cout && ci < cin;
-            const T* src = wg + ((size_t)(gco < cout ? gco : 0) * KK + t) * cin + (ci < cin ? ci : 0);
-            r[j] = *reinterpret_cast<const vec_t*>(src);
-          } else {
-            union {
-              vec_t vv;
-              T e[VG];
-            } u;
-            memset(&u, 0, sizeof(u));
-            ok[j] = (i < NWV) && gco < cout;
-            if (ok[j]) {
-              const T* src = wg + ((size_t)gco * KK + t) * cin + ci;
-#pragma unroll
-              for (int q = 0; q < VG; ++q)
-                if (ci + q < cin) u.e[q] = src[q];
-            }
-            r[j] = u.vv;
+            for (int q = 0; q < VG; ++q)
+              if (ci + q < cin) u.e[q] = src[q];
           }
+          r[p] = u.vv;
         }
       }
 #pragma unroll
-      for (int j = 0; j < SG; ++j) {
-        const int it = g0 + j;
-        if (it < NW) {
-          const int i = tid + it * 256;
-          if (i < NWV) {
-            const int v = i % VPP, t = (i / VPP) % KK, co = i / (VPP * KK);
-            vec_t val = r[j];
-            if (!ok[j]) memset(&val, 0, sizeof(val));
-            *reinterpret_cast<vec_t*>(&ws[co * WKP + t * CK + v * VG]) = val;
-          }
+      for (int p = 0; p < WPASS; ++p) {
+        const int co = wrow0 + p * WRPP;
+        if (wrow0 < WRPP && co < BN) {
+          vec_t val = r[p];
+          if (!ok[p]) memset(&val, 0, sizeof(val));
+          *reinterpret_cast<vec_t*>(&ws[wlds0 + p * (WRPP * WKP)]) = val;
         }
       }
     }

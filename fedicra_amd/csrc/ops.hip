@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   __shared__ float ssum[2 * 512];
   for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
     double tot = 0.0;
-#pragma unroll 8
+#pragma unroll
     for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) tot += sums[(size_t)slot * 2 * C + t];
     ssum[t] = (float)tot;
   }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
     double unb = 0.0;
     if (training) {
       double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
+#pragma unroll
       for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) {
         s1 += stats[((size_t)slot * C + c) * 2];
         s2 += stats[((size_t)slot * C + c) * 2 + 1];

@@ -68,7 +68,7 @@ typedef struct FiConv {
  * per-channel (sum, sum of squares) of the stored output are ATOMICALLY ADDED to one of the slots
  * (caller zeroes the whole buffer; fi_bn_finalize sums the slots) -- the batch statistics
  * BatchNorm2d (unet.py:21) needs, produced in the conv epilogue. */
-#define FI_STATS_SLOTS 32
+#define FI_STATS_SLOTS 8
 int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                   void* y0, void* y1, double* stats, void* stream);
 
