@@ -18,10 +18,12 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_pack_weights",
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
-    "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_dice_counts", "fi_adamw_hyper",
+    "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -194,6 +196,31 @@ def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize, deterministic=True):
                                    C.c_long(nbytes), stream()), "fi_conv2d_wgrad")
 
 
+def conv2d_wgrad_partial(x0, x1, dy, want_bias, *, ksize):
+    """Stage 1 only.  Returns (workspace tensor, slices, stride) for a later fi_wgrad_reduce_multi."""
+    _dev(x0)
+    N, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[3], 0, 0, 0, 0)
+    cin, cout, px = c0 + c1, dy.shape[3], N * H * W
+    nbytes = lib().fi_conv2d_wgrad_workspace(C.byref(d))
+    if nbytes < 0:
+        _chk(int(nbytes), "fi_conv2d_wgrad_workspace")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
+    slices, stride = C.c_int(0), C.c_long(0)
+    with _timed("conv_wgrad", (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
+                px * cin * _esz(x0) + px * cout * _esz(dy) + cin * cout * ksize * ksize * 4):
+        _chk(lib().fi_conv2d_wgrad_partial(C.byref(d), ptr(x0), ptr(x1), ptr(dy), int(want_bias), ptr(ws),
+                                           C.c_long(nbytes), C.byref(slices), C.byref(stride), stream()),
+             "fi_conv2d_wgrad_partial")
+    return ws, slices.value, stride.value
+
+
+def wgrad_reduce_multi(table, n):
+    with _timed("wgrad_reduce", (n,), 0, 0):
+        _chk(lib().fi_wgrad_reduce_multi(ptr(_dev(table)), int(n), stream()), "fi_wgrad_reduce_multi")
+
+
 def pack_weights(src, dst, cout, kk, cin, mode):
     _chk(lib().fi_pack_weights(ptr(_dev(src)), ptr(dst), cout, kk, cin, mode, dt(dst.dtype), stream()),
          "fi_pack_weights")
@@ -285,6 +312,24 @@ def ce_bwd(logits, labels, ignore_index, acc, gscale, dlogits):
     M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
     _chk(lib().fi_ce_bwd(ptr(logits), ptr(labels), C.c_long(M), Cc, ignore_index, ptr(acc), ptr(gscale), ptr(dlogits),
                          dt(dlogits.dtype), stream()), "fi_ce_bwd")
+
+
+def pdice_fwd(probs, labels, ignore_index, acc):
+    B, Cc = _dev(probs).shape[0], probs.shape[-1]
+    HW = probs.numel() // (B * Cc)
+    _chk(lib().fi_pdice_fwd(ptr(probs), ptr(labels), B, C.c_long(HW), Cc, int(ignore_index), ptr(acc), stream()),
+         "fi_pdice_fwd")
+
+
+def pdice_finalize(acc, weight, ncls, loss):
+    _chk(lib().fi_pdice_finalize(ptr(_dev(acc)), ptr(weight), int(ncls), ptr(loss), stream()), "fi_pdice_finalize")
+
+
+def pdice_bwd(probs, labels, ignore_index, acc, weight, gscale, dprobs):
+    B, Cc = _dev(probs).shape[0], probs.shape[-1]
+    HW = probs.numel() // (B * Cc)
+    _chk(lib().fi_pdice_bwd(ptr(probs), ptr(labels), B, C.c_long(HW), Cc, int(ignore_index), ptr(acc), ptr(weight),
+                            ptr(gscale), ptr(dprobs), stream()), "fi_pdice_bwd")
 
 
 def dice_counts(logits, gt, counts):

@@ -139,8 +139,75 @@ extern "C" long fi_conv2d_wgrad_workspace(const FiConv* d) {
   return (long)(p.part_stride * p.sb * sizeof(float));
 }
 
+static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw, float* dbias,
+                      void* workspace, long workspace_bytes, int reduce_now, int* slices_out, long* stride_out,
+                      void* stream);
+
 extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
                                float* dbias, void* workspace, long workspace_bytes, void* stream) {
+  return wgrad_impl(d, x0, x1, dy, dw, dbias, workspace, workspace_bytes, 1, nullptr, nullptr, stream);
+}
+
+extern "C" int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
+                                       void* workspace, long workspace_bytes, int* slices, long* stride,
+                                       void* stream) {
+  if (!workspace || !slices || !stride) return FI_ERR_NULL;
+  // dw / dbias are only used as "is requested" flags when the reduction is deferred
+  return wgrad_impl(d, x0, x1, dy, (float*)workspace, want_bias ? (float*)workspace : nullptr, workspace,
+                    workspace_bytes, 0, slices, stride, stream);
+}
+
+// table rows (int64 x 7): { partial ptr, slice stride (floats), slices, dw ptr, n_dw, dbias ptr or 0, cout }
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long* __restrict__ table) {
+  __shared__ float sm[8][32];
+  const long long* r = table + (size_t)blockIdx.y * 7;
+  const float* part = reinterpret_cast<const float*>(r[0]);
+  const size_t stride = (size_t)r[1];
+  const int slices = (int)r[2];
+  float* dw = reinterpret_cast<float*>(r[3]);
+  const size_t n_dw = (size_t)r[4];
+  float* dbias = reinterpret_cast<float*>(r[5]);
+  const size_t n = n_dw + (dbias ? (size_t)r[6] : 0);
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
+    const size_t i = base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int k = g;
+      for (; k + 24 < slices; k += 32) {
+        s0 += part[(size_t)k * stride + i];
+        s1 += part[(size_t)(k + 8) * stride + i];
+        s2 += part[(size_t)(k + 16) * stride + i];
+        s3 += part[(size_t)(k + 24) * stride + i];
+      }
+      for (; k < slices; k += 8) s0 += part[(size_t)k * stride + i];
+    }
+    __syncthreads();
+    sm[g][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n) {
+      float s = sm[0][e];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) s += sm[q][e];
+      if (i < n_dw)
+        dw[i] += s;
+      else
+        dbias[i - n_dw] += s;
+    }
+  }
+}
+
+extern "C" int fi_wgrad_reduce_multi(const long long* table, int ntensors, void* stream) {
+  if (!table) return FI_ERR_NULL;
+  if (ntensors <= 0) return 0;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(96, ntensors), dim3(256), 0, (hipStream_t)stream, table);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw, float* dbias,
+                      void* workspace, long workspace_bytes, int reduce_now, int* slices_out, long* stride_out,
+                      void* stream) {
   if (!d || !x0 || !dy || !dw) return FI_ERR_NULL;
   WgradPlan p;
   const int rc = plan_wgrad(d, &p);
@@ -180,7 +247,9 @@ extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, 
     r = d->ksize == 3 ? fi_conv_wgrad_bf16_k3(p.th, p.nfo, p.nfi, a, st)
                       : fi_conv_wgrad_bf16_k1(p.th, p.nfo, p.nfi, a, st);
   }
-  if (r || !workspace) return r;
+  if (slices_out) *slices_out = p.sb;
+  if (stride_out) *stride_out = (long)p.part_stride;
+  if (r || !workspace || !reduce_now) return r;
   const size_t n_dw = (size_t)cout * d->ksize * d->ksize * cin;
   const size_t n = n_dw + (dbias ? cout : 0);
   int grid = (int)((n + 31) / 32);

@@ -437,3 +437,110 @@ extern "C" int fi_probe_tr16(const short* in, const int* offs, short* out, void*
 }
 
 extern "C" int fi_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// (partial) Dice loss: pDLoss / DiceLoss of /root/reference/code/utils/losses.py:156-232.
+//   probs fp32 NHWC [B][HW][C] (softmax already applied), labels uint8 [B][HW].
+//   Reference quirk reproduced (pDLoss): the ignore mask keeps shape [B,1,H,W] while score/target planes are
+//   [B,H,W], so score*target*mask broadcasts to [B,B,H,W]:  sum_{b,b'} s[b'] t[b'] m[b]  =
+//   sum_hw M[hw] * sum_b' s[b'][hw] t[b'][hw]  with  M[hw] = sum_b m[b][hw].   ignore_index < 0: plain DiceLoss
+//   (M = 1).  acc (fp64 [C][3]) += {intersect, z_sum = sum s^2, y_sum = sum t^2}; caller zeroes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pdice_fwd_kernel(const float* __restrict__ probs,
+                                                        const uint8_t* __restrict__ labels, int B, long HW, int C,
+                                                        int ignore, double* acc) {
+  __shared__ double sm[4];
+  double I[FI_MAX_CLASSES], Z[FI_MAX_CLASSES], Y[FI_MAX_CLASSES];
+  for (int c = 0; c < FI_MAX_CLASSES; ++c) I[c] = Z[c] = Y[c] = 0.0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+    float M = 1.f;
+    if (ignore >= 0) {
+      M = 0.f;
+      for (int b = 0; b < B; ++b) M += (labels[(size_t)b * HW + p] != ignore) ? 1.f : 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+      const int lb = labels[(size_t)b * HW + p];
+      const float* s = probs + ((size_t)b * HW + p) * C;
+      for (int c = 0; c < C; ++c) {
+        const float sv = s[c], tv = (lb == c) ? 1.f : 0.f;
+        I[c] += (double)(sv * tv * M);
+        Z[c] += (double)(sv * sv * M);
+        Y[c] += (double)(tv * tv * M);
+      }
+    }
+  }
+  for (int c = 0; c < C; ++c) {
+    const double i_ = block_sum(I[c], sm), z_ = block_sum(Z[c], sm), y_ = block_sum(Y[c], sm);
+    if (threadIdx.x == 0) {
+      atomicAdd(&acc[c * 3 + 0], i_);
+      atomicAdd(&acc[c * 3 + 1], z_);
+      atomicAdd(&acc[c * 3 + 2], y_);
+    }
+  }
+}
+
+// loss = sum_c w_c * (1 - (2 I_c + 1e-5) / (Z_c + Y_c + 1e-5)) / C     (losses.py:170-192, 209-232)
+__global__ void pdice_finalize_kernel(const double* acc, const float* weight, int C, float* loss) {
+  double l = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double d = 1.0 - (2.0 * acc[c * 3] + 1e-5) / (acc[c * 3 + 1] + acc[c * 3 + 2] + 1e-5);
+    l += d * (weight ? (double)weight[c] : 1.0);
+  }
+  loss[0] = (float)(l / C);
+}
+
+// d loss / d s[b][hw][c] = g * w_c / C * M[hw] * ( -2 t / D_c + 2 s (2 I_c + eps) / D_c^2 ),  D_c = Z_c + Y_c + eps
+__global__ __launch_bounds__(256) void pdice_bwd_kernel(const float* __restrict__ probs,
+                                                        const uint8_t* __restrict__ labels, int B, long HW, int C,
+                                                        int ignore, const double* __restrict__ acc,
+                                                        const float* weight, const float* gscale,
+                                                        float* __restrict__ dprobs) {
+  float k1[FI_MAX_CLASSES], k2[FI_MAX_CLASSES];
+  const float g = gscale ? gscale[0] : 1.f;
+  for (int c = 0; c < C; ++c) {
+    const double D = acc[c * 3 + 1] + acc[c * 3 + 2] + 1e-5;
+    const double w = (weight ? (double)weight[c] : 1.0) * (double)g / C;
+    k1[c] = (float)(-2.0 * w / D);
+    k2[c] = (float)(2.0 * w * (2.0 * acc[c * 3] + 1e-5) / (D * D));
+  }
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+    float M = 1.f;
+    if (ignore >= 0) {
+      M = 0.f;
+      for (int b = 0; b < B; ++b) M += (labels[(size_t)b * HW + p] != ignore) ? 1.f : 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+      const int lb = labels[(size_t)b * HW + p];
+      const float* s = probs + ((size_t)b * HW + p) * C;
+      float* o = dprobs + ((size_t)b * HW + p) * C;
+      for (int c = 0; c < C; ++c) o[c] = M * (k1[c] * ((lb == c) ? 1.f : 0.f) + k2[c] * s[c]);
+    }
+  }
+}
+
+extern "C" int fi_pdice_fwd(const float* probs, const uint8_t* labels, int B, long HW, int C, int ignore_index,
+                            double* acc, void* stream) {
+  if (!probs || !labels || !acc) return FI_ERR_NULL;
+  if (C < 1 || C > FI_MAX_CLASSES || B < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(pdice_fwd_kernel, dim3(grid_for(HW, 256)), dim3(256), 0, (hipStream_t)stream, probs, labels, B,
+                     HW, C, ignore_index, acc);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_pdice_finalize(const double* acc, const float* weight, int C, float* loss, void* stream) {
+  if (!acc || !loss) return FI_ERR_NULL;
+  if (C < 1 || C > FI_MAX_CLASSES) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(pdice_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, weight, C, loss);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_pdice_bwd(const float* probs, const uint8_t* labels, int B, long HW, int C, int ignore_index,
+                            const double* acc, const float* weight, const float* gscale, float* dprobs,
+                            void* stream) {
+  if (!probs || !labels || !acc || !dprobs) return FI_ERR_NULL;
+  if (C < 1 || C > FI_MAX_CLASSES || B < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(pdice_bwd_kernel, dim3(grid_for(HW, 256)), dim3(256), 0, (hipStream_t)stream, probs, labels, B,
+                     HW, C, ignore_index, acc, weight, gscale, dprobs);
+  FI_CHECK_LAUNCH();
+  return 0;
+}

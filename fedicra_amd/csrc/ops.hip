@@ -831,18 +831,38 @@ extern "C" int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, in
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long long* __restrict__ table) {
+  // 32 (cout) x 32 (cin) tiles per filter tap, transposed through LDS: reads are coalesced along cin, the dgrad
+  // operand's writes along cout (the element-wise scatter this replaces took 44 us for the U-Net's 1.8 M weights)
+  __shared__ float tile[32][33];
   const long long* d = table + (size_t)blockIdx.y * 6;
   const float* src = reinterpret_cast<const float*>(d[0]);
   T* dst0 = reinterpret_cast<T*>(d[1]);
   T* dst1 = reinterpret_cast<T*>(d[2]);
   const int cout = (int)d[3], kk = (int)d[4], cin = (int)d[5];
-  const unsigned n = (unsigned)cout * kk * cin;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const T v = from_f32<T>(src[i]);
-    if (dst0) dst0[i] = v;
+  const int tco = (cout + 31) / 32, tci = (cin + 31) / 32;
+  const int ntiles = tco * tci * kk;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int t = tl % kk, ci0 = ((tl / kk) % tci) * 32, co0 = (tl / (kk * tci)) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + ty + r * 8, ci = ci0 + tx;
+      float v = 0.f;
+      if (co < cout && ci < cin) {
+        const size_t i = ((size_t)co * kk + t) * cin + ci;
+        v = src[i];
+        if (dst0) dst0[i] = from_f32<T>(v);
+      }
+      tile[ty + r * 8][tx] = v;
+    }
+    __syncthreads();
     if (dst1) {
-      const unsigned ci = i % cin, t = (i / cin) % kk, co = i / ((unsigned)cin * kk);
-      dst1[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + r * 8, co = co0 + tx;
+        if (co < cout && ci < cin) dst1[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = from_f32<T>(tile[tx][ty + r * 8]);
+      }
     }
   }
 }
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long long
 extern "C" int fi_pack_weights_multi(const long long* table, int ntensors, int dtype, void* stream) {
   if (!table) return FI_ERR_NULL;
   if (ntensors <= 0) return 0;
-  const dim3 g(32, ntensors), b(256);
+  const dim3 g(64, ntensors), b(256);
   if (dtype == FI_F32)
     hipLaunchKernelGGL(pack_weights_multi_kernel<float>, g, b, 0, (hipStream_t)stream, table);
   else if (dtype == FI_BF16)

@@ -171,6 +171,65 @@ def _packed(wk, dtype, mode, cout, kk, cin, param=None):
     return out
 
 
+_pending_wgrad = []            # (workspace, stride, slices, dw, n_dw, dbias, cout) awaiting the multi-tensor reduce
+_wgrad_cb_queued = False
+_table_keepalive = []          # pinned host tables of eager launches: must outlive the async copy
+_graph_tables = []             # tables captured into a hipGraph
+
+
+def _defer_wgrad_reduce(ws, stride, slices, dw, n_dw, db, cout):
+    global _wgrad_cb_queued
+    _pending_wgrad.append((ws, stride, slices, dw, n_dw, db, cout))
+    if not _wgrad_cb_queued:
+        # runs once, after the last node of the current backward pass
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
+        _wgrad_cb_queued = True
+
+
+def flush_wgrad():
+    """Second stage of the deterministic wgrad for every layer of this backward pass: ONE launch that adds the
+    per-workgroup partial slices, in fixed order, into the (flat) weight / bias gradients."""
+    global _wgrad_cb_queued
+    _wgrad_cb_queued = False
+    if not _pending_wgrad:
+        return
+    rows = [[ws.data_ptr(), stride, slices, dw.data_ptr(), n_dw, 0 if db is None else db.data_ptr(), cout]
+            for ws, stride, slices, dw, n_dw, db, cout in _pending_wgrad]
+    dev = _pending_wgrad[0][0].device
+    capturing = torch.cuda.is_current_stream_capturing()
+    host = _pinned_slot(len(rows), capturing)
+    host.copy_(torch.tensor(rows, dtype=torch.int64))
+    table = host.to(dev, non_blocking=True)
+    L.wgrad_reduce_multi(table, len(rows))
+    if capturing:
+        _graph_tables.append((table, list(_pending_wgrad)))    # the graph re-reads host + partials on every replay
+    _pending_wgrad.clear()
+
+
+_PIN_SLOTS, _PIN_ROWS = 64, 128
+_pin_pool = None
+_pin_next = [0, _PIN_SLOTS // 2]       # eager slots cycle in the first half; captured graphs take the second half for good
+
+
+def _pinned_slot(nrows, capturing):
+    """Pinned host staging for the reduce table, allocated once (no host allocation inside a stream capture)."""
+    global _pin_pool
+    if _pin_pool is None:
+        _pin_pool = torch.empty((_PIN_SLOTS, _PIN_ROWS, 7), dtype=torch.int64).pin_memory()
+    if nrows > _PIN_ROWS:
+        raise L.FiError("too many deferred wgrad reductions in one backward pass")
+    half = _PIN_SLOTS // 2
+    if capturing:
+        s = _pin_next[1]
+        if s >= _PIN_SLOTS:
+            raise L.FiError("out of pinned table slots for captured graphs")
+        _pin_next[1] += 1
+    else:
+        s = _pin_next[0]
+        _pin_next[0] = (s + 1) % half
+    return _pin_pool[s, :nrows]
+
+
 def _conv_backward(ctx, dy, x0, x1, wk, mod):
     """Shared by _Conv and _ConvBNAct: returns (dx0, dx1, gw, gb)."""
     ksize, cout, cin = ctx.ksize, wk.shape[0], wk.shape[3]
@@ -198,9 +257,14 @@ def _conv_backward(ctx, dy, x0, x1, wk, mod):
         db = None
         if ctx.need_b:
             db, _, gb = _grad_target(mod.bias)
-        L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=ksize)
-        if ctx.need_w and dw.data_ptr() != wt_.data_ptr():
-            wt_.add_(dw.permute(0, 3, 1, 2))
+        if ctx.need_w and dw.data_ptr() == wt_.data_ptr():
+            # stage 1 now (partial sums into a workspace); stage 2 of ALL layers in one launch at the end of backward
+            ws, slices, stride = L.conv2d_wgrad_partial(x0, x1, dy, db is not None, ksize=ksize)
+            _defer_wgrad_reduce(ws, stride, slices, dw, cout * kk * cin, db, cout)
+        else:
+            L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=ksize)
+            if ctx.need_w and dw.data_ptr() != wt_.data_ptr():
+                wt_.add_(dw.permute(0, 3, 1, 2))
     return dx0, dx1, gw, gb
 
 

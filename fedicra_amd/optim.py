@@ -76,6 +76,8 @@ class FusedAdamW:
         return g
 
     def step(self):
+        from . import ops
+        ops.flush_wgrad()                    # no-op unless a backward's deferred wgrad reduction is still pending
         params = dict(self.model.named_parameters())
         active = [n for n in self._names if params[n].grad is not None]
         if not active:

@@ -81,6 +81,14 @@ long fi_conv2d_wgrad_workspace(const FiConv* d);
 int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
                     float* dbias, void* workspace, long workspace_bytes, void* stream);
 
+/* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
+ * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of
+ * fi_wgrad_reduce_multi over a device table (int64[n][7]):
+ * { partial ptr, stride, slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout };  dw/dbias += fixed-order slice sums. */
+int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
+                            void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
+int fi_wgrad_reduce_multi(const long long* table, int ntensors, void* stream);
+
 /* weight repack from the fp32 master [Cout][k*k][Cin]:
  *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)
  *   mode 1: dst[ci][k*k-1-t][co]    = (dtype) src[co][t][ci]          (dgrad operand: conv of dy
@@ -155,6 +163,17 @@ int fi_ce_finalize(const double* acc, float* loss, void* stream);
  * gscale: device fp32 scalar (upstream gradient) or NULL for 1. */
 int fi_ce_bwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index, const double* acc,
               const float* gscale, void* dlogits, int dtype, void* stream);
+
+/* pDLoss / DiceLoss (/root/reference/code/utils/losses.py:156-232).  probs: fp32 NHWC [B][HW][C] (softmax already
+ * applied), labels uint8 [B][HW].  ignore_index >= 0: pDLoss incl. the reference's [B,B,H,W] mask broadcast
+ * (every image's ignore mask multiplies every image's products); ignore_index < 0: plain DiceLoss.
+ * acc (fp64 [C][3], caller zeroes) += {sum s*t*M, sum s*s*M, sum t*t*M};  loss = sum_c w_c*(1 - (2I+1e-5)/(Z+Y+1e-5))/C
+ * (weight fp32 [C] or NULL = ones); dprobs = gscale * dloss/dprobs (gscale device fp32 scalar or NULL = 1). */
+int fi_pdice_fwd(const float* probs, const uint8_t* labels, int B, long HW, int C, int ignore_index, double* acc,
+                 void* stream);
+int fi_pdice_finalize(const double* acc, const float* weight, int C, float* loss, void* stream);
+int fi_pdice_bwd(const float* probs, const uint8_t* labels, int B, long HW, int C, int ignore_index, const double* acc,
+                 const float* weight, const float* gscale, float* dprobs, void* stream);
 
 /* Dice bookkeeping of val_2D.py:9-22,66-74: pred = argmax_c logits (first max wins, as torch.argmax);
  * for class i in 1..C-1: region = (lbl == 1) if i == 1 else (lbl >= 1); counts[(i-1)*3 + {0,1,2}] +=

@@ -294,6 +294,43 @@ def test_ce_and_dice_against_golden(golden):
     assert torch.isnan(loss).item()
 
 
+def test_pdice_and_dice_losses_against_reference_golden(golden):
+    """fedicra_amd.losses.{pDLoss, DiceLoss} vs values / gradients produced by the reference's own classes
+    (incl. pDLoss's [B,B,H,W] mask broadcast)."""
+    from fedicra_amd.losses import CrossEntropyLoss, DiceLoss, pDLoss
+    g = golden("g3_losses.npz")
+    for C in (2, 3):
+        logits = torch.tensor(g[f"logits{C}"])
+        lab = torch.from_numpy(g[f"labels{C}"]).to(DEV)
+        probs = torch.softmax(logits, 1).to(DEV).requires_grad_(True)
+        pd = pDLoss(C, ignore_index=C)(probs, lab.unsqueeze(1))
+        pd.backward()
+        assert abs(pd.item() - float(g[f"pdice{C}"])) < 2e-6, (pd.item(), float(g[f"pdice{C}"]))
+        assert torch.allclose(probs.grad.cpu(), torch.tensor(g[f"pdice_grad{C}"]), rtol=1e-4, atol=1e-9)
+        probs2 = torch.softmax(logits, 1).to(DEV).requires_grad_(True)
+        dl = DiceLoss(C)(probs2, torch.from_numpy(g[f"dense{C}"]).to(DEV))
+        dl.backward()
+        assert abs(dl.item() - float(g[f"dice{C}"])) < 2e-6
+        assert torch.allclose(probs2.grad.cpu(), torch.tensor(g[f"dice_grad{C}"]), rtol=1e-4, atol=1e-9)
+        lg = logits.clone().to(DEV).requires_grad_(True)
+        ce = CrossEntropyLoss(ignore_index=C)(lg, lab)
+        ce.backward()
+        assert abs(ce.item() - float(g[f"ce{C}"])) < 1e-5
+        assert torch.allclose(lg.grad.cpu(), torch.tensor(g[f"ce_grad{C}"]), rtol=1e-4, atol=1e-8)
+    # the single-site trainer's validation loss 0.5*(CE + pDLoss) (Unet_pCE.py:171-177) composes on the device
+    w = [0.3, 0.7]
+    probs = torch.softmax(torch.tensor(g["logits2"]), 1)
+    ref_w = None
+    from oracle.losses_ref import _one_hot
+    t = torch.from_numpy(g["labels2"]).unsqueeze(1)
+    mask = (t != 2).float()
+    oh = _one_hot(t, 2)
+    ref_w = sum(w[i] * (1 - (2 * (probs[:, i] * oh[:, i] * mask).sum() + 1e-5) /
+                        ((probs[:, i] ** 2 * mask).sum() + (oh[:, i] ** 2 * mask).sum() + 1e-5)) for i in range(2)) / 2
+    got = pDLoss(2, 2)(probs.to(DEV), t.to(DEV), weight=w)
+    assert abs(got.item() - ref_w.item()) < 2e-6
+
+
 def test_adamw_matches_torch():
     lib = L()
     n = 10_007
