@@ -216,9 +216,12 @@ def conv2d_wgrad_partial(x0, x1, dy, want_bias, *, ksize):
     return ws, slices.value, stride.value
 
 
-def wgrad_reduce_multi(table, n):
+WGRAD_ROW = 10       # FI_WGRAD_ROW
+
+
+def wgrad_reduce_multi(table, n, nblocks):
     with _timed("wgrad_reduce", (n,), 0, 0):
-        _chk(lib().fi_wgrad_reduce_multi(ptr(_dev(table)), int(n), stream()), "fi_wgrad_reduce_multi")
+        _chk(lib().fi_wgrad_reduce_multi(ptr(_dev(table)), int(n), int(nblocks), stream()), "fi_wgrad_reduce_multi")
 
 
 def pack_weights(src, dst, cout, kk, cin, mode):

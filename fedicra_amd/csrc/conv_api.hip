@@ -43,6 +43,11 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
   return 4;
 }
 
+#ifdef FI_TRACE
+static long long* g_trace = nullptr;
+extern "C" void fi_debug_set_trace(long long* p) { g_trace = p; }
+#endif
+
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
   if (!d || !x0 || !w || !y0) return FI_ERR_NULL;
@@ -70,6 +75,9 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     nct = fi_cdiv(cout, nf * 16);
     th = pick_th(d->N, d->H, d->W, nct);
   }
+  // Tried (tools/ktrace.py, kbench): channel chunks twice as wide for the deep layers, to halve the number of
+  // sequential stage -> MFMA round trips (1.7-2 us each).  The kernels then need >256 registers, one workgroup per
+  // CU stays resident and 16x16 256->256 went 20.6 -> 32.8 us.  Not kept.
   ConvArgs a;
   a.x0 = x0;
   a.x1 = x1 ? x1 : x0;
@@ -91,6 +99,9 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
   a.tilesX = fi_cdiv(d->W, 16);
   a.tilesY = fi_cdiv(d->H, th);
   a.nct = nct;
+#ifdef FI_TRACE
+  a.trace = g_trace;
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (f32) return d->ksize == 3 ? fi_conv_fwd_f32_k3(th, nf, ck, a, st) : fi_conv_fwd_f32_k1(th, nf, ck, a, st);
   return d->ksize == 3 ? fi_conv_fwd_bf16_k3(th, nf, ck, a, st) : fi_conv_fwd_bf16_k1(th, nf, ck, a, st);
@@ -128,7 +139,7 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p) {
   if (sb < 1) sb = 1;
   if (sb > ntiles) sb = ntiles;
   p->sb = (int)sb;
-  p->part_stride = (size_t)cout * d->ksize * d->ksize * cin + cout;
+  p->part_stride = (((size_t)cout * d->ksize * d->ksize * cin + cout) + 3) & ~(size_t)3;   // 16-B rows for the reducer
   return 0;
 }
 
@@ -158,9 +169,16 @@ extern "C" int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const vo
 }
 
 // table rows (int64 x 7): { partial ptr, slice stride (floats), slices, dw ptr, n_dw, dbias ptr or 0, cout }
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long* __restrict__ table) {
-  __shared__ float sm[8][32];
-  const long long* r = table + (size_t)blockIdx.y * 7;
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long* __restrict__ table, int ntensors) {
+  // One launch folds every layer's partial slices (278 MB per U-Net step) into the gradient buffer.  Rows of
+  // FI_WGRAD_ROW int64: {part, stride, slices, dw, n_dw, dbias|0, cout, first_block, log2(lanes)}.  A block owns
+  // 4*lanes consecutive elements of one tensor; its 256/lanes thread groups take the slices round-robin with 16-B loads
+  // (rows are 16-B aligned: stride % 4 == 0), and the groups are then folded through LDS in a fixed order.
+  __shared__ float sm[256 * 4];
+  int row = 0;
+  for (int t = 1; t < ntensors; ++t)
+    if ((long long)blockIdx.x >= table[(size_t)t * FI_WGRAD_ROW + 7]) row = t;
+  const long long* r = table + (size_t)row * FI_WGRAD_ROW;
   const float* part = reinterpret_cast<const float*>(r[0]);
   const size_t stride = (size_t)r[1];
   const int slices = (int)r[2];
@@ -168,39 +186,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long
   const size_t n_dw = (size_t)r[4];
   float* dbias = reinterpret_cast<float*>(r[5]);
   const size_t n = n_dw + (dbias ? (size_t)r[6] : 0);
-  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
-    const size_t i = base + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < n) {
-      int k = g;
-      for (; k + 24 < slices; k += 32) {
-        s0 += part[(size_t)k * stride + i];
-        s1 += part[(size_t)(k + 8) * stride + i];
-        s2 += part[(size_t)(k + 16) * stride + i];
-        s3 += part[(size_t)(k + 24) * stride + i];
-      }
-      for (; k < slices; k += 8) s0 += part[(size_t)k * stride + i];
+  const int ll = (int)r[8], lanes = 1 << ll, groups = 256 >> ll;
+  const int e = threadIdx.x & (lanes - 1), g = threadIdx.x >> ll;
+  const size_t base = ((size_t)blockIdx.x - (size_t)r[7]) * (size_t)(lanes * 4);
+  const size_t i = base + (size_t)e * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (i < stride) {
+    const float4* p = reinterpret_cast<const float4*>(part + i);
+    const size_t s4 = stride / 4;
+    int k = g;
+    for (; k + groups < slices; k += 2 * groups) {
+      const float4 a = p[(size_t)k * s4], b = p[(size_t)(k + groups) * s4];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
-    __syncthreads();
-    sm[g][e] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (g == 0 && i < n) {
-      float s = sm[0][e];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) s += sm[q][e];
-      if (i < n_dw)
-        dw[i] += s;
-      else
-        dbias[i - n_dw] += s;
+    if (k < slices) {
+      const float4 a = p[(size_t)k * s4];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
+  }
+  float* mine = sm + (size_t)g * (lanes * 4) + e * 4;
+  mine[0] = s0.x + s1.x; mine[1] = s0.y + s1.y; mine[2] = s0.z + s1.z; mine[3] = s0.w + s1.w;
+  __syncthreads();
+  for (int q = threadIdx.x; q < lanes * 4; q += 256) {
+    const size_t j = base + q;
+    if (j >= n) break;
+    float s = sm[q];
+    for (int h = 1; h < groups; ++h) s += sm[h * (lanes * 4) + q];
+    if (j < n_dw)
+      dw[j] += s;
+    else
+      dbias[j - n_dw] += s;
   }
 }
 
-extern "C" int fi_wgrad_reduce_multi(const long long* table, int ntensors, void* stream) {
+extern "C" int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, void* stream) {
   if (!table) return FI_ERR_NULL;
-  if (ntensors <= 0) return 0;
-  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(96, ntensors), dim3(256), 0, (hipStream_t)stream, table);
+  if (ntensors <= 0 || nblocks <= 0) return 0;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table, ntensors);
   FI_CHECK_LAUNCH();
   return 0;
 }

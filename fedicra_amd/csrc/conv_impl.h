@@ -31,7 +31,19 @@ struct ConvArgs {
   int c0, c1, co0, co1;
   int acc0, acc1, y_f32;
   int tilesX, tilesY, nct;
+#ifdef FI_TRACE
+  long long* trace;   // [workgroups][8] timestamps (tools/ktrace.py); debug builds only
+#endif
 };
+
+#ifdef FI_TRACE
+#define FI_TR(slot)                                                                                        \
+  do {                                                                                                     \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define FI_TR(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // staging helpers
@@ -93,7 +105,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
   const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
-  int bid = blockIdx.x;
+  // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Re-number them so that one XCD walks
+  // a contiguous run of (tile, cout-slab) pairs: the nct slabs that re-stage the SAME input tile (and the
+  // neighbouring tiles that share its halo) then hit that XCD's L2 instead of fetching the tile once per XCD.
+  int bid;
+  {
+    const unsigned B = gridDim.x, g = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const unsigned Bq = B >> 3, r = B & 7u;
+    bid = (int)(g * Bq + (g < r ? g : r) + q);
+  }
   const int ct = bid % a.nct;
   bid /= a.nct;
   const int tx = bid % a.tilesX;
@@ -106,6 +126,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const T* wg = reinterpret_cast<const T*>(a.w);
   const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
   const bool wvec_ok = (cin % VG == 0);
+  FI_TR(0);
+#ifdef FI_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[(size_t)blockIdx.x * 8 + 6] = (long long)wall_clock64();
+    a.trace[(size_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                          ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 
   // acc[m][f][r] = out(channel ct*BN + f*16 + kg*4 + r ; pixel row wave*MF+m, col li): the weights are the
   // MFMA "A" operand and the pixels the "B" operand, so a lane ends up with 4 CONSECUTIVE channels of one
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     __syncthreads();  // everyone finished reading the previous chunk
     stage(cb);
     __syncthreads();
+    if (cb == 0) FI_TR(1);
 
     // ---- MFMA over this chunk
     if constexpr (CK >= KSTEP) {
@@ -268,6 +297,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     }
   }
 
+  FI_TR(3);
   // ---- epilogue
   float ssum[NF][4], ssq[NF][4];
 #pragma unroll
@@ -361,6 +391,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       }
     }
   }
+  FI_TR(4);
   if (a.stats) {
     __syncthreads();  // LDS reuse: all MFMA reads are done
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
@@ -394,6 +425,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       }
     }
   }
+  FI_TR(5);
+#ifdef FI_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = (long long)wall_clock64();
+#endif
 }
 
 template <typename T, int KS, int TH, int NF, int CK>
@@ -406,6 +441,11 @@ static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
   const size_t red = (size_t)4 * BN * 2 * sizeof(float);
   if (lds < red) lds = red;
   const long blocks = (long)a.N * a.tilesX * a.tilesY * a.nct;
+  if (lds > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per instantiation (160 KB per CU)
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_fwd_kernel<T, KS, TH, NF, CK>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+  }
   hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;

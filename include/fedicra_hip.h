@@ -83,11 +83,15 @@ int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void*
 
 /* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
  * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of
- * fi_wgrad_reduce_multi over a device table (int64[n][7]):
- * { partial ptr, stride, slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout };  dw/dbias += fixed-order slice sums. */
+ * fi_wgrad_reduce_multi over a device table (int64[n][FI_WGRAD_ROW]):
+ * { partial ptr, stride (multiple of 4), slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout, first_block, log2(lanes) }
+ * where a workgroup folds 4*lanes consecutive elements (lanes in {16, 64, 256}: few lanes when there are many slices),
+ * tensor t owns workgroups [first_block_t, first_block_t + ceil(stride_t / (4*lanes_t))) and nblocks is their total.
+ * dw/dbias += fixed-order slice sums. */
+#define FI_WGRAD_ROW 10
 int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
                             void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
-int fi_wgrad_reduce_multi(const long long* table, int ntensors, void* stream);
+int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, void* stream);
 
 /* weight repack from the fp32 master [Cout][k*k][Cin]:
  *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)

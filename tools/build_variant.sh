@@ -8,6 +8,6 @@ if [ "$REV" = "WORK" ]; then
 else
   git -C $ROOT archive $REV fedicra_amd/csrc include | tar -x -C $T
 fi
-make -C $T/fedicra_amd/csrc -j8 > $T/build.log 2>&1 || { tail -20 $T/build.log; exit 1; }
+make -C $T/fedicra_amd/csrc -j8 EXTRA="$EXTRA" > $T/build.log 2>&1 || { tail -20 $T/build.log; exit 1; }
 mkdir -p $ROOT/variants && cp $T/fedicra_amd/libfedicra_hip.so $ROOT/variants/$NAME.so && rm -rf $T
 echo built variants/$NAME.so
