@@ -63,6 +63,10 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     ck = cin >= 16 ? 16 : (cin > 4 ? 8 : 4);
   else
     ck = cin >= 32 ? 32 : (cin > 8 ? 16 : 8);
+  {  // channel counts that are not whole 16-byte vectors: only the narrowest chunk has the element-wise loader
+    const int vg = f32 ? 4 : 8;
+    if (d->c0 % vg || d->c1 % vg) ck = vg;
+  }
   // Output-channel slab per workgroup: as wide as possible (less re-staging of the input tile) as long as the
   // launch still has FI_TARGET_BLOCKS workgroups.  The small feature maps are latency-bound with one workgroup
   // per CU; narrower slabs put several workgroups on each CU, whose staging round trips then overlap.
@@ -74,6 +78,15 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     nf /= 2;
     nct = fi_cdiv(cout, nf * 16);
     th = pick_th(d->N, d->H, d->W, nct);
+  }
+  {  // tuning knobs (tools/kbench.py sweeps): force the tile height / slab width
+    static const long force_th = env_long("FI_FORCE_TH", 0), force_nf = env_long("FI_FORCE_NF", 0);
+    if (force_nf) {
+      nf = (int)force_nf;
+      while (nf > 1 && (nf / 2) * 16 >= cout) nf /= 2;
+      nct = fi_cdiv(cout, nf * 16);
+    }
+    if (force_th) th = (int)force_th;
   }
   // Tried (tools/ktrace.py, kbench): channel chunks twice as wide for the deep layers, to halve the number of
   // sequential stage -> MFMA round trips (1.7-2 us each).  The kernels then need >256 registers, one workgroup per

@@ -82,7 +82,22 @@ __device__ __forceinline__ typename DT<T>::vec_t load_cat(const T* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------------------------
-template <typename T, int KS, int TH, int NF, int CK>
+// Register count, not LDS, decides how many workgroups share a CU here, and these kernels live off other workgroups
+// hiding their staging round trips (tools/ktrace.py: 3-5 us of a 6-8 us workgroup is the wait for its tile).  Three
+// things keep the count down (U-Net convs 355+281 -> 285+229 us fwd+dgrad):
+//  * the tap / K-step loop around the MFMAs is NOT unrolled: unrolled, the compiler hoists every LDS fragment read
+//    of the chunk to the top (25 fragments = 100 VGPRs for a 16-row tile);
+//  * the element-wise loader for channel counts that are not whole 16-byte vectors exists in the narrowest-chunk
+//    instantiation only (VEC below; host check), not as a never-taken branch in every kernel;
+//  * PLAIN: one output dtype, no accumulate, whole 4-channel groups -> the epilogue is one vector store per fragment;
+//    fp32 logits, accumulating dgrads and odd channel counts take the generic instantiation.
+// Tried and not kept: persistent workgroups that keep the weight slab in LDS and prefetch their next tile into
+// registers (single-chunk layers): the prefetch costs 40 VGPRs, residency drops, 256^2 16->16 21.6 us either way and
+// 32->16 27.7 -> 52.8 us.
+#ifndef FI_MMA_UNROLL
+#define FI_MMA_UNROLL 1
+#endif
+template <typename T, int KS, int TH, int NF, int CK, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
@@ -124,8 +139,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const T* x0 = reinterpret_cast<const T*>(a.x0);
   const T* x1 = reinterpret_cast<const T*>(a.x1);
   const T* wg = reinterpret_cast<const T*>(a.w);
-  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
-  const bool wvec_ok = (cin % VG == 0);
+  constexpr bool VEC = CK > VG;   // chunks wider than one vector: channel counts are whole vectors (host check)
   FI_TR(0);
 #ifdef FI_TRACE
   if (a.trace && threadIdx.x == 0) {
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         ok[p] = xcolok && chok && py < XH && gy >= 0 && gy < H;
         const int cy = min(max(gy, 0), H - 1);
         const int pix = (n * H + cy) * W + xcx;   // < 2^31 pixels per tensor (host-checked)
-        if (vec_ok) {
+        if constexpr (VEC) {
           r[p] = *reinterpret_cast<const vec_t*>(colbase + (size_t)pix * cstride);
         } else {
           r[p] = load_cat<T>(x0, x1, a.c0, a.c1, (size_t)pix, ci, false);   // narrow tensors (image, logits grad)
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         const int gco = ct * BN + co;
         ok[p] = chok && co < BN && gco < cout;
         const T* src = colbase + (size_t)(gco < cout ? gco : 0) * (KK * cin);
-        if (wvec_ok) {
+        if constexpr (VEC) {
           r[p] = *reinterpret_cast<const vec_t*>(src);
         } else {
           union {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
     // ---- MFMA over this chunk
     if constexpr (CK >= KSTEP) {
-#pragma unroll
+#pragma unroll FI_MMA_UNROLL
       for (int t = 0; t < KK; ++t) {
         const int r = t / KS, s = t % KS;
 #pragma unroll
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     } else {
       // CK < KSTEP (bf16 with 8 or 16 staged channels): one MFMA spans several taps; each lane's
       // 8 contraction elements stay inside one tap because CK % 8 == 0.
-#pragma unroll
+#pragma unroll FI_MMA_UNROLL
       for (int ks = 0; ks < KCP / KSTEP; ++ks) {
         const int k0 = ks * KSTEP + kg * KV;
         int t = k0 / CK;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     void* ybase = second ? a.y1 : a.y0;
     const int accum = second ? a.acc1 : a.acc0;
     // whole 4-channel group inside one destination and 4-aligned -> one vector store
-    const bool vec4 = (cg + 3 < cout) && (cdst % 4 == 0) && (cofs % 4 == 0) && (second || cg + 3 < a.co0);
+    const bool vec4 = PLAIN || ((cg + 3 < cout) && (cdst % 4 == 0) && (cofs % 4 == 0) && (second || cg + 3 < a.co0));
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const int gy = ty * TH + wave * MF + m;
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         for (int r = 0; r < 4; ++r) v[r] = acc[m][f][r] + bv[r];
         if (vec4) {
           const size_t o = pixo * cdst + cofs;
-          if (a.y_f32) {
+          if (!PLAIN && a.y_f32) {
             float4* yp = reinterpret_cast<float4*>(reinterpret_cast<float*>(ybase) + o);
             if (accum) {
               const float4 old = *yp;
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
               typename std::conditional<sizeof(T) == 2, uint2, float4>::type q;
             } u;
             T* yp = reinterpret_cast<T*>(ybase) + o;
-            if (accum) {
+            if (!PLAIN && accum) {
               u.q = *reinterpret_cast<decltype(u.q)*>(yp);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += to_f32(u.e[r]);
@@ -441,12 +455,11 @@ static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
   const size_t red = (size_t)4 * BN * 2 * sizeof(float);
   if (lds < red) lds = red;
   const long blocks = (long)a.N * a.tilesX * a.tilesY * a.nct;
-  if (lds > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per instantiation (160 KB per CU)
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_fwd_kernel<T, KS, TH, NF, CK>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return (int)attr;
-  }
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+  if (plain)
+    hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }
