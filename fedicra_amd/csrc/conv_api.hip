@@ -19,6 +19,11 @@ int fi_conv_wgrad_quad_bf16_k3(int th, const WgradArgs& a, hipStream_t st);
 #include <cstdlib>
 // tuning knobs (read once): FI_MIN_BLOCKS = workgroups a launch should reach before the tile height stops
 // shrinking; FI_WGRAD_BLOCKS = total workgroups of a wgrad launch (each spatial slice costs |dw| of workspace).
+#ifdef FI_TRACE
+static long long* g_trace = nullptr;
+extern "C" void fi_debug_set_trace(long long* p) { g_trace = p; }
+#endif
+
 static long env_long(const char* name, long dflt) {
   const char* v = getenv(name);
   return v ? atol(v) : dflt;
@@ -42,11 +47,6 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
   }
   return 4;
 }
-
-#ifdef FI_TRACE
-static long long* g_trace = nullptr;
-extern "C" void fi_debug_set_trace(long long* p) { g_trace = p; }
-#endif
 
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
@@ -270,6 +270,9 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   a.nco = p.nco;
   a.nci = p.nci;
   a.spatialBlocks = p.sb;
+#ifdef FI_TRACE
+  a.trace = g_trace;
+#endif
   hipStream_t st = (hipStream_t)stream;
   int r;
   if (p.quad) {

@@ -79,6 +79,27 @@ __device__ __forceinline__ typename DT<T>::vec_t load_cat(const T* __restrict__ 
   return u.v;
 }
 
+// The same vector as load_cat for channel counts that are whole vectors, as an UNCONDITIONAL load from a clamped
+// address that is zeroed afterwards when (gy, gx) lies outside the image, ci beyond cin or !live.  A load under a
+// divergent branch makes the compiler wait for it at the merge point: the wgrad tile fetch (10 vectors per thread)
+// then paid one memory round trip per vector -- 4-7 us per tile in tools/ktrace.py.
+template <typename T>
+__device__ __forceinline__ typename DT<T>::vec_t load_cat_clamped(const T* __restrict__ x0, const T* __restrict__ x1,
+                                                                  int c0, int c1, int n, int gy, int gx, int H, int W,
+                                                                  int ci, bool live) {
+  typedef typename DT<T>::vec_t vec_t;
+  const int cin = c0 + c1;
+  const bool ok = live && gy >= 0 && gy < H && gx >= 0 && gx < W && ci < cin;
+  const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+  const int cc = ci < cin ? ci : 0;
+  const bool first = cc < c0;
+  const T* base = first ? x0 + cc : x1 + (cc - c0);
+  const int cs = first ? c0 : c1;
+  vec_t v = *reinterpret_cast<const vec_t*>(base + ((size_t)(n * H + cy) * W + cx) * cs);
+  if (!ok) memset(&v, 0, sizeof(v));
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------------------------
@@ -482,7 +503,26 @@ struct WgradArgs {
   int N, H, W;
   int c0, c1, cout;
   int tilesX, tilesY, nco, nci, spatialBlocks;
+#ifdef FI_TRACE
+  long long* trace;
+#endif
 };
+
+#ifdef FI_TRACE
+#define FI_TR_BEGIN()                                                                                       \
+  do {                                                                                                      \
+    FI_TR(0);                                                                                               \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + 6] = (long long)wall_clock64();      \
+  } while (0)
+#define FI_TR_END()                                                                                         \
+  do {                                                                                                      \
+    FI_TR(5);                                                                                               \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = (long long)wall_clock64();      \
+  } while (0)
+#else
+#define FI_TR_BEGIN() do { } while (0)
+#define FI_TR_END() do { } while (0)
+#endif
 
 // Fragment loaders for the wgrad contraction (K = pixels).  `tile` is a row-major [pixel][stride] LDS
 // image (pixel = row*rowlen + col); the fragment covers 16 channels starting at `chan` and the KSTEP
@@ -529,7 +569,7 @@ template <> struct WgFrag<bf16_t> {
   }
 };
 
-template <typename T, int KS, int TH, int NFO, int NFI>
+template <typename T, int KS, int TH, int NFO, int NFI, bool VECX, bool VECD>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
@@ -557,8 +597,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const T* x0 = reinterpret_cast<const T*>(a.x0);
   const T* x1 = reinterpret_cast<const T*>(a.x1);
   const T* dyg = reinterpret_cast<const T*>(a.dy);
-  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
-  const bool dvec_ok = (cout % VG == 0);
   const bool want_bias = a.dbias != nullptr && cit == 0;
 
   f32x4 acc[KK][NFO][NFI];
@@ -585,13 +623,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int it = 0; it < NX; ++it) {
       const int i = tid + it * 256;
       vec_t val;
-      memset(&val, 0, sizeof(val));
-      if (i < NXV) {
-        const int v = i % VPX, pix = i / VPX;
+      if constexpr (VECX) {
+        const int ii = i < NXV ? i : 0;
+        const int v = ii % VPX, pix = ii / VPX;
         const int py = pix / XW, px = pix % XW;
-        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BCI + v * VG, vec_ok);
+        val = load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                  cit * BCI + v * VG, i < NXV);
+      } else {
+        memset(&val, 0, sizeof(val));
+        if (i < NXV) {
+          const int v = i % VPX, pix = i / VPX;
+          const int py = pix / XW, px = pix % XW;
+          const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+          if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BCI + v * VG, false);
+        }
       }
       xr[it] = val;
     }
@@ -599,12 +645,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int it = 0; it < ND; ++it) {
       const int i = tid + it * 256;
       vec_t val;
-      memset(&val, 0, sizeof(val));
-      if (i < NDV) {
-        const int v = i % VPD, pix = i / VPD;
-        const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
-        if (gy < H && gx < W)
-          val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BCO + v * VG, dvec_ok);
+      if constexpr (VECD) {
+        const int ii = i < NDV ? i : 0;
+        const int v = ii % VPD, pix = ii / VPD;
+        val = load_cat_clamped<T>(dyg, dyg, cout, 0, n, ty * TH + pix / 16, tx * 16 + pix % 16, H, W,
+                                  cot * BCO + v * VG, i < NDV);
+      } else {
+        memset(&val, 0, sizeof(val));
+        if (i < NDV) {
+          const int v = i % VPD, pix = i / VPD;
+          const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
+          if (gy < H && gx < W)
+            val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BCO + v * VG, false);
+        }
       }
       dr[it] = val;
     }
@@ -623,11 +676,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   };
 
   const int ntiles = a.N * a.tilesX * a.tilesY;
+  FI_TR_BEGIN();
   if (sb < ntiles) fetch(sb);
   for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
     __syncthreads();
     commit();
     __syncthreads();
+    if (tile == sb) FI_TR(1);
     if (tile + a.spatialBlocks < ntiles) fetch(tile + a.spatialBlocks);
 
     for (int ks = wave; ks < NKS; ks += 4) {
@@ -650,6 +705,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
+  FI_TR(3);
   // ---- combine the 4 waves through LDS: the waves take turns (plain ds_read/ds_write, fixed order ->
   //      deterministic).  LDS float atomics cost ~220 cycles per wave-instruction here and made the kernel
   //      LDS-bound (SQ_WAIT_INST_LDS 43 % of wave cycles); the turn-taking costs 4 barriers instead.
@@ -680,6 +736,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
   __syncthreads();
+  FI_TR(4);
   if (a.part) {
     // two-stage, deterministic: this workgroup's partial sums go to its own slice of the caller's
     // workspace with plain stores; wgrad_reduce_kernel then adds the slices in a fixed order.
@@ -693,6 +750,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int gco = cot * BCO + tid;
       if (gco < cout) slice[(size_t)cout * KK * cin + gco] = red[KK * BCO * BCI + tid];
     }
+    FI_TR_END();
     return;
   }
   for (int i = tid; i < KK * BCO * BCI; i += 256) {
@@ -752,7 +810,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
 // with the pixel-split kernel above this doubles the MFMAs per staged tile, needs no cross-wave LDS
 // reduction, and writes 4x fewer partial slices per channel for the same number of workgroups.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int KS, int TH>
+template <typename T, int KS, int TH, bool VECX, bool VECD>
 __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
@@ -778,8 +836,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   const T* x0 = reinterpret_cast<const T*>(a.x0);
   const T* x1 = reinterpret_cast<const T*>(a.x1);
   const T* dyg = reinterpret_cast<const T*>(a.dy);
-  const bool vec_ok = (a.c0 % VG == 0) && (a.c1 % VG == 0);
-  const bool dvec_ok = (cout % VG == 0);
   const bool want_bias = a.dbias != nullptr && cit == 0 && qi == 0;
 
   f32x4 acc[KK];
@@ -797,13 +853,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
     for (int it = 0; it < NX; ++it) {
       const int i = tid + it * 256;
       vec_t val;
-      memset(&val, 0, sizeof(val));
-      if (i < NXV) {
-        const int v = i % VPX, pix = i / VPX;
+      if constexpr (VECX) {
+        const int ii = i < NXV ? i : 0;
+        const int v = ii % VPX, pix = ii / VPX;
         const int py = pix / XW, px = pix % XW;
-        const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-          val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BC + v * VG, vec_ok);
+        val = load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                  cit * BC + v * VG, i < NXV);
+      } else {
+        memset(&val, 0, sizeof(val));
+        if (i < NXV) {
+          const int v = i % VPX, pix = i / VPX;
+          const int py = pix / XW, px = pix % XW;
+          const int gy = ty * TH + py - HALO, gx = tx * 16 + px - HALO;
+          if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            val = load_cat<T>(x0, x1, a.c0, a.c1, ((size_t)n * H + gy) * W + gx, cit * BC + v * VG, false);
+        }
       }
       xr[it] = val;
     }
@@ -811,12 +875,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
     for (int it = 0; it < ND; ++it) {
       const int i = tid + it * 256;
       vec_t val;
-      memset(&val, 0, sizeof(val));
-      if (i < NDV) {
-        const int v = i % VPX, pix = i / VPX;
-        const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
-        if (gy < H && gx < W)
-          val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BC + v * VG, dvec_ok);
+      if constexpr (VECD) {
+        const int ii = i < NDV ? i : 0;
+        const int v = ii % VPX, pix = ii / VPX;
+        val = load_cat_clamped<T>(dyg, dyg, cout, 0, n, ty * TH + pix / 16, tx * 16 + pix % 16, H, W,
+                                  cot * BC + v * VG, i < NDV);
+      } else {
+        memset(&val, 0, sizeof(val));
+        if (i < NDV) {
+          const int v = i % VPX, pix = i / VPX;
+          const int gy = ty * TH + pix / 16, gx = tx * 16 + pix % 16;
+          if (gy < H && gx < W)
+            val = load_cat<T>(dyg, dyg, cout, 0, ((size_t)n * H + gy) * W + gx, cot * BC + v * VG, false);
+        }
       }
       dr[it] = val;
     }
@@ -835,11 +906,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   };
 
   const int ntiles = a.N * a.tilesX * a.tilesY;
+  FI_TR_BEGIN();
   if (sb < ntiles) fetch(sb);
   for (int tile = sb; tile < ntiles; tile += a.spatialBlocks) {
     __syncthreads();
     commit();
     __syncthreads();
+    if (tile == sb) FI_TR(1);
     if (tile + a.spatialBlocks < ntiles) fetch(tile + a.spatialBlocks);
 #pragma unroll 2
     for (int ks = 0; ks < NKS; ++ks) {
@@ -853,6 +926,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
     }
   }
 
+  FI_TR(3);
+  FI_TR(4);
   // ---- flush: D[row = co = kg*4+r][col = ci = li] of this wave's quadrant
   const size_t n_dw = (size_t)cout * KK * cin;
   float* slice = a.part ? a.part + (size_t)sb * a.part_stride : nullptr;
@@ -882,6 +957,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
       }
     }
   }
+  FI_TR_END();
 }
 
 template <typename T, int KS, int TH>
@@ -890,7 +966,11 @@ static int launch_conv_wgrad_quad(const WgradArgs& a, hipStream_t st) {
   constexpr int XP = 32 + DT<T>::VG;
   const size_t lds = (size_t)(XH * XW * XP + TH * 16 * XP) * sizeof(T);
   const long blocks = (long)a.spatialBlocks * a.nco * a.nci;
-  hipLaunchKernelGGL((conv_wgrad_quad_kernel<T, KS, TH>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  // the quadrant kernel is only chosen for cin, cout >= 32; odd channel counts take the generic loaders
+  if (a.c0 % DT<T>::VG == 0 && a.c1 % DT<T>::VG == 0 && a.cout % DT<T>::VG == 0)
+    hipLaunchKernelGGL((conv_wgrad_quad_kernel<T, KS, TH, true, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_quad_kernel<T, KS, TH, false, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }
@@ -904,7 +984,16 @@ static int launch_conv_wgrad(const WgradArgs& a, hipStream_t st) {
   const size_t red = (size_t)(KK * BCO * BCI + BCO) * sizeof(float);
   if (lds < red) lds = red;
   const long blocks = (long)a.spatialBlocks * a.nco * a.nci;
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  const bool vx = a.c0 % VG == 0 && a.c1 % VG == 0, vd = a.cout % VG == 0;
+  const dim3 g((unsigned)blocks), b(256);
+  if (vx && vd)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI, true, true>), g, b, lds, st, a);
+  else if (vd)     // first layer: 1-channel image, 16-channel gradient
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI, false, true>), g, b, lds, st, a);
+  else if (vx)     // logits layer: 16-channel input, 2-channel gradient
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI, true, false>), g, b, lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, TH, NFO, NFI, false, false>), g, b, lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -16,7 +16,7 @@ import torch
 from kbench import LAYERS, FiConv, p
 
 
-def main(path, dtype="bf16", N=12):
+def main(path, kind="fwd", dtype="bf16", N=12):
     lib = C.CDLL(path)
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     di = 1 if dtype == "bf16" else 0
@@ -31,11 +31,20 @@ def main(path, dtype="bf16", N=12):
         y = torch.empty(N, H, H, cout, device="cuda", dtype=td)
         stats = torch.zeros(8 * cout * 2, dtype=torch.float64, device="cuda")
         d = FiConv(di, N, H, H, k, c0, c1, cout, 0, 0, 0, 0)
+        dy = torch.randn(N, H, H, cout, device="cuda").to(td)
+        dw = torch.zeros(cout, k, k, cin, device="cuda")
+        db = torch.zeros(cout, device="cuda")
+        lib.fi_conv2d_wgrad_workspace.restype = C.c_long
+        nb = lib.fi_conv2d_wgrad_workspace(C.byref(d))
+        ws = torch.empty(max(nb, 4) // 4, device="cuda")
         for rep in range(3):
             trace.zero_()
             lib.fi_debug_set_trace(C.c_void_p(trace.data_ptr() if rep == 2 else 0))
-            rc = lib.fi_conv2d_fwd(C.byref(d), p(x0), p(x1), p(w), None, p(y), None, p(stats), st)
-            assert rc == 0
+            if kind == "fwd":
+                rc = lib.fi_conv2d_fwd(C.byref(d), p(x0), p(x1), p(w), None, p(y), None, p(stats), st)
+            else:   # phases: first tile staged / tile loop / wave combine / partial-slice store
+                rc = lib.fi_conv2d_wgrad_partial(C.byref(d), p(x0), p(x1), p(dy), 1, p(ws), C.c_long(nb), C.byref(C.c_int(0)), C.byref(C.c_long(0)), st)
+            assert rc == 0, rc
             torch.cuda.synchronize()
         lib.fi_debug_set_trace(C.c_void_p(0))
         t = trace.cpu().numpy()
