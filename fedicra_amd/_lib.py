@@ -12,6 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfedicra_hip.so")
+LIB_PATH = os.environ.get("FEDICRA_HIP_LIB", LIB_PATH)        # another build of the same C ABI (kernel A/B runs)
 
 FI_F32, FI_BF16 = 0, 1
 STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h

@@ -64,6 +64,21 @@ __device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
   x ^= x >> 16;
   return x ^ (uint32_t)(seed >> 32);
 }
+// Element-wise dropout draws for the 4 consecutive elements of group `group` (= flat element index / 4): ONE full
+// hash of the group index, then one multiply per element.  Integer multiplies are quarter rate on CDNA: a full hash
+// per element plus its 64-bit index arithmetic (~65 instructions per element) made the fused BN kernels ALU-bound --
+// 4 us of arithmetic for 32 elements per thread in tools traces, against 1-3 us of memory time.
+__device__ __forceinline__ void fi_rand32x4(uint64_t seed, uint64_t group, uint32_t (&r)[4]) {
+  const uint32_t h = fi_rand32(seed, group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t x = h + (uint32_t)(j + 1) * 0x9E3779B9u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    r[j] = x;
+  }
+}
 // keep with probability (1-p): threshold on a 32-bit uniform
 __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t drop_thresh) {
   return fi_rand32(seed, idx) >= drop_thresh;

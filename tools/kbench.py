@@ -34,13 +34,20 @@ def p(t):
 
 
 def timeit(fn, reps):
-    for _ in range(3):
-        fn()
+    # captured into one hipGraph and replayed: the per-launch host overhead would hide anything below ~5 us
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
@@ -50,7 +57,6 @@ def bench_lib(path, dtype, reps, N=12):
     lib = C.CDLL(path)
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     di = 1 if dtype == "bf16" else 0
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     has_ws = hasattr(lib, "fi_conv2d_wgrad_workspace")
     if has_ws:
         lib.fi_conv2d_wgrad_workspace.restype = C.c_long
@@ -74,11 +80,11 @@ def bench_lib(path, dtype, reps, N=12):
         key = f"{H:3d} {cin:3d}->{cout:3d} k{k}"
 
         def fwd():
-            rc = lib.fi_conv2d_fwd(C.byref(dfw), p(x0), p(x1), p(w), p(b), p(y), None, p(stats), st)
+            rc = lib.fi_conv2d_fwd(C.byref(dfw), p(x0), p(x1), p(w), p(b), p(y), None, p(stats), C.c_void_p(torch.cuda.current_stream().cuda_stream))
             assert rc == 0, rc
 
         def dgrad():
-            rc = lib.fi_conv2d_fwd(C.byref(ddg), p(dy), None, p(wt), None, p(d0), p(d1), None, st)
+            rc = lib.fi_conv2d_fwd(C.byref(ddg), p(dy), None, p(wt), None, p(d0), p(d1), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             assert rc == 0, rc
 
         if has_ws:
@@ -86,11 +92,11 @@ def bench_lib(path, dtype, reps, N=12):
             ws = torch.empty(max(nb, 4) // 4, device="cuda")
 
             def wgrad():
-                rc = lib.fi_conv2d_wgrad(C.byref(dfw), p(x0), p(x1), p(dy), p(dw), p(db), p(ws), C.c_long(nb), st)
+                rc = lib.fi_conv2d_wgrad(C.byref(dfw), p(x0), p(x1), p(dy), p(dw), p(db), p(ws), C.c_long(nb), C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 assert rc == 0, rc
         else:
             def wgrad():
-                rc = lib.fi_conv2d_wgrad(C.byref(dfw), p(x0), p(x1), p(dy), p(dw), p(db), st)
+                rc = lib.fi_conv2d_wgrad(C.byref(dfw), p(x0), p(x1), p(dy), p(dw), p(db), C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 assert rc == 0, rc
 
         out[key] = (timeit(fwd, reps), timeit(dgrad, reps) if c0 > 1 else 0.0, timeit(wgrad, reps))
