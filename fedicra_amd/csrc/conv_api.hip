@@ -88,9 +88,17 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     }
     if (force_th) th = (int)force_th;
   }
-  // Tried (tools/ktrace.py, kbench): channel chunks twice as wide for the deep layers, to halve the number of
-  // sequential stage -> MFMA round trips (1.7-2 us each).  The kernels then need >256 registers, one workgroup per
-  // CU stays resident and 16x16 256->256 went 20.6 -> 32.8 us.  Not kept.
+  // Deep layers (many input channels, small maps) spend their time in the sequential stage -> MFMA round trips of
+  // the channel-chunk loop (1.5-2 us each, tools/ktrace.py): chunks twice as wide when the slab is narrow enough for
+  // the LDS tile to stay under FI_FWD_LDS_CAP, so that several workgroups still share a CU.
+  {
+    static const long lds_cap = env_long("FI_FWD_LDS_CAP", 40 * 1024);
+    const int big = f32 ? 32 : 64, vg = f32 ? 4 : 8, esz = f32 ? 4 : 2, kstep = f32 ? 4 : 32;
+    const int halo = d->ksize / 2, kk = d->ksize * d->ksize;
+    const long kcp = (long)((kk * big + kstep - 1) / kstep) * kstep;
+    const long lds = ((long)(th + 2 * halo) * (16 + 2 * halo) * (big + vg) + (long)nf * 16 * (kcp + vg)) * esz;
+    if (nf <= 2 && ck * 2 == big && cin >= 2 * big && d->c0 % big == 0 && d->c1 % big == 0 && lds <= lds_cap) ck = big;
+  }
   ConvArgs a;
   a.x0 = x0;
   a.x1 = x1 ? x1 : x0;

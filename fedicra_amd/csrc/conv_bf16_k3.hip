@@ -4,7 +4,8 @@
 #define FWD_CASE(TH_, NF_, CK_) \
   if (th == TH_ && nf == NF_ && ck == CK_) return launch_conv_fwd<bf16_t, 3, TH_, NF_, CK_>(a, st);
 #define FWD_CK(TH_, NF_) FWD_CASE(TH_, NF_, 8) FWD_CASE(TH_, NF_, 16) FWD_CASE(TH_, NF_, 32)
-#define FWD_NF(TH_) FWD_CK(TH_, 1) FWD_CK(TH_, 2) FWD_CK(TH_, 4)
+// deep layers: channel chunks twice as wide = half as many sequential staging round trips (narrow slabs only: LDS)
+#define FWD_NF(TH_) FWD_CK(TH_, 1) FWD_CK(TH_, 2) FWD_CK(TH_, 4) FWD_CASE(TH_, 1, 64) FWD_CASE(TH_, 2, 64)
 
 int fi_conv_fwd_bf16_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st) {
   FWD_NF(4) FWD_NF(8) FWD_NF(16)

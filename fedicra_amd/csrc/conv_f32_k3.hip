@@ -4,7 +4,8 @@
 #define FWD_CASE(TH_, NF_, CK_) \
   if (th == TH_ && nf == NF_ && ck == CK_) return launch_conv_fwd<float, 3, TH_, NF_, CK_>(a, st);
 #define FWD_CK(TH_, NF_) FWD_CASE(TH_, NF_, 4) FWD_CASE(TH_, NF_, 8) FWD_CASE(TH_, NF_, 16)
-#define FWD_NF(TH_) FWD_CK(TH_, 1) FWD_CK(TH_, 2) FWD_CK(TH_, 4)
+// deep layers: channel chunks twice as wide = half as many sequential staging round trips (narrow slabs only: LDS)
+#define FWD_NF(TH_) FWD_CK(TH_, 1) FWD_CK(TH_, 2) FWD_CK(TH_, 4) FWD_CASE(TH_, 1, 32) FWD_CASE(TH_, 2, 32)
 
 int fi_conv_fwd_f32_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st) {
   FWD_NF(4) FWD_NF(8) FWD_NF(16)
