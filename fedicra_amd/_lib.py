@@ -22,7 +22,7 @@ EXPORTS = [
     "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
-    "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_upsample2x_fwd",
+    "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
     "fi_pdice_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
@@ -218,6 +218,7 @@ def conv2d_wgrad_partial(x0, x1, dy, want_bias, *, ksize):
 
 
 WGRAD_ROW = 10       # FI_WGRAD_ROW
+CE_SLOTS = 16        # FI_CE_SLOTS
 
 
 def wgrad_reduce_multi(table, n, nblocks):
@@ -288,6 +289,14 @@ def maxpool2_bwd(x, dy, dx, accumulate=False):
     with _timed("maxpool_bwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 2.25 * x.numel() * _esz(x)):
         _chk(lib().fi_maxpool2_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, int(accumulate), stream()),
              "fi_maxpool2_bwd")
+
+
+def maxpool2_bwd_add(x, dy, add, dx):
+    """dx = add + scatter(dy): the pooling gradient joins the gradient of the tensor's other consumer in one pass."""
+    N, H, W, Cc = _dev(x).shape
+    with _timed("maxpool_bwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 3.25 * x.numel() * _esz(x)):
+        _chk(lib().fi_maxpool2_bwd_add(dt(x.dtype), ptr(x), ptr(dy), ptr(add), ptr(dx), N, H, W, Cc, stream()),
+             "fi_maxpool2_bwd_add")
 
 
 def upsample2x_fwd(x, y):

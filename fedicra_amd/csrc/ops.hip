@@ -529,8 +529,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                          T* __restrict__ dx, int N, int H, int W, int C,
-                                                          int accumulate) {
+                                                          const T* add, T* dx, int N, int H, int W, int C) {
   constexpr int VG = DT<T>::VG;
   const int CV = C / VG, Ho = H / 2, Wo = W / 2;
   const long nvec = (long)N * Ho * Wo * CV;
@@ -562,9 +561,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (accumulate) {
+      if (add) {   // dx = add + scatter(dy): the other consumer's gradient (skip connection) joins in the same pass
         float old[VG];
-        load_vec<T>(dx + offs[q], old);
+        load_vec<T>(add + offs[q], old);
 #pragma unroll
         for (int j = 0; j < VG; ++j) out[q][j] += old[j];
       }
@@ -596,8 +595,8 @@ extern "C" int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, 
   return 0;
 }
 
-extern "C" int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                               int accumulate, void* stream) {
+static int maxpool_bwd_impl(int dtype, const void* x, const void* dy, const void* add, void* dx, int N, int H, int W,
+                            int C, void* stream) {
   if (!x || !dy || !dx) return FI_ERR_NULL;
   if ((H & 1) || (W & 1)) return FI_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
@@ -606,18 +605,29 @@ extern "C" int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* d
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 4);
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
-                       (const float*)dy, (float*)dx, N, H, W, C, accumulate);
+                       (const float*)dy, (const float*)add, (float*)dx, N, H, W, C);
   } else if (dtype == FI_BF16) {
     if (C % 8) return FI_ERR_SHAPE;
     const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
-                       (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
+                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)add, (bf16_t*)dx, N, H, W, C);
   } else {
     return FI_ERR_DTYPE;
   }
   FI_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                               int accumulate, void* stream) {
+  return maxpool_bwd_impl(dtype, x, dy, accumulate ? dx : nullptr, dx, N, H, W, C, stream);
+}
+
+extern "C" int fi_maxpool2_bwd_add(int dtype, const void* x, const void* dy, const void* add, void* dx, int N, int H,
+                                   int W, int C, void* stream) {
+  if (!add) return FI_ERR_NULL;
+  return maxpool_bwd_impl(dtype, x, dy, add, dx, N, H, W, C, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -103,6 +103,11 @@ class DownBlock(_FiModule):
     def _run(self, x):
         return self.maxpool_conv[1]._run(ops.maxpool2(x))
 
+    def _run_skip(self, x):
+        """(x for the skip connection, block output): pooling and skip share one backward pass (ops._PoolSkip)."""
+        skip, pooled = ops.pool_skip(x)
+        return skip, self.maxpool_conv[1]._run(pooled)
+
     def forward(self, x):
         return self._out(self._run(self._in(x)))
 
@@ -146,10 +151,10 @@ class Encoder(_FiModule):
 
     def _run(self, x):
         x0 = self.in_conv._run(x)
-        x1 = self.down1._run(x0)
-        x2 = self.down2._run(x1)
-        x3 = self.down3._run(x2)
-        x4 = self.down4._run(x3)
+        x0, x1 = self.down1._run_skip(x0)
+        x1, x2 = self.down2._run_skip(x1)
+        x2, x3 = self.down3._run_skip(x2)
+        x3, x4 = self.down4._run_skip(x3)
         return [x0, x1, x2, x3, x4]
 
     def forward(self, x):

@@ -403,6 +403,35 @@ class _MaxPool(Function):
         return dx
 
 
+class _PoolSkip(Function):
+    """(skip, pooled) = (z, maxpool2(z)) for an encoder feature that feeds both the next level and a decoder skip
+    connection (unet.py:91-99: x0..x3 are returned AND pooled).  autograd would add the two gradients with a separate
+    elementwise kernel; backward here writes skip-gradient + scattered pooling gradient in the max-pool pass itself
+    (same rounding: one fp32 add per element, then the storage dtype)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.maxpool2_fwd(x, y)
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dskip, dy):
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return dskip
+        dx = torch.empty_like(x)
+        if dskip is None:
+            L.maxpool2_bwd(x, dy.contiguous(), dx)
+        else:
+            if dskip.dtype != x.dtype:
+                dskip = dskip.to(x.dtype)
+            L.maxpool2_bwd_add(x, dy.contiguous(), dskip.contiguous(), dx)
+        return dx
+
+
 class _Upsample(Function):
     @staticmethod
     def forward(ctx, x):
@@ -424,7 +453,7 @@ class _CELoss(Function):
 
     @staticmethod
     def forward(ctx, logits, labels, ignore_index, grad_dtype):
-        acc = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        acc = torch.zeros(2 * L.CE_SLOTS, dtype=torch.float64, device=logits.device)
         L.ce_fwd(logits, labels, ignore_index, acc)
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
         L.ce_finalize(acc, loss)
@@ -498,6 +527,11 @@ def conv_bn_act(x0, x1, conv, bn, slope, drop_p=0.0, drop_kind="elem"):
 
 def maxpool2(x):
     return _MaxPool.apply(x)
+
+
+def pool_skip(x):
+    """Returns (x, maxpool2(x)); use the first result wherever x is consumed besides the pooling."""
+    return _PoolSkip.apply(x)
 
 
 def upsample2x(x):

@@ -153,15 +153,21 @@ int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int 
 /* dx = route dy to the first maximum of each window (scan order, strict >), zeros elsewhere. */
 int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate,
                     void* stream);
+/* dx = add + (dy routed as above): the encoder features x0..x3 are pooled AND returned as skip connections
+ * (unet.py:91-99), so their gradient is the sum of two; this writes the sum in the pooling pass (add != dx allowed). */
+int fi_maxpool2_bwd_add(int dtype, const void* x, const void* dy, const void* add, void* dx, int N, int H, int W, int C,
+                        void* stream);
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet.py:58-59): [N,h,w,C]->[N,2h,2w,C] */
 int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream);
 int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------- losses ------------------
  * CrossEntropyLoss(ignore_index) (/root/reference/code/flower_pCE_2D.py:57,124): logits fp32 NHWC
- * [M][C], labels uint8 [M].  acc[0] += sum of -log p[label], acc[1] += #non-ignored (fp64, caller zeroes). */
+ * [M][C], labels uint8 [M].  acc is fp64 [FI_CE_SLOTS][2] (caller zeroes): workgroups add {sum of -log p[label],
+ * #non-ignored} to slot (workgroup % FI_CE_SLOTS); fi_ce_finalize / fi_ce_bwd fold the slots. */
+#define FI_CE_SLOTS 16
 int fi_ce_fwd(const float* logits, const uint8_t* labels, long M, int C, int ignore_index, double* acc, void* stream);
-/* loss[0] = acc[0]/acc[1] (fp32; NaN when nothing is labeled, as torch) */
+/* loss[0] = sum_s acc[s][0] / sum_s acc[s][1] (fp32; NaN when nothing is labeled, as torch) */
 int fi_ce_finalize(const double* acc, float* loss, void* stream);
 /* dlogits = gscale * (softmax - onehot) / count for labeled pixels, 0 otherwise; written in `dtype`.
  * gscale: device fp32 scalar (upstream gradient) or NULL for 1. */

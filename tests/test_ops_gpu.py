@@ -267,7 +267,7 @@ def test_ce_and_dice_against_golden(golden):
         logits = torch.tensor(g[f"logits{C}"])
         lab = torch.from_numpy(g[f"labels{C}"])
         ld = logits.permute(0, 2, 3, 1).contiguous().to(DEV)
-        acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+        acc = torch.zeros(2 * lib.CE_SLOTS, dtype=torch.float64, device=DEV)
         lib.ce_fwd(ld, lab.to(DEV), C, acc)
         loss = torch.empty(1, device=DEV)
         lib.ce_finalize(acc, loss)
@@ -287,7 +287,7 @@ def test_ce_and_dice_against_golden(golden):
             d_dev = 2.0 * cnt[i - 1, 0] / (cnt[i - 1, 1] + cnt[i - 1, 2])
             assert d_dev == 2.0 * (P & G).sum() / (P.sum() + G.sum())
     # all-ignored -> NaN like torch
-    acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    acc = torch.zeros(2 * lib.CE_SLOTS, dtype=torch.float64, device=DEV)
     lib.ce_fwd(torch.zeros(1, 8, 8, 2, device=DEV), torch.full((1, 8, 8), 2, dtype=torch.uint8, device=DEV), 2, acc)
     loss = torch.empty(1, device=DEV)
     lib.ce_finalize(acc, loss)
