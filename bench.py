@@ -95,7 +95,9 @@ def roofline_pass(client, a, dtype_name):
     client._train(cfg)                                   # warm the eager path
     L.profile_begin()
     client._train(cfg)
-    prof = L.profile_end().summary()
+    kp = L.profile_end()
+    prof = kp.summary()
+    L._prof_last_overhead = kp.overhead_ms
     total_ms = sum(v["ms"] for v in prof.values())
     # dominant kernel = the kernel FAMILY (one __global__ template: conv_fwd also serves dgrad) with the largest
     # share of GPU time; its launches are priced together: achieved = sum(algorithmic work) / sum(duration),
@@ -124,6 +126,7 @@ def roofline_pass(client, a, dtype_name):
         breakdown[k[0]] = b + v["ms"]
     roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": None, "kernel": "/".join(map(str, key)), "launches_per_step": calls / 3.0,
+            "event_bracket_overhead_us_subtracted": round(L._prof_last_overhead * 1e3, 2),
             "avg_us": round(avg_ms * 1e3, 2), "arithmetic_intensity_flop_per_byte": round(ai, 1),
             "frac_of_mfma_peak": round(flops / (avg_ms * 1e-3) / 1e12 / mf_peak, 4),
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,

@@ -93,10 +93,50 @@ def _dev(t):
 class KernelProfile:
     """HIP-event timing of individual C-ABI launches on the stream they are issued on.  Only active
     between profile_begin()/profile_end(); zero cost otherwise.  Each record carries the launch's
-    ALGORITHMIC flops and bytes (DESIGN.md 'roofline accounting') so that bench.py can price it."""
+    ALGORITHMIC flops and bytes (DESIGN.md 'roofline accounting') so that bench.py can price it.
+
+    Two things keep the host out of the numbers (an eager launch through ctypes costs ~8 us of host time, more than
+    most of these kernels run for, so a plain bracket measures the GPU waiting for Python):
+      * block(): at the start of every profiled iteration the stream is held by a spin kernel long enough for the
+        host to enqueue the whole iteration; the GPU then runs launches and event records back to back;
+      * the cost of the bracket itself (calibrate()) is subtracted from every interval."""
+
+    BLOCK_CYCLES = 60_000_000          # torch.cuda._sleep argument: ~30 ms, several times one iteration's enqueue time
 
     def __init__(self):
         self.rows = []
+        self.overhead_ms = 0.0
+
+    def block(self):
+        torch.cuda._sleep(self.BLOCK_CYCLES)
+
+    def calibrate(self):
+        """Bracket cost = interval around ONE tiny kernel minus the per-launch cost of that kernel when 20 of them
+        share a bracket (slope).  What stays in a measured interval is the kernel plus one back-to-back dispatch gap
+        (~1.5 us), which rocprofv3's begin/end stamps do not contain."""
+        x = torch.zeros(1, device="cuda")
+        tiny = lambda: scale(x, x, 1.0)
+        tiny()
+
+        def bracket(k, reps):
+            ev = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(k):
+                    tiny()
+                e1.record()
+                ev.append((e0, e1))
+            torch.cuda.synchronize()
+            v = sorted(a.elapsed_time(b) for a, b in ev)
+            return v[len(v) // 2]
+
+        self.block()
+        t1 = bracket(1, 60)
+        self.block()
+        t20 = bracket(20, 15)
+        per = (t20 - t1) / 19.0
+        self.overhead_ms = max(t1 - per, 0.0)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -104,7 +144,7 @@ class KernelProfile:
         for key, flops, nbytes, e0, e1 in self.rows:
             a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["calls"] += 1
-            a["ms"] += e0.elapsed_time(e1)
+            a["ms"] += max(e0.elapsed_time(e1) - self.overhead_ms, 0.0)
             a["flops"] += flops
             a["bytes"] += nbytes
         return agg
@@ -115,7 +155,9 @@ _prof = None
 
 def profile_begin():
     global _prof
-    _prof = KernelProfile()
+    p = KernelProfile()
+    p.calibrate()
+    _prof = p
     return _prof
 
 
@@ -123,6 +165,12 @@ def profile_end():
     global _prof
     p, _prof = _prof, None
     return p
+
+
+def profile_block():
+    """Called at the start of an iteration (ops.begin_iteration): no-op unless a profile is being taken."""
+    if _prof is not None:
+        _prof.block()
 
 
 class _Timed:

@@ -105,6 +105,7 @@ def begin_iteration(device=None):
     (FedICRA's no-grad forwards with other clients' embeddings) still get independent masks.  Also rewinds
     and clears the accumulator arena (one memset)."""
     _call_idx.clear()
+    L.profile_block()
     if device is not None:
         _arena.begin(torch.device(device))
 
