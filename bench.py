@@ -132,6 +132,17 @@ def roofline_pass(client, a, dtype_name):
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
             "share_of_gpu_time": round(dom["ms"] / total_ms, 4),
             "kernel_time_breakdown_ms_per_iter": {k: round(v / 3.0, 4) for k, v in sorted(breakdown.items())}}
+    # HBM traffic cannot be counted from inside the process: it comes from the last committed rocprofv3 PMC run of this
+    # same workload (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied -- see the json's header)
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_traffic.json")
+    if dtype_name == "bf16" and a.size == 256 and a.batch == 12 and os.path.exists(pmc_path):
+        try:
+            fam_pmc = json.load(open(pmc_path))["families"].get(fname)
+            if fam_pmc:
+                roof["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)"
+        except (OSError, ValueError, KeyError):
+            pass
     if os.environ.get("FEDICRA_BENCH_VERBOSE"):
         top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:40]
         for k, v in top:
