@@ -23,7 +23,7 @@ EXPORTS = [
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
-    "fi_upsample2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
+    "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
     "fi_pdice_bwd", "fi_dice_counts", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
@@ -358,6 +358,26 @@ def upsample2x_bwd(dy, dx, accumulate=False):
     with _timed("upsample_bwd", (str(dx.dtype)[6:],) + tuple(dx.shape), 0, 5 * dx.numel() * _esz(dx)):
         _chk(lib().fi_upsample2x_bwd(dt(dx.dtype), ptr(dy), ptr(dx), N, h, w, Cc, int(accumulate), stream()),
              "fi_upsample2x_bwd")
+
+
+def maxpool3d_fwd(x, y):
+    N, D, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_maxpool3d_fwd(dt(x.dtype), ptr(x), ptr(y), N, D, H, W, Cc, stream()), "fi_maxpool3d_fwd")
+
+
+def maxpool3d_bwd(x, dy, dx):
+    N, D, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_maxpool3d_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(dx), N, D, H, W, Cc, stream()), "fi_maxpool3d_bwd")
+
+
+def upsample3d2x_fwd(x, y):
+    N, d, h, w, Cc = _dev(x).shape
+    _chk(lib().fi_upsample3d2x_fwd(dt(x.dtype), ptr(x), ptr(y), N, d, h, w, Cc, stream()), "fi_upsample3d2x_fwd")
+
+
+def upsample3d2x_bwd(dy, dx):
+    N, d, h, w, Cc = _dev(dx).shape
+    _chk(lib().fi_upsample3d2x_bwd(dt(dx.dtype), ptr(dy), ptr(dx), N, d, h, w, Cc, stream()), "fi_upsample3d2x_bwd")
 
 
 def ce_fwd(logits, labels, ignore_index, acc):

@@ -1,0 +1,278 @@
+// 3D companions of the pooling / resampling kernels for the unet_3D surface:
+// MaxPool3d(2) and trilinear x2 up-sampling (align_corners = False, nn.Upsample's default) over dense NDHWC
+// (a volume is D consecutive NHWC slices, so the 2D convolution / normalisation kernels work on it slice-wise).
+// HBM-bound gather kernels: one 16-byte channel vector per lane.
+#include "common.h"
+
+template <typename T>
+__device__ __forceinline__ void ld(const T* p, float (&f)[DT<T>::VG]) {
+  union {
+    typename DT<T>::vec_t v;
+    T e[DT<T>::VG];
+  } u;
+  u.v = *reinterpret_cast<const typename DT<T>::vec_t*>(p);
+#pragma unroll
+  for (int j = 0; j < DT<T>::VG; ++j) f[j] = to_f32(u.e[j]);
+}
+template <typename T>
+__device__ __forceinline__ void st(T* p, const float (&f)[DT<T>::VG]) {
+  union {
+    typename DT<T>::vec_t v;
+    T e[DT<T>::VG];
+  } u;
+#pragma unroll
+  for (int j = 0; j < DT<T>::VG; ++j) u.e[j] = from_f32<T>(f[j]);
+  *reinterpret_cast<typename DT<T>::vec_t*>(p) = u.v;
+}
+
+static inline int grid3(long work, int per_block) {
+  long b = (work + per_block - 1) / per_block;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- MaxPool3d(kernel 2, stride 2).  x [N,D,H,W,C] -> y [N,D/2,H/2,W/2,C].  Backward routes dy to the FIRST maximum of
+//      the window in (d, h, w) scan order (strict >), as ATen does.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void maxpool3d_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
+                                                        int N, int D, int H, int W, int C) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long nvec = (long)N * Do * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    p /= Ho;
+    const int od = (int)(p % Do);
+    const int n = (int)(p / Do);
+    size_t offs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dyy = (q >> 1) & 1, dx = q & 1;
+      offs[q] = ((((size_t)n * D + 2 * od + dz) * H + 2 * oy + dyy) * W + 2 * ox + dx) * C + (size_t)cv * VG;
+    }
+    float v[8][VG];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ld<T>(x + offs[q], v[q]);
+    if (!BWD) {
+      float m[VG];
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        float mm = v[0][j];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) mm = v[q][j] > mm ? v[q][j] : mm;
+        m[j] = mm;
+      }
+      st<T>(out + i * VG, m);
+    } else {
+      float g[VG], o[8][VG];
+      ld<T>(dy + i * VG, g);
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        int best = 0;
+        float mm = v[0][j];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+          if (v[q][j] > mm) {
+            mm = v[q][j];
+            best = q;
+          }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q][j] = q == best ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st<T>(out + offs[q], o[q]);
+    }
+  }
+}
+
+// ---- trilinear x2, align_corners = False:  src = (o + 0.5) / 2 - 0.5 clamped at 0;  i0 = floor(src), i1 = min(i0 + 1,
+//      in - 1), l1 = src - i0  (ATen's area_pixel_compute_source_index).
+__device__ __forceinline__ void half_coord(int o, int in, int& i0, int& i1, float& l0, float& l1) {
+  float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample3d_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int d, int h,
+                                                             int w, int C) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Do = 2 * d, Ho = 2 * h, Wo = 2 * w;
+  const long nvec = (long)N * Do * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    p /= Ho;
+    const int od = (int)(p % Do);
+    const int n = (int)(p / Do);
+    int z0, z1, y0, y1, x0, x1;
+    float lz[2], ly[2], lx[2];
+    half_coord(od, d, z0, z1, lz[0], lz[1]);
+    half_coord(oy, h, y0, y1, ly[0], ly[1]);
+    half_coord(ox, w, x0, x1, lx[0], lx[1]);
+    const int zi[2] = {z0, z1}, yi[2] = {y0, y1}, xi[2] = {x0, x1};
+    const T* b = x + (size_t)n * d * h * w * C + (size_t)cv * VG;
+    float acc[VG];
+#pragma unroll
+    for (int j = 0; j < VG; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v[VG];
+          ld<T>(b + (((size_t)zi[a] * h + yi[bb]) * w + xi[c]) * C, v);
+          const float wgt = lz[a] * ly[bb] * lx[c];
+#pragma unroll
+          for (int j = 0; j < VG; ++j) acc[j] += wgt * v[j];
+        }
+    st<T>(y + i * VG, acc);
+  }
+}
+
+// taps of input coordinate i along one axis (align_corners = False): outputs 2i-1 .. 2i+2 are the only candidates;
+// wt[k] = weight output (2i - 1 + k) gives to i  (0 outside the tensor)
+__device__ __forceinline__ void half_taps(int i, int in, float (&wt)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = 2 * i - 1 + k;
+    float wv = 0.f;
+    if (o >= 0 && o < 2 * in) {
+      int i0, i1;
+      float l0, l1;
+      half_coord(o, in, i0, i1, l0, l1);
+      if (i0 == i) wv += l0;
+      if (i1 == i) wv += l1;
+    }
+    wt[k] = wv;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample3d_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int d, int h,
+                                                             int w, int C) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, Do = 2 * d, Ho = 2 * h, Wo = 2 * w;
+  const long nvec = (long)N * d * h * w * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h);
+    p /= h;
+    const int iz = (int)(p % d);
+    const int n = (int)(p / d);
+    float wz[4], wy[4], wx[4];
+    half_taps(iz, d, wz);
+    half_taps(iy, h, wy);
+    half_taps(ix, w, wx);
+    const T* b = dy + (size_t)n * Do * Ho * Wo * C + (size_t)cv * VG;
+    float acc[VG];
+#pragma unroll
+    for (int j = 0; j < VG; ++j) acc[j] = 0.f;
+    for (int a = 0; a < 4; ++a) {
+      if (wz[a] == 0.f) continue;
+      const int oz = min(max(2 * iz - 1 + a, 0), Do - 1);
+      for (int bb = 0; bb < 4; ++bb) {
+        if (wy[bb] == 0.f) continue;
+        const int oy = min(max(2 * iy - 1 + bb, 0), Ho - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ox = min(max(2 * ix - 1 + c, 0), Wo - 1);
+          float g[VG];
+          ld<T>(b + (((size_t)oz * Ho + oy) * Wo + ox) * C, g);
+          const float wgt = wz[a] * wy[bb] * wx[c];
+#pragma unroll
+          for (int j = 0; j < VG; ++j) acc[j] += wgt * g[j];
+        }
+      }
+    }
+    st<T>(dx + i * VG, acc);
+  }
+}
+
+
+extern "C" int fi_maxpool3d_fwd(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  if ((D & 1) || (H & 1) || (W & 1)) return FI_ERR_SHAPE;
+  hipStream_t st_ = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / vg);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL((maxpool3d_kernel<float, false>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x,
+                       (const float*)nullptr, (float*)y, N, D, H, W, C);
+  else
+    hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, false>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
+                       (const bf16_t*)nullptr, (bf16_t*)y, N, D, H, W, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C,
+                                void* stream) {
+  if (!x || !dy || !dx) return FI_ERR_NULL;
+  if ((D & 1) || (H & 1) || (W & 1)) return FI_ERR_SHAPE;
+  hipStream_t st_ = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / vg);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL((maxpool3d_kernel<float, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x,
+                       (const float*)dy, (float*)dx, N, D, H, W, C);
+  else
+    hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_upsample3d2x_fwd(int dtype, const void* x, void* y, int N, int d, int h, int w, int C, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  hipStream_t st_ = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * 8 * d * h * w * (C / vg);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(upsample3d_fwd_kernel<float>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x, (float*)y,
+                       N, d, h, w, C);
+  else
+    hipLaunchKernelGGL(upsample3d_fwd_kernel<bf16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
+                       (bf16_t*)y, N, d, h, w, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_upsample3d2x_bwd(int dtype, const void* dy, void* dx, int N, int d, int h, int w, int C, void* stream) {
+  if (!dy || !dx) return FI_ERR_NULL;
+  hipStream_t st_ = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * d * h * w * (C / vg);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(upsample3d_bwd_kernel<float>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)dy,
+                       (float*)dx, N, d, h, w, C);
+  else
+    hipLaunchKernelGGL(upsample3d_bwd_kernel<bf16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)dy,
+                       (bf16_t*)dx, N, d, h, w, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}

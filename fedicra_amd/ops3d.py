@@ -1,0 +1,199 @@
+"""3D companions of fedicra_amd.ops for the unet_3D surface (SURVEY.md section 8, row a18;
+/root/reference/code/networks/unet_3D.py:20-94, networks/utils.py:99-123, 260-276).
+
+Volumes are dense NDHWC tensors ``[N, D, H, W, C]`` in the compute dtype, i.e. D consecutive NHWC slices, so the 2D
+kernels of libfedicra_hip.so do the heavy lifting:
+
+* ``Conv3d(3x3x3, pad 1)`` = for each depth tap kd one 3x3 implicit-GEMM launch over the slices that tap reaches,
+  accumulating into the output volume (the centre tap goes last: it covers every slice, so its epilogue sees the
+  finished sums and produces the per-channel statistics);
+* ``InstanceNorm3d(affine=False) + ReLU`` = the fused BN-finalize/apply kernel run per sample (batch statistics of
+  one sample ARE its instance statistics), backward likewise through the BN backward reduce / apply kernels;
+* ``MaxPool3d(2)``, trilinear x2 (align_corners False): fi_maxpool3d_*, fi_upsample3d2x_*;
+* ``Dropout``: the counter-RNG mask of the 2D path (regenerated in backward).
+
+No CPU fallback: everything routes through fedicra_amd._lib.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import ops
+
+
+def _taps(ksize, D):
+    """(kd, output slice range, input slice offset) for every depth tap; the centre tap last."""
+    if ksize == 1:
+        return [(0, 0, D, 0)]
+    return [(kd, max(0, 1 - kd), min(D, D + 1 - kd), kd - 1) for kd in (0, 2, 1)]
+
+
+def _w_taps(weight, dtype, mode):
+    """Conv3d weight [Cout,Cin,kD,kH,kW] -> per depth tap the packed 2D operand ([Cout][kH*kW][Cin] forward,
+    flipped/transposed for dgrad)."""
+    cout, cin, kd, kh, kw = weight.shape
+    out = []
+    for t in range(kd):
+        wk = weight[:, :, t].permute(0, 2, 3, 1).contiguous().float()          # [Cout,kH,kW,Cin] fp32
+        dst = torch.empty(cout * kh * kw * cin, dtype=dtype, device=weight.device)
+        L.pack_weights(wk, dst, cout, kh * kw, cin, mode)
+        out.append(dst)
+    return out
+
+
+class _Conv3d(Function):
+    """y = conv3d(cat(x0, x1)) + bias, optionally followed by InstanceNorm3d(affine=False) + ReLU."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, norm, y_f32):
+        N, D, H, W, _ = x0.shape
+        cout, cin, kd, ksize, _ = weight.shape
+        dev, dt = x0.device, x0.dtype
+        wp = _w_taps(weight, dt, 0)
+        ydt = torch.float32 if (y_f32 and not norm) else dt
+        y = torch.zeros((N, D, H, W, cout), dtype=ydt, device=dev)
+        stats = torch.zeros((N, L.STATS_SLOTS * cout * 2), dtype=torch.float64, device=dev) if norm else None
+        for n in range(N):
+            for t, lo, hi, off in _taps(kd, D):
+                centre = off == 0
+                L.conv2d_fwd(x0[n, lo + off:hi + off], None if x1 is None else x1[n, lo + off:hi + off], wp[t],
+                             bias if centre else None, y[n, lo:hi], None, stats[n] if (norm and centre) else None,
+                             ksize=ksize, acc0=True, y_f32=ydt == torch.float32 and dt != torch.float32)
+        if not norm:
+            ctx.save_for_backward(x0, x1, weight)
+            ctx.norm, ctx.has_bias = False, bias is not None
+            return y
+        z = torch.empty_like(y)
+        coef = torch.empty((N, 4, cout), dtype=torch.float32, device=dev)
+        one, zero = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)        # scratch: no running statistics
+        for n in range(N):
+            L.bn_fused_fwd(y[n], z[n], stats[n], one, zero, rm, rv, None, 0.0, 1e-5, True, coef[n], 0.0, None)
+        ctx.save_for_backward(x0, x1, weight, y, coef)
+        ctx.norm, ctx.has_bias = True, bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if ctx.norm:
+            x0, x1, weight, y, coef = ctx.saved_tensors
+        else:
+            x0, x1, weight = ctx.saved_tensors
+        N, D, H, W, c0 = x0.shape
+        cout, cin, kd, ksize, _ = weight.shape
+        dev, dt = x0.device, x0.dtype
+        dz = dz.contiguous()
+        if ctx.norm:
+            dy = torch.empty_like(y)
+            for n in range(N):
+                sums = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=dev)
+                L.bn_act_bwd_reduce(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, 0.0, None)
+                L.bn_act_bwd_apply(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, True, dy[n], None,
+                                   None, 0.0, None)
+        else:
+            dy = dz if dz.dtype == dt else dz.to(dt)
+        need_x0, need_x1 = ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1]
+        dx0 = dx1 = gw = gb = None
+        taps = _taps(kd, D)
+        if need_x0 or need_x1:
+            wt = _w_taps(weight, dt, 1)
+            d0 = torch.zeros_like(x0)
+            d1 = None if x1 is None else torch.zeros_like(x1)
+            for n in range(N):
+                for t, lo, hi, off in taps:
+                    L.conv2d_fwd(dy[n, lo:hi], None, wt[t], None, d0[n, lo + off:hi + off],
+                                 None if d1 is None else d1[n, lo + off:hi + off], None, ksize=ksize, acc0=True,
+                                 acc1=True, tag="conv_dgrad")
+            dx0 = d0 if need_x0 else None
+            dx1 = d1 if need_x1 else None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gwk = torch.zeros((kd, cout, ksize, ksize, cin), dtype=torch.float32, device=dev)
+            gb = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            for n in range(N):
+                for t, lo, hi, off in taps:
+                    L.conv2d_wgrad(x0[n, lo + off:hi + off], None if x1 is None else x1[n, lo + off:hi + off],
+                                   dy[n, lo:hi], gwk[t], gb if off == 0 else None, ksize=ksize)
+            gw = gwk.permute(1, 4, 0, 2, 3).contiguous()               # [Cout,Cin,kD,kH,kW]
+        return dx0, dx1, gw, gb, None, None
+
+
+class _MaxPool3d(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, D, H, W, Cc = x.shape
+        y = torch.empty((N, D // 2, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.maxpool3d_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.maxpool3d_bwd(x, dy.contiguous(), dx)
+        return dx
+
+
+class _Upsample3d(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, d, h, w, Cc = x.shape
+        y = torch.empty((N, 2 * d, 2 * h, 2 * w, Cc), dtype=x.dtype, device=x.device)
+        L.upsample3d2x_fwd(x, y)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        L.upsample3d2x_bwd(dy.contiguous(), dx)
+        return dx
+
+
+class _Dropout(Function):
+    """Element-wise dropout on a dense channels-last tensor: z = x * mask / (1 - p); backward applies the same
+    (regenerated) mask to the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, owner):
+        C = x.shape[-1]
+        v = x.reshape(-1, 1, 1, C)
+        spec = ops._drop_spec(p, "elem", v.shape[0], 1, 1, C, x.device, owner=owner)
+        one, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+        z = torch.empty_like(v)
+        L.bn_act_fwd(v, one, zero, z, 1.0, spec)
+        ctx.spec, ctx.C = spec, C
+        return z.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        C = ctx.C
+        v = dz.contiguous().reshape(-1, 1, 1, C)
+        one, zero = torch.ones(C, device=dz.device), torch.zeros(C, device=dz.device)
+        out = torch.empty_like(v)
+        L.bn_act_fwd(v, one, zero, out, 1.0, ctx.spec)
+        return out.reshape(dz.shape), None, None
+
+
+def conv3d(x0, x1, conv, norm=False, y_f32=False):
+    """conv: nn.Conv3d (kernel 3 pad 1, or kernel 1).  x1: second input of a channel concatenation or None."""
+    k = conv.kernel_size
+    if not (k[0] == k[1] == k[2] and k[0] in (1, 3) and conv.padding == (k[0] // 2,) * 3 and conv.stride == (1, 1, 1)):
+        raise NotImplementedError("conv3d: only 3x3x3/pad 1 and 1x1x1, stride 1 (all the unet_3D surface uses)")
+    return _Conv3d.apply(x0, x1, conv.weight, conv.bias, bool(norm), bool(y_f32))
+
+
+def maxpool3d(x):
+    return _MaxPool3d.apply(x)
+
+
+def upsample3d2x(x):
+    return _Upsample3d.apply(x)
+
+
+def dropout(x, p, training, owner=None):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), owner)

@@ -161,6 +161,16 @@ int fi_maxpool2_bwd_add(int dtype, const void* x, const void* dy, const void* ad
 int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream);
 int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate, void* stream);
 
+/* 3D surface (unet_3D, /root/reference/code/networks/unet_3D.py:20-94): volumes are dense NDHWC, i.e. D consecutive NHWC
+ * slices -- Conv3d and InstanceNorm3d are run slice-wise through fi_conv2d_* / fi_bn_* by the host mirror.
+ * nn.MaxPool3d(2) (unet_3D.py:35): y[N,D/2,H/2,W/2,C]; backward routes dy to the first maximum in (d,h,w) scan order. */
+int fi_maxpool3d_fwd(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
+int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, void* stream);
+/* nn.Upsample(scale_factor=(2,2,2), mode='trilinear') with align_corners=False (networks/utils.py:264):
+ * [N,d,h,w,C] -> [N,2d,2h,2w,C];  backward = exact adjoint (gather over the 4x4x4 candidate outputs). */
+int fi_upsample3d2x_fwd(int dtype, const void* x, void* y, int N, int d, int h, int w, int C, void* stream);
+int fi_upsample3d2x_bwd(int dtype, const void* dy, void* dx, int N, int d, int h, int w, int C, void* stream);
+
 /* ---------------------------------------------------------------- losses ------------------
  * CrossEntropyLoss(ignore_index) (/root/reference/code/flower_pCE_2D.py:57,124): logits fp32 NHWC
  * [M][C], labels uint8 [M].  acc is fp64 [FI_CE_SLOTS][2] (caller zeroes): workgroups add {sum of -log p[label],

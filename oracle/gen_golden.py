@@ -282,9 +282,47 @@ def g7_ala():
     save("g7_ala.npz", **d)
 
 
+def g9_unet3d():
+    """3D U-Net surface (a18): the reference's own unet_3D(1 -> 2 classes) on a 32^3 volume: eval logits, parameter
+    gradients of a partial cross-entropy, and the state produced by its initialisation under a fixed torch seed."""
+    from networks.unet_3D import unet_3D
+    torch.manual_seed(11)
+    m = unet_3D(n_classes=2, in_channels=1)
+    d = {}
+    d.update(state_checksums(m, "init_seed11/"))
+    seeded_state(m, 2031)
+    rng = np.random.default_rng(909)
+    x = rng.random((1, 1, 32, 32, 32), dtype=np.float32)
+    lab = rng.integers(0, 3, (1, 32, 32, 32)).astype(np.int64)          # 2 = ignore
+    m.eval()                                                            # dropout off; InstanceNorm has no mode
+    xt = torch.from_numpy(x)
+    out = m(xt)
+    d["x"], d["labels"], d["eval_logits"] = x, lab.astype(np.uint8), out.detach().numpy()
+    loss = torch.nn.functional.cross_entropy(out, torch.from_numpy(lab), ignore_index=2)
+    loss.backward()
+    d["loss"] = np.array(loss.item())
+    for k, p in m.named_parameters():
+        d["grad_ck/" + k] = checksum(p.grad)
+    d["grad/final.weight"] = m.final.weight.grad.numpy().copy()
+    d["grad/conv1.conv1.0.weight"] = m.conv1.conv1[0].weight.grad.numpy().copy()
+    d["grad/center.conv2.0.bias"] = m.center.conv2[0].bias.grad.numpy().copy()
+    d["keys"] = np.array(list(m.state_dict().keys()))
+    # a two-sample, 3-channel, 3-class input (different batch / channel plumbing); 32^3 is the smallest volume whose
+    # centre level still has more than one voxel for InstanceNorm.  Inputs are regenerated from the seed by the tests.
+    m3 = unet_3D(n_classes=3, in_channels=3)
+    seeded_state(m3, 2032)
+    m3.eval()
+    x3 = np.random.default_rng(910).random((2, 3, 32, 32, 32), dtype=np.float32)
+    with torch.no_grad():
+        o3 = m3(torch.from_numpy(x3))
+    d["eval_logits3_ck"] = checksum(o3)
+    d["eval_logits3_block"] = o3[:, :, 10:14, 8:16, 8:16].numpy().copy()
+    save("g9_unet3d.npz", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d"]
     for w in which:
         globals()[w]()

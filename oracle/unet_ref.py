@@ -252,8 +252,8 @@ def seeded_state(module: nn.Module, seed: int = 2022, extra: dict | None = None)
                 v = rng.uniform(0.5, 1.5, t.shape)
             elif name.endswith("running_mean"):
                 v = rng.uniform(-0.1, 0.1, t.shape)
-            elif t.dim() == 4:
-                b = 1.0 / np.sqrt(t.shape[1] * t.shape[2] * t.shape[3])
+            elif t.dim() in (4, 5):                       # Conv2d / Conv3d weights
+                b = 1.0 / np.sqrt(float(np.prod(t.shape[1:])))
                 v = rng.uniform(-b, b, t.shape) * 1.7
             elif name.endswith("weight"):
                 v = rng.uniform(0.5, 1.5, t.shape)

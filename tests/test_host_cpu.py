@@ -192,3 +192,19 @@ def test_weighted_allreduce_gloo_multiprocess(tmp_path, world):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_unet3d_surface_keys_and_init_match_reference_golden(golden):
+    """a18 module surface: same state_dict keys as the reference's unet_3D and, under the same torch seed, the same
+    initial state (the constructors consume the RNG in the reference's order)."""
+    from fedicra_amd.networks.net_factory_3d import net_factory_3d
+    from fedicra_amd.networks.unet_3D import unet_3D
+    from helpers import assert_ck
+    g = golden("g9_unet3d.npz")
+    torch.manual_seed(11)
+    m = unet_3D(n_classes=2, in_channels=1)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    for k, v in m.state_dict().items():
+        assert_ck(v.double(), g["init_seed11/" + k], what=k)
+    with pytest.raises(NotImplementedError):
+        net_factory_3d("vnet")
