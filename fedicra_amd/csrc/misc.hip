@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, 
                                                          float* __restrict__ m, float* __restrict__ v, long n,
                                                          const float* __restrict__ hyper, float beta1, float beta2,
                                                          float eps, bf16_t* __restrict__ shadow) {
+  if (hyper[0] < 0.f) return;   // fi_amp_guard: the unscaled gradients held an inf/NaN -> this step is skipped
   const float decay = hyper[1], step = hyper[2], bc2s = hyper[3];
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -253,6 +254,66 @@ extern "C" int fi_adamw_step(float* p, const float* g, float* m, float* v, long 
   if (n <= 0) return 0;
   hipLaunchKernelGGL(adamw_step_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                      hyper, beta1, beta2, eps, (bf16_t*)shadow_bf16);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic loss scaling (torch.cuda.amp.GradScaler semantics; flower_pCE_2D.py:47-48,143-146), all state on the device
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amp_unscale_kernel(float* __restrict__ g, long n, const float* __restrict__ scale,
+                                                          float* found_inf) {
+  const float inv = 1.0f / scale[0];
+  bool bad = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = g[i] * inv;
+    bad |= !isfinite(v);
+    g[i] = v;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;     // every writer stores the same value
+}
+__global__ void amp_guard_kernel(int* step, float* hyper, const float* found_inf) {
+  if (found_inf[0] != 0.f) {
+    step[0] -= 1;            // GradScaler.step() does not call optimizer.step(): the step count does not advance
+    hyper[0] = -1.f;         // makes fi_adamw_step a no-op
+  }
+}
+__global__ void amp_update_kernel(float* scale, int* tracker, float* found_inf, float growth, float backoff,
+                                  int interval) {
+  if (found_inf[0] != 0.f) {
+    scale[0] *= backoff;
+    tracker[0] = 0;
+  } else {
+    const int t = tracker[0] + 1;
+    if (t == interval) {
+      scale[0] *= growth;
+      tracker[0] = 0;
+    } else {
+      tracker[0] = t;
+    }
+  }
+  found_inf[0] = 0.f;
+}
+
+extern "C" int fi_amp_unscale(float* grads, long n, const float* scale, float* found_inf, void* stream) {
+  if (!grads || !scale || !found_inf) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(amp_unscale_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, grads, n, scale,
+                     found_inf);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_amp_guard(int* step, float* hyper, const float* found_inf, void* stream) {
+  if (!step || !hyper || !found_inf) return FI_ERR_NULL;
+  hipLaunchKernelGGL(amp_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, hyper, found_inf);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_amp_update(float* scale, int* growth_tracker, float* found_inf, float growth_factor,
+                             float backoff_factor, int growth_interval, void* stream) {
+  if (!scale || !growth_tracker || !found_inf) return FI_ERR_NULL;
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale, growth_tracker, found_inf,
+                     growth_factor, backoff_factor, growth_interval);
   FI_CHECK_LAUNCH();
   return 0;
 }

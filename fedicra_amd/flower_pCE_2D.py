@@ -41,6 +41,11 @@ class MyClient(BaseClient):
     def __init__(self, args, model, trainloader, valloader, amp=False):
         super().__init__(args, model, trainloader, valloader)
         self.amp = amp
+        if self.amp:                                         # flower_pCE_2D.py:46-48
+            from .amp import GradScaler
+            from .networks.unet import set_compute_dtype
+            self.scaler = GradScaler()
+            set_compute_dtype(model.model, "bf16")           # autocast(enabled=True): reduced-precision compute (amp.py)
         self.best_performance = 0.0
         self.use_graph = bool(getattr(args, "use_graph", False))
         self.optimizer = None
@@ -105,8 +110,13 @@ class MyClient(BaseClient):
                 acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], _heatmaps[-1].detach())
             loss_lc = -acc / (args.min_num_clients - 1)
             loss = torch.add(loss, loss_lc, alpha=args.alpha)
-        loss.backward()
-        opt.step()
+        if self.amp:                                         # :143-146
+            self.scaler.scale(loss).backward()
+            self.scaler.step(opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            opt.step()
         opt.advance_lr()
         rec.loss, rec.loss_ce, rec.loss_lc, rec.logits = loss.detach(), loss_ce.detach(), \
             (None if loss_lc is None else loss_lc.detach()), logits.detach()

@@ -76,6 +76,11 @@ class FusedAdamW:
         return g
 
     def step(self):
+        self.step_scaled(None, None)
+
+    def step_scaled(self, scale, found_inf):
+        """step(); with (scale, found_inf) device scalars the gradients are first divided by `scale` and the update is
+        skipped -- moments, parameters and step count untouched -- when any of them is inf/NaN (amp.GradScaler.step)."""
         from . import ops
         ops.flush_wgrad()                    # no-op unless a backward's deferred wgrad reduction is still pending
         params = dict(self.model.named_parameters())
@@ -84,11 +89,15 @@ class FusedAdamW:
             return
         gi, ranges = self._group_for(active)
         P, G = self.model.flat_params, self.model.flat_grads
+        if scale is not None:
+            for s, e in ranges:
+                L.amp_unscale(G[s:e], scale, found_inf)
         L.adamw_hyper(self.steps[gi:gi + 1], self.hyper[gi], self.lr_state, self.betas[0], self.betas[1], self.wd)
+        if scale is not None:
+            L.amp_guard(self.steps[gi:gi + 1], self.hyper[gi], found_inf)
         for s, e in ranges:
             L.adamw_step(P[s:e], G[s:e], self.m[s:e], self.v[s:e], self.hyper[gi], self.betas[0], self.betas[1],
                          self.eps, None if self.shadow is None else self.shadow[s:e])
-        from . import ops
         ops.bump_weights_epoch()            # raw-pointer write: invalidate the conv operand packs
 
     def advance_lr(self):

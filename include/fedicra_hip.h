@@ -212,9 +212,23 @@ int fi_dice_counts(const float* logits, const uint8_t* gt, long M, int C, long l
  * fi_lr_poly_advance: ++iter[0]; lr_state[0] = base_lr*(1 - iter/max_iter)^0.9 (flower_pCE_2D.py:154-157). */
 int fi_adamw_hyper(int* step, float* hyper, const double* lr_state, float beta1, float beta2, float wd, void* stream);
 int fi_lr_poly_advance(int* iter, double* lr_state, double base_lr, double max_iter, void* stream);
-/* p, m, v updated in place over [0,n); g read.  shadow (bf16, may be NULL) receives a bf16 copy of p. */
+/* p, m, v updated in place over [0,n); g read.  shadow (bf16, may be NULL) receives a bf16 copy of p.
+ * A negative hyper[0] makes the call a no-op (see fi_amp_guard). */
 int fi_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
                   float eps, void* shadow_bf16, void* stream);
+
+/* Dynamic loss scaling = torch.cuda.amp.GradScaler (`--amp 1`: /root/reference/code/flower_pCE_2D.py:47-48,143-146,
+ * flower_common.py:466-468,576-584), with every scalar on the device (hipGraph-capturable):
+ *   scale (fp32[1]), growth_tracker (int32[1]), found_inf (fp32[1], 0 or 1).
+ * fi_amp_unscale: grads[i] *= 1/scale; found_inf = 1 when any result is inf/NaN        (scaler.unscale_)
+ * fi_amp_guard  : after fi_adamw_hyper -- when found_inf, undo the step-count increment and set hyper[0] = -1 so that
+ *                 fi_adamw_step does nothing                                            (scaler.step skips optimizer.step)
+ * fi_amp_update : found_inf ? (scale *= backoff, tracker = 0) : (++tracker == interval ? scale *= growth, tracker = 0);
+ *                 then found_inf = 0                                                    (scaler.update) */
+int fi_amp_unscale(float* grads, long n, const float* scale, float* found_inf, void* stream);
+int fi_amp_guard(int* step, float* hyper, const float* found_inf, void* stream);
+int fi_amp_update(float* scale, int* growth_tracker, float* found_inf, float growth_factor, float backoff_factor,
+                  int growth_interval, void* stream);
 
 /* ---------------------------------------------------------------- aggregation helpers ------
  * flwr `aggregate`: w = reduce(add, [w_k * n_k]) / total.

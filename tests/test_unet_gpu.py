@@ -459,3 +459,61 @@ def test_evaluate_dice_matches_oracle():
             tot += eval_case(pred, b["label"][0].numpy(), 2)[0]
     assert abs(met["val_mean_dice"] - tot / 6) < 1e-4, (met["val_mean_dice"], tot / 6)
     assert abs(met["val_1_dice"] - tot / 6) < 1e-4
+
+
+def test_amp_gradscaler_matches_reference_state_machine():
+    """`--amp 1` (a19): loss scaling by a power of two is exact, so a clean AMP run reproduces the plain bf16 run; an
+    inf/NaN gradient skips the optimizer step (parameters, moments and step count untouched), halves the scale and
+    clears the flag -- torch.cuda.amp.GradScaler's state machine, held on the device."""
+    from fedicra_amd import ops
+    from fedicra_amd.amp import GradScaler
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from helpers import loader
+    batches = loader(2, 4, 64, cid=0)
+    finals, losses = [], []
+    for amp in (False, True):
+        for use_graph in ((False,) if not amp else (False, True)):
+            args = _args(use_graph=use_graph, iters=4, amp=int(amp))
+            ops.manual_seed(1)
+            net = _mk(UNet, 1, 2, dtype="bf16")
+            client = MyClient(args, MyModel(args, net, batches, batches), batches, batches, amp=amp)
+            client._train({"iter_global": 4, "iters": 4, "eval_iters": 8, "batch_size": 4, "stage": "fit"})
+            finals.append(net.flat_state.clone())
+            losses.append(list(client.last_losses))
+            if amp:
+                assert client.scaler.get_scale() == 65536.0 and int(client.scaler._tracker.item()) == 4
+                # last_losses holds the UNscaled loss like the reference's logging
+    assert np.allclose(losses[0], losses[1], rtol=0, atol=2e-3), (losses[0], losses[1])
+    assert np.allclose(losses[0][:2], losses[1][:2], atol=1e-5)
+    assert np.allclose(losses[1], losses[2], atol=5e-3)
+    # ---- skipped step
+    from fedicra_amd.optim import FusedAdamW
+    net = _mk(UNet, 1, 2, dtype="bf16").train()
+    opt = FusedAdamW(net, lr=0.01, base_lr=0.01, max_iterations=100)
+    sc = GradScaler(init_scale=1024.0, growth_interval=2)
+    b = batches[0]
+    x, y = b["image"].unsqueeze(1).to(DEV), b["label"].to(DEV)
+
+    def one_step(poison):
+        ops.begin_iteration(x.device)
+        opt.zero_grad()
+        loss = ops.ce_loss(net(x)[0].permute(0, 2, 3, 1), y, 2)
+        sc.scale(loss).backward()
+        if poison:
+            ops.flush_wgrad()
+            net.flat_grads[5] = float("inf")
+        sc.step(opt)
+        sc.update()
+
+    one_step(False)
+    assert sc.get_scale() == 1024.0 and int(opt.steps[0].item()) == 1
+    before = (net.flat_params.clone(), opt.m.clone(), opt.v.clone())
+    one_step(True)
+    assert torch.equal(net.flat_params, before[0]) and torch.equal(opt.m, before[1]) and torch.equal(opt.v, before[2])
+    assert int(opt.steps[0].item()) == 1 and sc.get_scale() == 512.0 and float(sc._found_inf.item()) == 0.0
+    one_step(False)
+    one_step(False)                                       # two clean steps = growth_interval -> scale doubles
+    assert int(opt.steps[0].item()) == 3 and sc.get_scale() == 1024.0
+    assert not torch.equal(net.flat_params, before[0])
