@@ -25,7 +25,7 @@ EXPORTS = [
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
     "fi_pdice_bwd", "fi_dice_counts", "fi_adamw_hyper",
-    "fi_lr_poly_advance", "fi_adamw_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
+    "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
 
@@ -433,6 +433,11 @@ def adamw_step(p, g, m, v, hyper, beta1, beta2, eps, shadow=None):
         _chk(lib().fi_adamw_step(ptr(_dev(p)), ptr(g), ptr(m), ptr(v), C.c_long(p.numel()), ptr(hyper),
                                  C.c_float(beta1), C.c_float(beta2), C.c_float(eps), ptr(shadow), stream()),
              "fi_adamw_step")
+
+
+def sgd_step(p, g, buf, lr_state, momentum, wd, skip_hyper=None):
+    _chk(lib().fi_sgd_step(ptr(_dev(p)), ptr(g), ptr(buf), C.c_long(p.numel()), ptr(lr_state), C.c_float(momentum),
+                           C.c_float(wd), ptr(skip_hyper), stream()), "fi_sgd_step")
 
 
 def amp_unscale(grads, scale_t, found_inf):

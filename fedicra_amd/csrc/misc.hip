@@ -259,6 +259,33 @@ extern "C" int fi_adamw_step(float* p, const float* g, float* m, float* v, long 
 }
 
 // ------------------------------------------------------------------------------------------------
+// SGD with momentum and (coupled) weight decay: the single-site trainer's optimizer
+// (/root/reference/code/Unet_pCE.py:88-89: SGD(lr, momentum=0.9, weight_decay=1e-4), dampening 0, no nesterov)
+//   g' = g + wd*p;  buf = momentum*buf + g'  (buf starts at 0, which reproduces torch's first-step buf = g');  p -= lr*buf
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ buf, long n, const double* lr_state,
+                                                       float momentum, float wd, const float* hyper) {
+  if (hyper && hyper[0] < 0.f) return;          // fi_amp_guard convention: skipped step
+  const float lr = (float)lr_state[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] + wd * p[i];
+    const float b = momentum * buf[i] + gi;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+extern "C" int fi_sgd_step(float* p, const float* g, float* momentum_buf, long n, const double* lr_state, float momentum,
+                           float weight_decay, const float* skip_hyper, void* stream) {
+  if (!p || !g || !momentum_buf || !lr_state) return FI_ERR_NULL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf, n,
+                     lr_state, momentum, weight_decay, skip_hyper);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // dynamic loss scaling (torch.cuda.amp.GradScaler semantics; flower_pCE_2D.py:47-48,143-146), all state on the device
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void amp_unscale_kernel(float* __restrict__ g, long n, const float* __restrict__ scale,

@@ -103,3 +103,54 @@ class FusedAdamW:
     def advance_lr(self):
         """lr <- base_lr * (1 - iter/max_iterations)^0.9 with iter incremented first (flower_pCE_2D.py:150-157)."""
         L.lr_poly_advance(self.iter, self.lr_state, self.base_lr, float(self.max_iterations))
+
+
+class FusedSGD:
+    """``torch.optim.SGD(params, lr, momentum=0.9, weight_decay=1e-4)`` of the single-site trainer
+    (/root/reference/code/Unet_pCE.py:88-89) over the flat parameter buffer, same device-resident LR / iteration state
+    and interface as FusedAdamW (zero_grad / step / step_scaled / advance_lr)."""
+
+    def __init__(self, model, lr, base_lr=None, max_iterations=None, momentum=0.9, weight_decay=1e-4):
+        self.model, self.momentum, self.wd = model, momentum, weight_decay
+        self.base_lr = lr if base_lr is None else base_lr
+        self.max_iterations = max_iterations
+        dev = model.flat_params.device
+        self.buf = torch.zeros(model.flat_params.numel(), dtype=torch.float32, device=dev)
+        self.lr_state = torch.tensor([lr], dtype=torch.float64, device=dev)
+        self.iter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)        # [0] < 0: skipped step (amp)
+        self._step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._names = [n_ for n_, _ in model.named_parameters()]
+
+    def set_lr(self, lr: float, current_iter: int = 0):
+        self.lr_state.fill_(lr)
+        self.iter.fill_(int(current_iter))
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.model.zero_grad(set_to_none)
+
+    def step(self):
+        self.step_scaled(None, None)
+
+    def step_scaled(self, scale, found_inf):
+        from . import ops
+        ops.flush_wgrad()
+        params = dict(self.model.named_parameters())
+        active = [n for n in self._names if params[n].grad is not None]
+        if not active:
+            return
+        ranges = self.model.param_ranges(tuple(active))
+        P, G = self.model.flat_params, self.model.flat_grads
+        skip = None
+        if scale is not None:
+            for s, e in ranges:
+                L.amp_unscale(G[s:e], scale, found_inf)
+            self._hyper.zero_()
+            L.amp_guard(self._step, self._hyper, found_inf)
+            skip = self._hyper
+        for s, e in ranges:
+            L.sgd_step(P[s:e], G[s:e], self.buf[s:e], self.lr_state, self.momentum, self.wd, skip)
+        ops.bump_weights_epoch()
+
+    def advance_lr(self):
+        L.lr_poly_advance(self.iter, self.lr_state, self.base_lr, float(self.max_iterations))

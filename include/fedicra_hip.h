@@ -217,6 +217,12 @@ int fi_lr_poly_advance(int* iter, double* lr_state, double base_lr, double max_i
 int fi_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
                   float eps, void* shadow_bf16, void* stream);
 
+/* torch.optim.SGD(lr, momentum, weight_decay) of the single-site trainer (/root/reference/code/Unet_pCE.py:88-89):
+ * g' = g + wd*p; buf = momentum*buf + g' (buf zero-initialised); p -= lr_state[0]*buf.  skip_hyper (may be NULL): a
+ * negative skip_hyper[0] makes the call a no-op (fi_amp_guard). */
+int fi_sgd_step(float* p, const float* g, float* momentum_buf, long n, const double* lr_state, float momentum,
+                float weight_decay, const float* skip_hyper, void* stream);
+
 /* Dynamic loss scaling = torch.cuda.amp.GradScaler (`--amp 1`: /root/reference/code/flower_pCE_2D.py:47-48,143-146,
  * flower_common.py:466-468,576-584), with every scalar on the device (hipGraph-capturable):
  *   scale (fp32[1]), growth_tracker (int32[1]), found_inf (fp32[1], 0 or 1).

@@ -517,3 +517,52 @@ def test_amp_gradscaler_matches_reference_state_machine():
     one_step(False)                                       # two clean steps = growth_interval -> scale doubles
     assert int(opt.steps[0].item()) == 3 and sc.get_scale() == 1024.0
     assert not torch.equal(net.flat_params, before[0])
+
+
+def test_single_site_trainer_sgd_matches_torch_loop():
+    """Unet_pCE.train (a15 single-site variant): SGD(momentum 0.9, wd 1e-4), pCE, the trainer's one-step-behind poly
+    LR -- against the same loop written with torch.optim.SGD on the CPU oracle network, dropout masks pinned."""
+    from fedicra_amd import ops
+    from fedicra_amd.Unet_pCE import train
+    from fedicra_amd.networks.unet import UNet
+    from oracle.losses_ref import pce_loss
+    from oracle.unet_ref import RefUNet, seeded_state
+    from helpers import loader
+    batches = loader(2, 4, 64, cid=0)
+    args = _args(base_lr=0.03, max_iterations=4, in_chns=1)
+    # oracle loop
+    ref = RefUNet(1, 2)
+    seeded_state(ref, 2022)
+    ref.train()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.03, momentum=0.9, weight_decay=0.0001)
+    torch.manual_seed(3)
+    ref_loss, it = [], 0
+    for _ in range(3):
+        for b in batches:
+            if it >= 4:
+                break
+            loss = pce_loss(ref(b["image"].unsqueeze(1))[0], b["label"], 2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            lr_ = 0.03 * (1.0 - it / 4) ** 0.9
+            for g in opt.param_groups:
+                g["lr"] = lr_
+            it += 1
+            ref_loss.append(loss.item())
+    # HIP
+    net = _mk(UNet, 1, 2)
+    ops.set_dropout_mask_provider(_mask_provider())
+    try:
+        torch.manual_seed(3)
+        out = train(args, trainloader=batches, valloader=None, model=net)
+    finally:
+        ops.set_dropout_mask_provider(None)
+    print("ref", ref_loss, "hip", out["loss"])
+    assert len(out["loss"]) == 4
+    assert out["lr"] == [0.03 * (1.0 - i / 4) ** 0.9 for i in range(4)]
+    errs = [abs(a - b) for a, b in zip(out["loss"], ref_loss)]
+    assert errs[0] < 1e-5 and errs[1] < 5e-4 and max(errs) < 1e-2, errs
+    w_ref = ref.state_dict()["decoder.out_conv.weight"]
+    w_hip = net.state_dict()["decoder.out_conv.weight"].cpu()
+    assert (w_hip - w_ref).abs().max().item() < 2e-3
