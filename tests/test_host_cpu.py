@@ -208,3 +208,49 @@ def test_unet3d_surface_keys_and_init_match_reference_golden(golden):
         assert_ck(v.double(), g["init_seed11/" + k], what=k)
     with pytest.raises(NotImplementedError):
         net_factory_3d("vnet")
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Argument validation happens before any launch: NULL pointers, empty / ragged shapes, channel counts the vector
+    kernels cannot serve and unknown dtypes come back as FI_ERR_* codes (nothing is thrown across the ABI, nothing is
+    launched -- so this runs on the CPU-only box too)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "fedicra_amd", "libfedicra_hip.so"))
+
+    class FiConv(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int) for n in ("dtype", "N", "H", "W", "ksize", "c0", "c1", "co0", "co1", "accumulate0",
+                                                "accumulate1", "y_f32")]
+
+    class FiBnAct(ctypes.Structure):
+        _fields_ = [("dtype", ctypes.c_int), ("pixels", ctypes.c_long), ("C", ctypes.c_int), ("hw", ctypes.c_int),
+                    ("slope", ctypes.c_float), ("drop_mode", ctypes.c_int), ("drop_p", ctypes.c_float),
+                    ("seed", ctypes.c_uint64), ("mask", ctypes.c_void_p), ("seed_offset", ctypes.c_void_p)]
+    ERR_DTYPE, ERR_SHAPE, ERR_UNSUPPORTED, ERR_NULL = -1, -2, -3, -4
+    p = ctypes.c_void_p(0x1000)                      # never dereferenced: every call below fails validation first
+    ok = FiConv(0, 1, 8, 8, 3, 16, 0, 16, 0, 0, 0, 0)
+    assert lib.fi_conv2d_fwd(ctypes.byref(ok), None, None, p, None, p, None, None, None) == ERR_NULL
+    assert lib.fi_conv2d_fwd(ctypes.byref(FiConv(7, 1, 8, 8, 3, 16, 0, 16, 0, 0, 0, 0)), p, None, p, None, p, None, None,
+                             None) == ERR_DTYPE
+    assert lib.fi_conv2d_fwd(ctypes.byref(FiConv(0, 1, 8, 8, 5, 16, 0, 16, 0, 0, 0, 0)), p, None, p, None, p, None, None,
+                             None) == ERR_UNSUPPORTED                                     # 5x5 kernels
+    for bad in (FiConv(0, 0, 8, 8, 3, 16, 0, 16, 0, 0, 0, 0), FiConv(0, 1, 0, 8, 3, 16, 0, 16, 0, 0, 0, 0),
+                FiConv(0, 1, 8, 8, 3, 0, 0, 16, 0, 0, 0, 0), FiConv(0, 1, 8, 8, 3, 16, 0, 0, 0, 0, 0, 0)):
+        assert lib.fi_conv2d_fwd(ctypes.byref(bad), p, None, p, None, p, None, None, None) == ERR_SHAPE   # empty inputs
+    assert lib.fi_conv2d_fwd(ctypes.byref(FiConv(0, 1, 8, 8, 3, 16, 8, 16, 0, 0, 0, 0)), p, None, p, None, p, None, None,
+                             None) == ERR_NULL                                            # c1 > 0 without x1
+    lib.fi_conv2d_wgrad_workspace.restype = ctypes.c_long
+    assert lib.fi_conv2d_wgrad_workspace(ctypes.byref(ok)) > 0
+    assert lib.fi_conv2d_wgrad(ctypes.byref(ok), p, None, p, p, None, p, ctypes.c_long(16), None) == ERR_SHAPE  # workspace too small
+    assert lib.fi_maxpool2_fwd(0, p, p, 1, 7, 8, 16, None) == ERR_SHAPE                    # odd height
+    assert lib.fi_maxpool3d_fwd(0, p, p, 1, 4, 4, 5, 8, None) == ERR_SHAPE
+    assert lib.fi_maxpool2_fwd(0, p, p, 1, 8, 8, 6, None) == ERR_SHAPE                     # C not a whole 16-byte vector
+    assert lib.fi_upsample2x_fwd(1, p, p, 1, 4, 4, 12, None) == ERR_SHAPE
+    assert lib.fi_upsample3d2x_fwd(3, p, p, 1, 2, 2, 2, 8, None) == ERR_DTYPE
+    bn = FiBnAct(1, 64, 24, 64, 0.01, 0, 0.0, 0, None, None)                               # 24 channels: 3 vectors, 256 % 3 != 0
+    assert lib.fi_bn_act_fwd(ctypes.byref(bn), p, p, p, p, None) == ERR_SHAPE
+    assert lib.fi_bn_act_bwd_reduce(ctypes.byref(bn), p, p, p, p, p, p, None, None) == ERR_NULL
+    assert lib.fi_ce_fwd(p, p, ctypes.c_long(64), 9, 9, p, None) == ERR_SHAPE              # > 8 classes
+    assert lib.fi_ce_fwd(None, p, ctypes.c_long(64), 2, 2, p, None) == ERR_NULL
+    assert lib.fi_adamw_step(p, p, p, p, ctypes.c_long(0), p, ctypes.c_float(0.9), ctypes.c_float(0.999),
+                             ctypes.c_float(1e-8), None, None) == 0                        # empty range: no-op
+    assert lib.fi_wgrad_reduce_multi(None, 3, 10, None) == ERR_NULL
+    assert lib.fi_wgrad_reduce_multi(p, 0, 0, None) == 0
