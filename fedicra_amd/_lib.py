@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -416,6 +416,17 @@ def pdice_bwd(probs, labels, ignore_index, acc, weight, gscale, dprobs):
 def dice_counts(logits, gt, counts):
     M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
     _chk(lib().fi_dice_counts(ptr(logits), ptr(gt), C.c_long(M), Cc, ptr(counts), stream()), "fi_dice_counts")
+
+
+def seg_borders(logits_hwc, gt_u8, k, pred_list, gt_list, counts):
+    H, W, Cc = _dev(logits_hwc).shape
+    _chk(lib().fi_seg_borders(ptr(logits_hwc), ptr(gt_u8), H, W, Cc, int(k), ptr(pred_list), ptr(gt_list), ptr(counts),
+                              stream()), "fi_seg_borders")
+
+
+def surface_distances(from_list, to_list, counts, from_index, to_index, W, out):
+    _chk(lib().fi_surface_distances(ptr(_dev(from_list)), ptr(to_list), ptr(counts), int(from_index), int(to_index),
+                                    int(W), int(from_list.numel()), ptr(out), stream()), "fi_surface_distances")
 
 
 def adamw_hyper(step, hyper, lr_state, beta1, beta2, wd):

@@ -190,6 +190,109 @@ extern "C" int fi_dice_counts(const float* logits, const uint8_t* gt, long M, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Surface distances for the 95th-percentile Hausdorff distance (medpy.metric.binary.hd95, val_2D.py:14):
+//   border(m) = m AND NOT erode(m) with the 4-neighbourhood cross (connectivity 1; outside the image counts as 0),
+//   d(a -> B) = Euclidean distance from border pixel a of one mask to the nearest border pixel of the other.
+// fi_seg_borders lists the border pixels of the prediction (argmax of the logits) and of the ground truth for one
+// foreground class (class 1: label == 1; classes >= 2: label >= 1, val_2D.py:66-74); fi_surface_distances fills in the
+// distances by exhaustive search (exact: integer squared distances, one fp64 square root).  The percentile itself is
+// taken on the host from the returned distances.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool seg_is(const float* z, int C, int k) {
+  int best = 0;
+  float mx = z[0];
+  for (int c = 1; c < C; ++c)
+    if (z[c] > mx) {
+      mx = z[c];
+      best = c;
+    }
+  return k == 1 ? best == 1 : best >= 1;
+}
+__global__ __launch_bounds__(256) void seg_borders_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ gt,
+                                                          int H, int W, int C, int k, int* __restrict__ plist,
+                                                          int* __restrict__ glist, int* counts) {
+  const long M = (long)H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+    const int yy = (int)(i / W), xx = (int)(i % W);
+    const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
+    if (seg_is(logits + i * C, C, k)) {
+      bool inner = true;
+      for (int q = 0; q < 4; ++q) {
+        const int y2 = yy + dy[q], x2 = xx + dx[q];
+        inner = inner && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W && seg_is(logits + ((long)y2 * W + x2) * C, C, k);
+      }
+      if (!inner) plist[atomicAdd(&counts[0], 1)] = (int)i;
+    }
+    const int g = gt[i];
+    if (k == 1 ? g == 1 : g >= 1) {
+      bool inner = true;
+      for (int q = 0; q < 4; ++q) {
+        const int y2 = yy + dy[q], x2 = xx + dx[q];
+        bool on = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+        if (on) {
+          const int g2 = gt[(long)y2 * W + x2];
+          on = k == 1 ? g2 == 1 : g2 >= 1;
+        }
+        inner = inner && on;
+      }
+      if (!inner) glist[atomicAdd(&counts[1], 1)] = (int)i;
+    }
+  }
+}
+// one workgroup per CHUNK of 256 source pixels; the other list streams through LDS in tiles of 1024
+__global__ __launch_bounds__(256) void surface_dist_kernel(const int* __restrict__ a, const int* __restrict__ b,
+                                                           const int* counts, int ia, int ib, int W,
+                                                           double* __restrict__ out) {
+  __shared__ int bx[1024], by[1024];
+  const int na = counts[ia], nb = counts[ib];
+  for (int base = blockIdx.x * 256; base < na; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    int ax = 0, ay = 0;
+    if (i < na) {
+      ax = a[i] % W;
+      ay = a[i] / W;
+    }
+    long best = 0x7fffffffffffffffL;
+    for (int t0 = 0; t0 < nb; t0 += 1024) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < 1024; t += 256) {
+        const int j = t0 + t;
+        const int v = j < nb ? b[j] : b[0];
+        bx[t] = v % W;
+        by[t] = v / W;
+      }
+      __syncthreads();
+      const int lim = min(1024, nb - t0);
+      for (int t = 0; t < lim; ++t) {
+        const long ddx = ax - bx[t], ddy = ay - by[t];
+        const long d2 = ddx * ddx + ddy * ddy;
+        best = d2 < best ? d2 : best;
+      }
+    }
+    if (i < na) out[i] = nb > 0 ? sqrt((double)best) : 0.0;
+  }
+}
+
+extern "C" int fi_seg_borders(const float* logits, const uint8_t* gt, int H, int W, int C, int k, int* pred_list,
+                              int* gt_list, int* counts, void* stream) {
+  if (!logits || !gt || !pred_list || !gt_list || !counts) return FI_ERR_NULL;
+  if (C < 2 || C > FI_MAX_CLASSES || k < 1 || k >= C || H < 1 || W < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(seg_borders_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, logits, gt, H,
+                     W, C, k, pred_list, gt_list, counts);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_surface_distances(const int* from_list, const int* to_list, const int* counts, int from_index,
+                                    int to_index, int W, int max_from, double* out, void* stream) {
+  if (!from_list || !to_list || !counts || !out) return FI_ERR_NULL;
+  if (W < 1 || max_from < 1 || (from_index | to_index) & ~1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(surface_dist_kernel, dim3(grid_for(max_from, 256)), dim3(256), 0, (hipStream_t)stream, from_list,
+                     to_list, counts, from_index, to_index, W, out);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // AdamW
 // ------------------------------------------------------------------------------------------------
 __global__ void adamw_hyper_kernel(int* step, float* hyper, const double* lr_state, float beta1, float beta2,

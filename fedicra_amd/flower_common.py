@@ -71,9 +71,39 @@ def dice_table(logits_nchw_view, labels_u8, classes):
     return counts
 
 
-def metrics_from_counts(tp, npred, ngt, total):
-    """The count-based medpy metrics of val_2D.py:13-19 for ONE image/class; hd95 needs a distance
-    transform and is reported as NaN (out of scope)."""
+def hd95_table(logits_nchw_view, labels_u8, classes):
+    """medpy.metric.binary.hd95 (val_2D.py:14) per image and foreground class -> float64 [n, C-1].
+
+    The border extraction and the nearest-border search run on the device (fi_seg_borders / fi_surface_distances,
+    exact); numpy takes the 95th percentile of the two directed distance sets, as medpy does.  NaN where the prediction
+    or the ground truth has no pixel of the class (medpy raises there; the reference only guards the empty prediction)."""
+    lg = logits_nchw_view.permute(0, 2, 3, 1)
+    if not lg.is_contiguous() or lg.dtype != torch.float32:
+        lg = lg.contiguous().float()
+    n, H, W, _ = lg.shape
+    dev = lg.device
+    out = np.full((n, classes - 1), np.nan)
+    plist = torch.empty(H * W, dtype=torch.int32, device=dev)
+    glist = torch.empty(H * W, dtype=torch.int32, device=dev)
+    d_pg = torch.empty(H * W, dtype=torch.float64, device=dev)
+    d_gp = torch.empty(H * W, dtype=torch.float64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    for i in range(n):
+        for k in range(1, classes):
+            counts.zero_()
+            L.seg_borders(lg[i], labels_u8[i], k, plist, glist, counts)
+            L.surface_distances(plist, glist, counts, 0, 1, W, d_pg)
+            L.surface_distances(glist, plist, counts, 1, 0, W, d_gp)
+            n_p, n_g = (int(v) for v in counts.cpu())
+            if n_p == 0 or n_g == 0:
+                continue
+            sds = np.concatenate([d_pg[:n_p].cpu().numpy(), d_gp[:n_g].cpu().numpy()])
+            out[i, k - 1] = np.percentile(sds, 95)
+    return out
+
+
+def metrics_from_counts(tp, npred, ngt, total, hd95=float("nan")):
+    """The medpy metrics of val_2D.py:13-19 for ONE image/class from its integer counts (+ hd95 from hd95_table)."""
     if npred == 0:                                        # val_2D.py:12,21-22
         return [0.0] * 7
     fp, fn = npred - tp, ngt - tp
@@ -85,7 +115,7 @@ def metrics_from_counts(tp, npred, ngt, total):
     jc = tp / float(union) if union else 0.0
     spec = tn / float(tn + fp) if (tn + fp) else 0.0
     ravd = (npred - ngt) / float(ngt) if ngt else float("nan")
-    return [dice, float("nan"), recall, precision, jc, spec, ravd]
+    return [dice, float(hd95), recall, precision, jc, spec, ravd]
 
 
 def evaluate(args, model, dataloader, amp=False):
@@ -98,10 +128,11 @@ def evaluate(args, model, dataloader, amp=False):
         logits = model(x)[0]
     model.train(was_training) if was_training else None
     counts = dice_table(logits, y, args.num_classes).cpu().numpy()
+    hd = hd95_table(logits, y, args.num_classes)
     total = int(y.shape[-1] * y.shape[-2])
     metric_list = np.zeros((args.num_classes - 1, len(VAL_METRICS)))
     for i in range(counts.shape[0]):
-        metric_list += np.array([metrics_from_counts(*map(int, counts[i, c]), total)
+        metric_list += np.array([metrics_from_counts(*map(int, counts[i, c]), total, hd[i, c])
                                  for c in range(args.num_classes - 1)])
     n_images = len(dataloader.dataset) if hasattr(dataloader, "dataset") else counts.shape[0]
     metric_list = metric_list / n_images

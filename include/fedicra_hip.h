@@ -200,6 +200,17 @@ int fi_pdice_bwd(const float* probs, const uint8_t* labels, int B, long HW, int 
  * {|P & G|, |P|, |G|}  (int64, atomically added, caller zeroes). */
 int fi_dice_counts(const float* logits, const uint8_t* gt, long M, int C, long long* counts, void* stream);
 
+/* Surface distances for medpy.metric.binary.hd95 (/root/reference/code/val_2D.py:14): border(m) = m AND NOT
+ * erode(m) with the 4-neighbourhood (connectivity 1, outside = background).  fi_seg_borders appends the flat pixel
+ * indices of the border of the prediction (argmax of logits [H*W][C]; class k=1: ==1, k>=2: >=1, val_2D.py:66-74) to
+ * pred_list and of the ground truth to gt_list (int32 [H*W] each, order unspecified) and adds their numbers to
+ * counts[0], counts[1] (int32, caller zeroes).  fi_surface_distances: out[i] (fp64, i < counts[from_index]) = Euclidean
+ * distance from from_list[i] to the nearest pixel of to_list (exhaustive, exact); max_from bounds the launch. */
+int fi_seg_borders(const float* logits, const uint8_t* gt, int H, int W, int C, int k, int* pred_list, int* gt_list,
+                   int* counts, void* stream);
+int fi_surface_distances(const int* from_list, const int* to_list, const int* counts, int from_index, int to_index,
+                         int W, int max_from, double* out, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ----------------
  * torch.optim.AdamW(betas, eps, weight_decay, amsgrad=False) as created at flower_pCE_2D.py:55.
  * All scalars live on the device so that a captured hipGraph can be replayed:

@@ -73,3 +73,23 @@ def eval_case(pred_lbl: np.ndarray, gt_lbl: np.ndarray, classes: int) -> list:
         else:
             out.append(dice_percase(pred_lbl >= 1, gt_lbl >= 1))
     return out
+
+
+def hd95_percase(pred: np.ndarray, gt: np.ndarray) -> float:
+    """medpy.metric.binary.hd95(result, reference) with its defaults (voxelspacing None, connectivity 1), restated from
+    medpy 0.4.0's published algorithm (medpy is not installed here: PARITY UNPINNED for this formula; call site
+    /root/reference/code/val_2D.py:14):
+        border(m) = m XOR binary_erosion(m, generate_binary_structure(ndim, 1))
+        sds(a, b) = distance_transform_edt(~border(b))[border(a)]
+        hd95      = numpy.percentile(hstack(sds(result, reference), sds(reference, result)), 95)
+    Returns NaN where medpy raises (an empty mask)."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    pred, gt = pred > 0, gt > 0
+    if not pred.any() or not gt.any():
+        return float("nan")
+    fp = generate_binary_structure(pred.ndim, 1)
+    pb = pred ^ binary_erosion(pred, structure=fp, iterations=1)
+    gb = gt ^ binary_erosion(gt, structure=fp, iterations=1)
+    d1 = distance_transform_edt(~gb)[pb]
+    d2 = distance_transform_edt(~pb)[gb]
+    return float(np.percentile(np.hstack((d1, d2)), 95))

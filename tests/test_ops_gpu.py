@@ -396,3 +396,35 @@ def test_layout_and_cast():
         back = torch.empty(2, 3, 5, 7, device=DEV)
         lib.nhwc_to_nchw(d, back)
         assert torch.equal(back.cpu(), x.to(dtype).float())
+
+
+def test_hd95_surface_distances_match_scipy_restatement():
+    """hd95 (a17): device border extraction + exhaustive nearest-border search against the scipy restatement of medpy's
+    algorithm (oracle.losses_ref.hd95_percase) -- blobs, nested classes, a mask touching the image edge, speckle and the
+    empty cases."""
+    from fedicra_amd.flower_common import hd95_table
+    from oracle.losses_ref import hd95_percase
+    rng = np.random.default_rng(5)
+    H, W, C = 48, 64, 3
+    yy, xx = np.mgrid[0:H, 0:W]
+
+    def disks(cx, cy, r1, r2):
+        d = np.hypot(xx - cx, yy - cy)
+        return (d < r1).astype(np.uint8) + (d < r2).astype(np.uint8)       # 0 / 1 ring / 2 core
+
+    preds = [disks(30, 20, 14, 6), disks(5, 5, 12, 4), (rng.random((H, W)) < 0.3).astype(np.uint8), np.zeros((H, W), np.uint8),
+             disks(40, 30, 9, 0)]
+    gts = [disks(33, 22, 12, 7), disks(8, 4, 10, 5), disks(30, 20, 10, 3), disks(30, 20, 10, 3), np.zeros((H, W), np.uint8)]
+    logits = torch.zeros(len(preds), C, H, W)
+    for i, p in enumerate(preds):
+        logits[i] = torch.nn.functional.one_hot(torch.from_numpy(p.astype(np.int64)), C).permute(2, 0, 1).float() * 4.0
+    got = hd95_table(logits.to(DEV), torch.from_numpy(np.stack(gts)).to(DEV), C)
+    for i, (p, g) in enumerate(zip(preds, gts)):
+        for k in range(1, C):
+            P = (p == 1) if k == 1 else (p >= 1)
+            G = (g == 1) if k == 1 else (g >= 1)
+            ref = hd95_percase(P, G)
+            if np.isnan(ref):
+                assert np.isnan(got[i, k - 1]), (i, k, got[i, k - 1])
+            else:
+                assert got[i, k - 1] == ref, (i, k, got[i, k - 1], ref)       # exact: integer d^2, one fp64 sqrt
