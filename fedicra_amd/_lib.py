@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -416,6 +416,19 @@ def pdice_bwd(probs, labels, ignore_index, acc, weight, gscale, dprobs):
 def dice_counts(logits, gt, counts):
     M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
     _chk(lib().fi_dice_counts(ptr(logits), ptr(gt), C.c_long(M), Cc, ptr(counts), stream()), "fi_dice_counts")
+
+
+CRF_SLOTS = 16       # FI_CRF_SLOTS
+
+
+def gatedcrf_fwd(y_nhwc, feat_nhwc, radius, weights, sigma_xy, sigma_sample, prod, acc):
+    """weights / sigma_xy / sigma_sample: python sequences, one entry per kernel (sigma <= 0: modality not used)."""
+    N, H, W, Cc = _dev(y_nhwc).shape
+    F_ = feat_nhwc.shape[3]
+    nk = len(weights)
+    arr = lambda v: (C.c_float * nk)(*[float(t) for t in v])
+    _chk(lib().fi_gatedcrf_fwd(ptr(y_nhwc), ptr(_dev(feat_nhwc)), N, H, W, Cc, F_, int(radius), nk, arr(weights),
+                               arr(sigma_xy), arr(sigma_sample), ptr(prod), ptr(acc), stream()), "fi_gatedcrf_fwd")
 
 
 def seg_borders(logits_hwc, gt_u8, k, pred_list, gt_list, counts):

@@ -200,6 +200,20 @@ int fi_pdice_bwd(const float* probs, const uint8_t* labels, int B, long HW, int 
  * {|P & G|, |P|, |G|}  (int64, atomically added, caller zeroes). */
 int fi_dice_counts(const float* logits, const uint8_t* gt, long M, int C, long long* counts, void* stream);
 
+/* Gated CRF loss, Potts model, no masks (/root/reference/code/utils/gate_crf_loss.py:20-124 as called at
+ * flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours.py:143-150), fused: no unfolded tensors.
+ *   y    fp32 [N][H][W][C] class probabilities (C <= 8);  feat fp32 [N][H][W][F] the `sample` modality (F <= 4)
+ *   nk <= 4 kernels: weights[k], sigma_xy[k], sigma_sample[k] -- HOST arrays, read before the launch (a sigma <= 0
+ *   leaves that modality out of kernel k)
+ *   K(i,d) = sum_k w_k exp(-0.5 (|d_xy|^2/sigma_xy^2 + |feat(i+d)-feat(i)|^2/sigma_s^2)), K(i,0) = 0, |d| <= radius (<= 8);
+ *   a neighbour outside the image counts with feat = 0, mesh position (0,0) and y = 0 (the reference's zero-padded unfold).
+ *   prod[i][c] = sum_d K(i,d) y[i+d][c];  acc (fp64 [FI_CRF_SLOTS][2], caller zeroes) += { sum K, sum_c y[i][c] prod[i][c] }.
+ * loss = (sum_s acc[s][0] - sum_s acc[s][1]) / (N*H*W);  d loss / d y = -2 prod / (N*H*W)  (K is symmetric). */
+#define FI_CRF_SLOTS 16
+int fi_gatedcrf_fwd(const float* y, const float* feat, int N, int H, int W, int C, int F, int radius, int nk,
+                    const float* weights, const float* sigma_xy, const float* sigma_sample, float* prod, double* acc,
+                    void* stream);
+
 /* Surface distances for medpy.metric.binary.hd95 (/root/reference/code/val_2D.py:14): border(m) = m AND NOT
  * erode(m) with the 4-neighbourhood (connectivity 1, outside = background).  fi_seg_borders appends the flat pixel
  * indices of the border of the prediction (argmax of logits [H*W][C]; class k=1: ==1, k>=2: >=1, val_2D.py:66-74) to

@@ -320,9 +320,29 @@ def g9_unet3d():
     save("g9_unet3d.npz", **d)
 
 
+def g10_gatedcrf():
+    """Gated CRF loss (section 8f-2): the reference's own module, as its trainer calls it (Potts, no masks)."""
+    from utils.gate_crf_loss import ModelLossSemsegGatedCRF
+    rng = np.random.default_rng(77)
+    d = {}
+    cases = {"a": (2, 3, 24, 20, 3, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5),
+             "b": (1, 2, 17, 31, 1, [{"weight": 0.9, "xy": 6, "rgb": 0.1}, {"weight": 0.1, "xy": 6}], 3)}
+    for name, (N, C, H, W, F_, desc, radius) in cases.items():
+        logits = torch.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32)).requires_grad_(True)
+        sample = torch.from_numpy(rng.random((N, F_, H, W), dtype=np.float32))
+        y = torch.softmax(logits, dim=1)
+        y.retain_grad()
+        loss = ModelLossSemsegGatedCRF()(y, desc, radius, sample.clone(), H, W)["loss"]
+        loss.backward()
+        d[f"{name}/logits"], d[f"{name}/sample"] = logits.detach().numpy(), sample.numpy()
+        d[f"{name}/loss"], d[f"{name}/grad_y"] = np.array(loss.item()), y.grad.numpy()
+        d[f"{name}/grad_logits"] = logits.grad.numpy()
+    save("g10_gatedcrf.npz", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf"]
     for w in which:
         globals()[w]()
