@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -59,6 +59,7 @@ def lib():
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
         _lib.fi_conv2d_wgrad_workspace.restype = C.c_long
+        _lib.fi_tree_mst_workspace.restype = C.c_long
     return _lib
 
 
@@ -416,6 +417,56 @@ def pdice_bwd(probs, labels, ignore_index, acc, weight, gscale, dprobs):
 def dice_counts(logits, gt, counts):
     M, Cc = _dev(logits).numel() // logits.shape[-1], logits.shape[-1]
     _chk(lib().fi_dice_counts(ptr(logits), ptr(gt), C.c_long(M), Cc, ptr(counts), stream()), "fi_dice_counts")
+
+
+def tree_grid_weights(fm, weight):
+    B, Cc, H, W = _dev(fm).shape
+    _chk(lib().fi_tree_grid_weights(ptr(fm), B, Cc, H, W, ptr(weight), stream()), "fi_tree_grid_weights")
+
+
+def tree_mst(weight, H, W, edges):
+    B = _dev(weight).shape[0]
+    per = lib().fi_tree_mst_workspace(H, W)
+    ws = torch.empty(per * B, dtype=torch.uint8, device=weight.device)
+    _chk(lib().fi_tree_mst(ptr(weight), B, H, W, ptr(edges), ptr(ws), C.c_long(per * B), stream()), "fi_tree_mst")
+
+
+def tree_bfs(edges, H, W, sidx, spar, schild, levels):
+    B = _dev(edges).shape[0]
+    adj = torch.empty((B, H * W, 4), dtype=torch.int32, device=edges.device)
+    _chk(lib().fi_tree_bfs(ptr(edges), B, H, W, ptr(sidx), ptr(spar), ptr(schild), ptr(levels), ptr(adj), stream()),
+         "fi_tree_bfs")
+
+
+def tree_edge_weights(embed, sidx, spar, inv_sigma, w):
+    B, Ce, V = _dev(embed).shape
+    _chk(lib().fi_tree_edge_weights(ptr(embed), ptr(sidx), ptr(spar), B, Ce, V, C.c_float(inv_sigma), ptr(w), stream()),
+         "fi_tree_edge_weights")
+
+
+def tree_edge_weights_bwd(embed, sidx, spar, schild, w, gw, inv_sigma, gembed):
+    B, Ce, V = _dev(embed).shape
+    _chk(lib().fi_tree_edge_weights_bwd(ptr(embed), ptr(sidx), ptr(spar), ptr(schild), ptr(w), ptr(gw), B, Ce, V,
+                                        C.c_float(inv_sigma), ptr(gembed), stream()), "fi_tree_edge_weights_bwd")
+
+
+def tree_aggr_up(x, w, sidx, schild, levels, out):
+    B, Cc, V = _dev(out).shape
+    _chk(lib().fi_tree_aggr_up(ptr(x), ptr(w), ptr(sidx), ptr(schild), ptr(levels), B, Cc, V, ptr(out), stream()),
+         "fi_tree_aggr_up")
+
+
+def tree_prop_down(xs, w, sidx, spar, levels, out):
+    B, Cc, V = _dev(out).shape
+    _chk(lib().fi_tree_prop_down(ptr(xs), ptr(w), ptr(sidx), ptr(spar), ptr(levels), B, Cc, V, ptr(out), stream()),
+         "fi_tree_prop_down")
+
+
+def tree_grad_rec(in_data, in_grad, out_data, w, sidx, spar, levels, grad):
+    B, Cd, V = _dev(in_data).shape
+    Cg = in_grad.shape[1]
+    _chk(lib().fi_tree_grad_rec(ptr(in_data), ptr(in_grad), ptr(out_data), ptr(w), ptr(sidx), ptr(spar), ptr(levels), B, Cd,
+                                Cg, V, ptr(grad), stream()), "fi_tree_grad_rec")
 
 
 CRF_SLOTS = 16       # FI_CRF_SLOTS

@@ -1,0 +1,451 @@
+// Tree-filter stack of the reference's tree-energy loss, MI355X-native:
+//   /root/reference/code/utils/TreeEnergyLoss/kernels/lib_tree_filter/{modules/tree_filter.py, src/mst, src/bfs, src/refine}
+// The reference builds the minimum spanning tree on the HOST (D2H copy, one std::thread per image running a serial
+// Boruvka, H2D copy: mst.cu:86-117) and walks the tree with 64-thread workgroups that spin on a shared-memory
+// wavefront (refine.cu:49-66).  Here everything stays on the device:
+//   * fi_tree_grid_weights : 4-neighbour grid edge weights (squared L2 feature distance + 1), torch's rounding order
+//   * fi_tree_mst          : Boruvka with 64-bit (weight bits, edge index) keys and atomicMin -- the total order that
+//                            reproduces the reference's "first edge in list order wins a tie" rule, so the edge SET is
+//                            the reference's; one persistent workgroup per image, no host round trip
+//   * fi_tree_bfs          : deterministic breadth-first order from vertex 0 (frontier order; neighbours up, down,
+//                            left, right) + the level boundaries the recursions below are parallelised over
+//   * fi_tree_edge_weights / _bwd : exp(-|e_i - e_parent|^2 * inv_sigma) per tree edge and its gradient w.r.t. e
+//   * fi_tree_aggr_up / fi_tree_prop_down / fi_tree_grad_rec : the three tree recursions, one workgroup per
+//                            (image, channel), all nodes of a BFS level in parallel, one barrier per level
+// Layouts: per-image planes [B][C][V] fp32 (V = H*W, row-major pixels) -- the loss works on NCHW fp32 tensors.
+#include "common.h"
+
+#define TREE_THREADS 1024
+
+__device__ __forceinline__ void edge_ends(int e, int H, int W, int& u, int& v) {
+  const int nrow = (H - 1) * W;
+  if (e < nrow) {
+    u = e;
+    v = e + W;
+  } else {
+    const int k = e - nrow, h = k / (W - 1), w = k % (W - 1);
+    u = h * W + w;
+    v = u + 1;
+  }
+}
+
+// ---- grid edge weights: vertical pairs first, then horizontal pairs (tree_filter.py:14-34)
+__global__ __launch_bounds__(256) void tree_grid_weights_kernel(const float* __restrict__ fm, int B, int C, int H, int W,
+                                                                float* __restrict__ weight) {
+  const int V = H * W, E = 2 * V - H - W;
+  const long total = (long)B * E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / E), e = (int)(i % E);
+    int u, v;
+    edge_ends(e, H, W, u, v);
+    const float* p = fm + (size_t)b * C * V;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = __fsub_rn(p[(size_t)c * V + u], p[(size_t)c * V + v]);
+      s = __fadd_rn(s, __fmul_rn(d, d));        // products rounded, then summed in channel order: torch's (d*d).sum(1)
+    }
+    weight[i] = __fadd_rn(s, 1.0f);
+  }
+}
+
+// ---- block-wide exclusive scan of one int per thread (TREE_THREADS threads); returns the prefix, *total the sum
+__device__ __forceinline__ int block_exscan(int v, int* sm /* [17] */, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) sm[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < TREE_THREADS / 64; ++k) {
+      const int t = sm[k];
+      sm[k] = run;
+      run += t;
+    }
+    sm[16] = run;
+  }
+  __syncthreads();
+  *total = sm[16];
+  return sm[wv] + inc - v;
+}
+
+// ---- Boruvka.  ws per image: comp[V] int, par[V] int, best[V] u64, flag[E] u8
+__global__ __launch_bounds__(TREE_THREADS) void tree_mst_kernel(const float* __restrict__ weight, int* __restrict__ edge_out,
+                                                                char* __restrict__ wsbase, long ws_stride, int H, int W) {
+  const int V = H * W, E = 2 * V - H - W, b = blockIdx.x, tid = threadIdx.x;
+  char* ws = wsbase + (size_t)b * ws_stride;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(ws);
+  int* comp = reinterpret_cast<int*>(ws + (size_t)V * 8);
+  int* par = comp + V;
+  unsigned char* flag = reinterpret_cast<unsigned char*>(par + V);
+  const float* wt = weight + (size_t)b * E;
+  __shared__ int sm[17];
+  __shared__ int nroots;
+  for (int v = tid; v < V; v += TREE_THREADS) comp[v] = v;
+  for (int e = tid; e < E; e += TREE_THREADS) flag[e] = 0;
+  __syncthreads();
+  for (int round = 0; round < 40; ++round) {
+    for (int v = tid; v < V; v += TREE_THREADS) {
+      best[v] = ~0ull;
+      par[v] = v;
+    }
+    __syncthreads();
+    // cheapest outgoing edge of every component under the total order (weight, edge index)
+    for (int e = tid; e < E; e += TREE_THREADS) {
+      int u, v;
+      edge_ends(e, H, W, u, v);
+      const int cu = comp[u], cv = comp[v];
+      if (cu != cv) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(wt[e]) << 32) | (unsigned)e;   // weights >= 1
+        atomicMin(&best[cu], key);
+        atomicMin(&best[cv], key);
+      }
+    }
+    __syncthreads();
+    // hook every component onto the other end of its edge; of two components that chose the same edge the smaller id stays
+    for (int c = tid; c < V; c += TREE_THREADS) {
+      if (comp[c] != c) continue;
+      const unsigned long long k = best[c];
+      if (k == ~0ull) continue;
+      const int e = (int)(k & 0xffffffffu);
+      int u, v;
+      edge_ends(e, H, W, u, v);
+      const int cu = comp[u], cv = comp[v];
+      const int other = cu == c ? cv : cu;
+      flag[e] = 1;
+      par[c] = (best[other] == k && c < other) ? c : other;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int v = tid; v < V; v += TREE_THREADS) {
+      int r = comp[v];
+      while (par[r] != r) r = par[r];
+      comp[v] = r;              // par[] is only read here; comp[v] belongs to this thread
+      mine += r == v;
+    }
+    __syncthreads();
+    if (tid == 0) nroots = 0;
+    __syncthreads();
+    mine = (int)wave_sum((float)mine);
+    if ((tid & 63) == 0) atomicAdd(&nroots, mine);
+    __syncthreads();
+    if (nroots <= 1) break;
+  }
+  // ordered compaction of the chosen edges (edge-index order) into edge_out[b][V-1][2]
+  const int per = (E + TREE_THREADS - 1) / TREE_THREADS;
+  const int lo = min(tid * per, E), hi = min(lo + per, E);
+  int cnt = 0;
+  for (int e = lo; e < hi; ++e) cnt += flag[e];
+  int total;
+  int pos = block_exscan(cnt, sm, &total);
+  int* out = edge_out + (size_t)b * (V - 1) * 2;
+  for (int e = lo; e < hi; ++e)
+    if (flag[e]) {
+      int u, v;
+      edge_ends(e, H, W, u, v);
+      if (pos < V - 1) {
+        out[2 * pos] = u;
+        out[2 * pos + 1] = v;
+      }
+      ++pos;
+    }
+}
+
+// ---- breadth-first order.  ws per image: adj[V][4] int (up, down, left, right; -1 = none)
+__global__ __launch_bounds__(TREE_THREADS) void tree_bfs_kernel(const int* __restrict__ edges, int* __restrict__ sidx,
+                                                                int* __restrict__ spar, int* __restrict__ schild,
+                                                                int* __restrict__ levels, int* __restrict__ adjbase, int H,
+                                                                int W) {
+  const int V = H * W, b = blockIdx.x, tid = threadIdx.x;
+  const int* ed = edges + (size_t)b * (V - 1) * 2;
+  int* adj = adjbase + (size_t)b * V * 4;
+  int* si = sidx + (size_t)b * V;
+  int* sp = spar + (size_t)b * V;
+  int* sc = schild + (size_t)b * V * 4;
+  int* lv = levels + (size_t)b * (V + 2);          // lv[0] = number of levels L, lv[1 + l] = first position of level l
+  __shared__ int sm[17];
+  for (int i = tid; i < V * 4; i += TREE_THREADS) {
+    adj[i] = -1;
+    sc[i] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < V - 1; i += TREE_THREADS) {
+    const int a = min(ed[2 * i], ed[2 * i + 1]), c = max(ed[2 * i], ed[2 * i + 1]);
+    if (c == a + W) {
+      adj[a * 4 + 1] = c;
+      adj[c * 4 + 0] = a;
+    } else {        // c == a + 1 (grid trees only)
+      adj[a * 4 + 3] = c;
+      adj[c * 4 + 2] = a;
+    }
+  }
+  if (tid == 0) {
+    si[0] = 0;
+    sp[0] = 0;
+    lv[1] = 0;
+  }
+  __syncthreads();
+  int lo = 0, hi = 1, nlev = 0;
+  while (lo < hi) {
+    int next = hi;
+    for (int base = lo; base < hi; base += TREE_THREADS) {
+      const int i = base + tid;
+      int kids[4], nk = 0;
+      if (i < hi) {
+        const int cur = si[i];
+        const int pv = i == 0 ? -1 : si[sp[i]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nb = adj[cur * 4 + q];
+          if (nb >= 0 && nb != pv) kids[nk++] = nb;
+        }
+      }
+      int total;
+      const int off = block_exscan(nk, sm, &total);
+      for (int q = 0; q < nk; ++q) {
+        const int pos = next + off + q;
+        si[pos] = kids[q];
+        sp[pos] = i;
+        sc[i * 4 + q] = pos;
+      }
+      next += total;
+      __syncthreads();
+    }
+    ++nlev;
+    if (tid == 0) lv[1 + nlev] = hi;
+    lo = hi;
+    hi = next;
+    __syncthreads();
+  }
+  if (tid == 0) lv[0] = nlev;
+}
+
+// ---- tree edge weights (sorted order) and their gradient w.r.t. the embedding
+__global__ __launch_bounds__(256) void tree_edge_weights_kernel(const float* __restrict__ embed, const int* __restrict__ sidx,
+                                                                const int* __restrict__ spar, int B, int Ce, int V,
+                                                                float inv_sigma, float* __restrict__ w) {
+  const long total = (long)B * V;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int b = (int)(t / V), i = (int)(t % V);
+    const int* si = sidx + (size_t)b * V;
+    const int cur = si[i], parv = si[spar[(size_t)b * V + i]];
+    const float* e = embed + (size_t)b * Ce * V;
+    float s = 0.f;
+    for (int c = 0; c < Ce; ++c) {
+      const float d = __fsub_rn(e[(size_t)c * V + cur], e[(size_t)c * V + parv]);
+      s = __fadd_rn(s, __fmul_rn(d, d));
+    }
+    w[t] = expf(-s * inv_sigma);
+  }
+}
+__global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float* __restrict__ embed,
+                                                                    const int* __restrict__ sidx,
+                                                                    const int* __restrict__ spar,
+                                                                    const int* __restrict__ schild,
+                                                                    const float* __restrict__ w, const float* __restrict__ gw,
+                                                                    int B, int Ce, int V, float inv_sigma,
+                                                                    float* __restrict__ gembed) {
+  // d w_i / d e = -inv_sigma * w_i * 2 (e_i - e_par);  vertex at sorted position i collects its own edge and its children's
+  const long total = (long)B * V;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int b = (int)(t / V), i = (int)(t % V);
+    const int* si = sidx + (size_t)b * V;
+    const int* sp = spar + (size_t)b * V;
+    const int* sc = schild + (size_t)b * V * 4;
+    const float* wb = w + (size_t)b * V;
+    const float* gb = gw + (size_t)b * V;
+    const float* e = embed + (size_t)b * Ce * V;
+    const int cur = si[i];
+    for (int c = 0; c < Ce; ++c) {
+      const float ei = e[(size_t)c * V + cur];
+      float g = 0.f;
+      if (i > 0) g += -2.f * inv_sigma * wb[i] * gb[i] * (ei - e[(size_t)c * V + si[sp[i]]]);
+      for (int q = 0; q < 4; ++q) {
+        const int ch = sc[i * 4 + q];
+        if (ch <= 0) break;
+        g += 2.f * inv_sigma * wb[ch] * gb[ch] * (e[(size_t)c * V + si[ch]] - ei);
+      }
+      gembed[((size_t)b * Ce + c) * V + cur] = g;
+    }
+  }
+}
+
+// ---- recursions: one workgroup per (image, channel); the nodes of one BFS level are independent
+__global__ __launch_bounds__(256) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const int* __restrict__ sidx, const int* __restrict__ schild,
+                                                           const int* __restrict__ levels, int C, int V,
+                                                           float* __restrict__ out) {
+  const int b = blockIdx.x, c = blockIdx.y;
+  const int* si = sidx + (size_t)b * V;
+  const int* sc = schild + (size_t)b * V * 4;
+  const int* lv = levels + (size_t)b * (V + 2);
+  const float* wb = w + (size_t)b * V;
+  const float* xb = x ? x + ((size_t)b * C + c) * V : nullptr;
+  float* ob = out + ((size_t)b * C + c) * V;
+  const int L = lv[0];
+  for (int l = L - 1; l >= 0; --l) {
+    const int lo = lv[1 + l], hi = lv[2 + l];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      float s = xb ? xb[si[i]] : 1.0f;
+      for (int q = 0; q < 4; ++q) {
+        const int ch = sc[i * 4 + q];
+        if (ch <= 0) break;
+        s = __fadd_rn(s, __fmul_rn(ob[ch], wb[ch]));
+      }
+      ob[i] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void tree_prop_down_kernel(const float* __restrict__ xs, const float* __restrict__ w,
+                                                             const int* __restrict__ sidx, const int* __restrict__ spar,
+                                                             const int* __restrict__ levels, int C, int V,
+                                                             float* __restrict__ out) {
+  const int b = blockIdx.x, c = blockIdx.y;
+  const int* si = sidx + (size_t)b * V;
+  const int* sp = spar + (size_t)b * V;
+  const int* lv = levels + (size_t)b * (V + 2);
+  const float* wb = w + (size_t)b * V;
+  const float* xb = xs + ((size_t)b * C + c) * V;
+  float* ob = out + ((size_t)b * C + c) * V;
+  const int L = lv[0];
+  for (int l = 0; l < L; ++l) {
+    const int lo = lv[1 + l], hi = lv[2 + l];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      if (i == 0) {
+        ob[si[0]] = xb[0];                          // the root's edge weight counts as 0 (refine.cu:43-46)
+      } else {
+        const float wi = wb[i];
+        ob[si[i]] = __fadd_rn(__fmul_rn(xb[i], __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(ob[si[sp[i]]], wi));
+      }
+    }
+    __syncthreads();
+  }
+}
+// refine.cu:136-199: grad[cur] = in_grad[cur]*(out_data[par] - w*in_data[cur]) + in_data[cur]*(G[par] - w*in_grad[cur]),
+// G = in_grad propagated root->leaf in place.  in_data/out_data have Cd channels (channel k % Cd), gradients Cg.
+__global__ __launch_bounds__(256) void tree_grad_rec_kernel(const float* __restrict__ in_data, float* __restrict__ in_grad,
+                                                            const float* __restrict__ out_data, const float* __restrict__ w,
+                                                            const int* __restrict__ sidx, const int* __restrict__ spar,
+                                                            const int* __restrict__ levels, int Cd, int Cg, int V,
+                                                            float* __restrict__ grad) {
+  const int b = blockIdx.x, k = blockIdx.y;
+  const int Cmax = Cd > Cg ? Cd : Cg;
+  const int* si = sidx + (size_t)b * V;
+  const int* sp = spar + (size_t)b * V;
+  const int* lv = levels + (size_t)b * (V + 2);
+  const float* wb = w + (size_t)b * V;
+  const float* idb = in_data + ((size_t)b * Cd + k % Cd) * V;
+  const float* odb = out_data + ((size_t)b * Cd + k % Cd) * V;
+  float* igb = in_grad + ((size_t)b * Cg + k % Cg) * V;
+  float* gb = grad + ((size_t)b * Cmax + k) * V;
+  const int L = lv[0];
+  for (int l = 0; l < L; ++l) {
+    const int lo = lv[1 + l], hi = lv[2 + l];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      if (i == 0) {
+        gb[0] = 0.f;
+      } else {
+        const int p = sp[i];
+        const float wi = wb[i], ig = igb[i], id = idb[i], gp = igb[p];     // igb[p]: already propagated (previous level)
+        gb[i] = ig * (odb[si[p]] - wi * id) + id * (gp - wi * ig);
+        igb[i] = ig * (1.0f - wi * wi) + gp * wi;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static inline int tree_grid(long work) {
+  long b = (work + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+extern "C" long fi_tree_mst_workspace(int H, int W) {
+  if (H < 1 || W < 1) return FI_ERR_SHAPE;
+  const long V = (long)H * W, E = 2 * V - H - W;
+  return ((V * 16 + E + 255) / 256) * 256;       // best u64[V], comp int[V], par int[V], flag u8[E]; per image
+}
+extern "C" int fi_tree_grid_weights(const float* fm, int B, int C, int H, int W, float* weight, void* stream) {
+  if (!fm || !weight) return FI_ERR_NULL;
+  if (B < 1 || C < 1 || H < 2 || W < 2) return FI_ERR_SHAPE;
+  const long E = 2L * H * W - H - W;
+  hipLaunchKernelGGL(tree_grid_weights_kernel, dim3(tree_grid(B * E)), dim3(256), 0, (hipStream_t)stream, fm, B, C, H, W,
+                     weight);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_mst(const float* weight, int B, int H, int W, int* edge_out, void* workspace, long workspace_bytes,
+                           void* stream) {
+  if (!weight || !edge_out || !workspace) return FI_ERR_NULL;
+  if (B < 1 || H < 2 || W < 2) return FI_ERR_SHAPE;
+  const long per = fi_tree_mst_workspace(H, W);
+  if (workspace_bytes < per * B) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_mst_kernel, dim3(B), dim3(TREE_THREADS), 0, (hipStream_t)stream, weight, edge_out, (char*)workspace,
+                     per, H, W);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_bfs(const int* edges, int B, int H, int W, int* sorted_index, int* sorted_parent, int* sorted_child,
+                           int* levels, int* adjacency_workspace, void* stream) {
+  if (!edges || !sorted_index || !sorted_parent || !sorted_child || !levels || !adjacency_workspace) return FI_ERR_NULL;
+  if (B < 1 || H < 2 || W < 2) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_bfs_kernel, dim3(B), dim3(TREE_THREADS), 0, (hipStream_t)stream, edges, sorted_index, sorted_parent,
+                     sorted_child, levels, adjacency_workspace, H, W);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_edge_weights(const float* embed, const int* sorted_index, const int* sorted_parent, int B, int Ce,
+                                    int V, float inv_sigma, float* w, void* stream) {
+  if (!embed || !sorted_index || !sorted_parent || !w) return FI_ERR_NULL;
+  if (B < 1 || Ce < 1 || V < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_edge_weights_kernel, dim3(tree_grid((long)B * V)), dim3(256), 0, (hipStream_t)stream, embed,
+                     sorted_index, sorted_parent, B, Ce, V, inv_sigma, w);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_edge_weights_bwd(const float* embed, const int* sorted_index, const int* sorted_parent,
+                                        const int* sorted_child, const float* w, const float* grad_w, int B, int Ce, int V,
+                                        float inv_sigma, float* grad_embed, void* stream) {
+  if (!embed || !sorted_index || !sorted_parent || !sorted_child || !w || !grad_w || !grad_embed) return FI_ERR_NULL;
+  if (B < 1 || Ce < 1 || V < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_edge_weights_bwd_kernel, dim3(tree_grid((long)B * V)), dim3(256), 0, (hipStream_t)stream, embed,
+                     sorted_index, sorted_parent, sorted_child, w, grad_w, B, Ce, V, inv_sigma, grad_embed);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_aggr_up(const float* x, const float* w, const int* sorted_index, const int* sorted_child,
+                               const int* levels, int B, int C, int V, float* out, void* stream) {
+  if (!w || !sorted_index || !sorted_child || !levels || !out) return FI_ERR_NULL;
+  if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_aggr_up_kernel, dim3(B, C), dim3(256), 0, (hipStream_t)stream, x, w, sorted_index, sorted_child,
+                     levels, C, V, out);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_prop_down(const float* x_sorted, const float* w, const int* sorted_index, const int* sorted_parent,
+                                 const int* levels, int B, int C, int V, float* out, void* stream) {
+  if (!x_sorted || !w || !sorted_index || !sorted_parent || !levels || !out) return FI_ERR_NULL;
+  if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_prop_down_kernel, dim3(B, C), dim3(256), 0, (hipStream_t)stream, x_sorted, w, sorted_index,
+                     sorted_parent, levels, C, V, out);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fi_tree_grad_rec(const float* in_data, float* in_grad, const float* out_data, const float* w,
+                                const int* sorted_index, const int* sorted_parent, const int* levels, int B, int Cd, int Cg,
+                                int V, float* grad, void* stream) {
+  if (!in_data || !in_grad || !out_data || !w || !sorted_index || !sorted_parent || !levels || !grad) return FI_ERR_NULL;
+  if (B < 1 || Cd < 1 || Cg < 1 || V < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(tree_grad_rec_kernel, dim3(B, Cd > Cg ? Cd : Cg), dim3(256), 0, (hipStream_t)stream, in_data, in_grad,
+                     out_data, w, sorted_index, sorted_parent, levels, Cd, Cg, V, grad);
+  FI_CHECK_LAUNCH();
+  return 0;
+}

@@ -214,6 +214,44 @@ int fi_gatedcrf_fwd(const float* y, const float* feat, int N, int H, int W, int 
                     const float* weights, const float* sigma_xy, const float* sigma_sample, float* prod, double* acc,
                     void* stream);
 
+/* ---------------------------------------------------------------- tree filter (tree-energy loss) --------
+ * The reference's `tree_filter_cuda` extension (/root/reference/code/utils/TreeEnergyLoss/kernels/lib_tree_filter/src:
+ * mst_forward = host Boruvka behind a D2H/H2D round trip, bfs_forward, refine_forward / _backward_feature / _backward_weight)
+ * as device-resident kernels.  Per-image planes [B][C][V] fp32, V = H*W row-major; "sorted" = breadth-first position.
+ *
+ * fi_tree_grid_weights: weight[b][e] = |fm[b][:,u] - fm[b][:,v]|^2 + 1 over the 4-neighbour grid, vertical pairs
+ *   ((h,w),(h+1,w)) first, then horizontal ((h,w),(h,w+1))  (modules/tree_filter.py:14-34);  E = 2HW - H - W.
+ * fi_tree_mst: minimum spanning tree under the total order (weight, edge index) -- the tree the reference's Boruvka
+ *   (mst/boruvka.cpp:20-112: a tie goes to the first edge in list order) selects; edge_out int32 [B][V-1][2] in edge-index
+ *   order (the reference emits the same SET in Boruvka order).  workspace: B * fi_tree_mst_workspace(H, W) bytes.
+ * fi_tree_bfs: breadth-first order from vertex 0 (bfs/bfs.cu:19-98): sorted_index [B][V] (vertex at each position),
+ *   sorted_parent [B][V] (position of the parent; 0 for the root), sorted_child [B][V][4] (positions, 0 = none);
+ *   levels int32 [B][V+2]: levels[b][0] = number of levels L, levels[b][1+l] = first position of level l (.. [1+L] = V);
+ *   adjacency_workspace int32 [B][V][4].  Deterministic (frontier order; neighbours up, down, left, right).
+ * fi_tree_edge_weights: w[b][i] = exp(-|e[:,sorted_index[i]] - e[:,parent]|^2 * inv_sigma)   (tree_filter.py:92-110);
+ *   fi_tree_edge_weights_bwd: grad_embed (original order) from grad_w (sorted).
+ * fi_tree_aggr_up  : out[i] = x[sorted_index[i]] + sum_child out[child]*w[child]   (x == NULL: 1)   refine.cu:70-134
+ * fi_tree_prop_down: out[sorted_index[i]] = x[i]*(1 - w[i]^2) + out[parent vertex]*w[i], w[root] := 0 refine.cu:19-68
+ * fi_tree_grad_rec : edge-weight gradient recursion, in_grad propagated in place                    refine.cu:136-199
+ *   (in_data / in_grad sorted, out_data original order; Cd data channels, Cg gradient channels, grad [B][max][V] sorted). */
+long fi_tree_mst_workspace(int H, int W);
+int fi_tree_grid_weights(const float* fm, int B, int C, int H, int W, float* weight, void* stream);
+int fi_tree_mst(const float* weight, int B, int H, int W, int* edge_out, void* workspace, long workspace_bytes,
+                void* stream);
+int fi_tree_bfs(const int* edges, int B, int H, int W, int* sorted_index, int* sorted_parent, int* sorted_child,
+                int* levels, int* adjacency_workspace, void* stream);
+int fi_tree_edge_weights(const float* embed, const int* sorted_index, const int* sorted_parent, int B, int Ce, int V,
+                         float inv_sigma, float* w, void* stream);
+int fi_tree_edge_weights_bwd(const float* embed, const int* sorted_index, const int* sorted_parent, const int* sorted_child,
+                             const float* w, const float* grad_w, int B, int Ce, int V, float inv_sigma, float* grad_embed,
+                             void* stream);
+int fi_tree_aggr_up(const float* x, const float* w, const int* sorted_index, const int* sorted_child, const int* levels,
+                    int B, int C, int V, float* out, void* stream);
+int fi_tree_prop_down(const float* x_sorted, const float* w, const int* sorted_index, const int* sorted_parent,
+                      const int* levels, int B, int C, int V, float* out, void* stream);
+int fi_tree_grad_rec(const float* in_data, float* in_grad, const float* out_data, const float* w, const int* sorted_index,
+                     const int* sorted_parent, const int* levels, int B, int Cd, int Cg, int V, float* grad, void* stream);
+
 /* Surface distances for medpy.metric.binary.hd95 (/root/reference/code/val_2D.py:14): border(m) = m AND NOT
  * erode(m) with the 4-neighbourhood (connectivity 1, outside = background).  fi_seg_borders appends the flat pixel
  * indices of the border of the prediction (argmax of logits [H*W][C]; class k=1: ==1, k>=2: >=1, val_2D.py:66-74) to

@@ -49,3 +49,71 @@ def test_gated_crf_trainer_shape_against_oracle():
         assert (yd.grad.cpu() - gref).abs().max().item() < 2e-5 * gref.abs().max().item()
     with pytest.raises(NotImplementedError):
         ModelLossSemsegGatedCRF()(yd, desc, 5, sample.to(DEV), H, W, mask_src=torch.ones(1, 1, H, W, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------ tree filter
+def _rand_guides(B, C, H, W, seed, ties=False):
+    rng = np.random.default_rng(seed)
+    if ties:                                           # piecewise-constant: many exactly equal edge weights
+        return torch.from_numpy(rng.integers(0, 3, (B, C, H, W)).astype(np.float32))
+    return torch.from_numpy(rng.random((B, C, H, W), dtype=np.float32))
+
+
+@pytest.mark.parametrize("case", [(2, 3, 9, 13, False), (1, 2, 16, 16, True), (3, 1, 20, 7, True), (2, 3, 64, 48, False)])
+def test_tree_mst_is_the_references_tree(case):
+    """Grid weights bit-equal to torch's, spanning tree = the edge SET the reference's own Boruvka (compiled from its
+    source into oracle/_ref) selects -- including inputs full of ties -- and a valid deterministic BFS order."""
+    from fedicra_amd.utils.tree_filter import MinimumSpanningTree, TreeFilter2D
+    from fedicra_amd import _lib as L
+    from oracle import tree_ref as T
+    B, C, H, W, ties = case
+    fm = _rand_guides(B, C, H, W, seed=H * W, ties=ties)
+    wd = torch.empty((B, 2 * H * W - H - W), device=DEV)
+    L.tree_grid_weights(fm.to(DEV), wd)
+    # same arithmetic (products rounded, then summed in channel order); torch's own reduction order is not specified,
+    # so one ulp is allowed here and the spanning trees below are compared on the SAME (device) weights
+    assert torch.allclose(wd.cpu(), T.grid_weights(fm), rtol=3e-7, atol=0), "grid weights differ from torch's"
+    tree = MinimumSpanningTree(TreeFilter2D.norm2_distance)(fm.to(DEV))
+    assert tuple(tree.shape) == (B, H * W - 1, 2)
+    idx, wt = T.grid_index(H, W), wd.cpu().numpy()
+    edges = tree.edges.cpu().numpy()
+    V = H * W
+    for b in range(B):
+        ref = T.mst_reference(idx, wt[b], V) if T.have_reference_boruvka() else T.mst_kruskal(idx, wt[b], V)
+        assert T.edge_set(edges[b]) == T.edge_set(ref), f"image {b}: spanning tree differs from the reference's"
+        assert T.edge_set(edges[b]) == T.edge_set(T.mst_kruskal(idx, wt[b], V))
+    sidx = torch.empty((B, V), dtype=torch.int32, device=DEV)
+    spar, schild = torch.empty_like(sidx), torch.empty((B, V, 4), dtype=torch.int32, device=DEV)
+    levels = torch.empty((B, V + 2), dtype=torch.int32, device=DEV)
+    L.tree_bfs(tree.edges, H, W, sidx, spar, schild, levels)
+    for b in range(B):
+        rs, rp, rc, rl = T.bfs(edges[b], V, W)
+        assert np.array_equal(sidx[b].cpu().numpy(), rs) and np.array_equal(spar[b].cpu().numpy(), rp)
+        assert np.array_equal(schild[b].cpu().numpy(), rc)
+        lv = levels[b].cpu().numpy()
+        assert lv[0] == len(rl) - 1 and list(lv[1:2 + lv[0]]) == rl
+
+
+@pytest.mark.parametrize("low_tree", [True, False])
+def test_tree_filter_forward_backward_against_oracle(low_tree):
+    """TreeFilter2D output, d/d feature and (high-level tree) d/d embedding vs the CPU restatement of refine.cu."""
+    from fedicra_amd.utils.tree_filter import MinimumSpanningTree, TreeFilter2D
+    from oracle import tree_ref as T
+    B, C, Ce, H, W = 2, 2, 3, 24, 20
+    g = torch.Generator().manual_seed(5)
+    feat = torch.rand(B, C, H, W, generator=g)
+    emb = torch.rand(B, Ce, H, W, generator=g) * (0.3 if low_tree else 1.0)
+    gout = torch.rand(B, C, H, W, generator=g)
+    fr, er = feat.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    fd, ed = feat.to(DEV).requires_grad_(True), emb.to(DEV).requires_grad_(True)
+    tree = MinimumSpanningTree(TreeFilter2D.norm2_distance)(ed)
+    ref = T.tree_filter(fr, er, tree.edges.cpu().numpy(), 0.02, low_tree)     # same tree: the MST has its own test
+    (ref * gout).sum().backward()
+    out = TreeFilter2D(groups=1, sigma=0.02)(fd, ed, tree, low_tree=low_tree)
+    (out * gout.to(DEV)).sum().backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 2e-5
+    assert (fd.grad.cpu() - fr.grad).abs().max().item() < 2e-5 * max(1.0, fr.grad.abs().max().item())
+    if low_tree:
+        assert ed.grad is None and er.grad is None
+    else:
+        assert (ed.grad.cpu() - er.grad).abs().max().item() < 5e-5 * max(1.0, er.grad.abs().max().item())
