@@ -1,0 +1,67 @@
+"""Tree-energy losses of the reference (/root/reference/code/flower_common.py:646-689 `TreeEnergyLoss`, :756-818
+`MScaleRecurveTreeEnergyLoss`), same constructor / forward signatures and return tuples, on the device-resident tree
+filter (fedicra_amd/utils/tree_filter.py).  The elementwise glue (softmax, bilinear resize of the guidance maps, masked
+L1) stays on torch ops exactly as in the reference; every tree operation is a libfedicra_hip.so launch."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils.tree_filter import MinimumSpanningTree, TreeFilter2D
+
+
+def _prep(preds, low_feats, unlabeled_ROIs):
+    with torch.no_grad():
+        _, _, h, w = preds.size()
+        low_feats = F.interpolate(low_feats.float(), size=(h, w), mode="bilinear", align_corners=False)
+        rois = F.interpolate(unlabeled_ROIs.unsqueeze(1).float(), size=(h, w), mode="nearest")
+        N = rois.sum()
+    return low_feats, rois, N, (h, w)
+
+
+class TreeEnergyLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mst_layers = MinimumSpanningTree(TreeFilter2D.norm2_distance)
+        self.tree_filter_layers = TreeFilter2D(groups=1, sigma=0.02)
+
+    def forward(self, preds, low_feats, high_feats, unlabeled_ROIs, weight):
+        preds = preds.float()
+        low_feats, rois, N, size = _prep(preds, low_feats, unlabeled_ROIs)
+        prob = torch.softmax(preds, dim=1)
+        tree = self.mst_layers(low_feats)
+        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=tree)
+        if high_feats is not None:
+            high_feats = F.interpolate(high_feats.float(), size=size, mode="bilinear", align_corners=False)
+            tree = self.mst_layers(high_feats)
+            AS = self.tree_filter_layers(feature_in=AS, embed_in=high_feats, tree=tree, low_tree=False)
+        tree_loss = (rois * torch.abs(prob - AS)).sum()
+        if N > 0:
+            tree_loss = tree_loss / N
+        return weight * tree_loss, AS
+
+
+class MScaleRecurveTreeEnergyLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mst_layers = MinimumSpanningTree(TreeFilter2D.norm2_distance)
+        self.tree_filter_layers = TreeFilter2D(groups=1, sigma=0.02)
+
+    def forward(self, preds, low_feats, high_feats_1, high_feats_2, high_feats_3, unlabeled_ROIs, weight):
+        preds = preds.float()
+        low_feats, rois, N, size = _prep(preds, low_feats, unlabeled_ROIs)
+        prob = torch.softmax(preds, dim=1)
+        tree = self.mst_layers(low_feats)
+        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=tree)
+        outs, cur = [], AS
+        for hf in (high_feats_1, high_feats_2, high_feats_3):
+            # the reference dereferences AS_1..AS_3 unconditionally at the end: all three maps are required
+            hf = F.interpolate(hf.float(), size=size, mode="bilinear", align_corners=False)
+            tree = self.mst_layers(hf)
+            cur = self.tree_filter_layers(feature_in=cur, embed_in=hf, tree=tree, low_tree=False)
+            outs.append(cur)
+        tree_loss = (rois * torch.abs(prob - outs[2])).sum()
+        if N > 0:
+            tree_loss = tree_loss / N
+        return weight * tree_loss, outs[0], outs[1], outs[2]

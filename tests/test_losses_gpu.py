@@ -117,3 +117,36 @@ def test_tree_filter_forward_backward_against_oracle(low_tree):
         assert ed.grad is None and er.grad is None
     else:
         assert (ed.grad.cpu() - er.grad).abs().max().item() < 5e-5 * max(1.0, er.grad.abs().max().item())
+
+
+def test_tree_energy_losses_against_oracle():
+    """TreeEnergyLoss / MScaleRecurveTreeEnergyLoss (flower_common.py:646-818): loss value, filtered maps and the
+    gradients that reach the logits and the three guidance feature maps, vs the CPU restatement run on the SAME trees
+    (the restatement recomputes them from the same device-side weights' order: piecewise-smooth guides without near-ties)."""
+    from fedicra_amd.tree_energy import MScaleRecurveTreeEnergyLoss, TreeEnergyLoss
+    from oracle import tree_ref as T
+    B, C, H, W = 2, 2, 32, 24
+    g = torch.Generator().manual_seed(11)
+    preds = torch.randn(B, C, H, W, generator=g)
+    img = torch.rand(B, 3, H, W, generator=g)
+    highs = [torch.rand(B, 2, H // s, W // s, generator=g) for s in (4, 2, 1)]       # aux heads at S/4, S/2, S
+    rois = (torch.rand(B, H, W, generator=g) < 0.9)
+    pr = preds.clone().requires_grad_(True)
+    hr = [h.clone().requires_grad_(True) for h in highs]
+    ref = T.mscale_recurve_tree_energy_loss(pr, img, hr[0], hr[1], hr[2], rois, 0.4)
+    ref[0].backward()
+    pd = preds.to(DEV).requires_grad_(True)
+    hd = [h.to(DEV).requires_grad_(True) for h in highs]
+    out = MScaleRecurveTreeEnergyLoss()(pd, img.to(DEV), hd[0], hd[1], hd[2], rois.to(DEV), 0.4)
+    out[0].backward()
+    assert abs(out[0].item() - ref[0].item()) < 2e-5 * max(1.0, abs(ref[0].item())), (out[0].item(), ref[0].item())
+    for k in range(1, 4):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() < 5e-5
+    assert (pd.grad.cpu() - pr.grad).abs().max().item() < 5e-5 * max(1.0, pr.grad.abs().max().item())
+    for a, b_ in zip(hd, hr):
+        assert (a.grad.cpu() - b_.grad).abs().max().item() < 2e-4 * max(1e-3, b_.grad.abs().max().item())
+    # single-tree variant, low-level tree only
+    p2 = preds.to(DEV).requires_grad_(True)
+    l2, AS = TreeEnergyLoss()(p2, img.to(DEV), None, rois.to(DEV), 1.0)
+    r2, ASr = T.tree_energy_loss(preds.clone().requires_grad_(True), img, rois, 1.0)
+    assert abs(l2.item() - r2.item()) < 2e-5 and (AS.detach().cpu() - ASr.detach()).abs().max().item() < 5e-5
