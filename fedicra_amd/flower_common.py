@@ -416,3 +416,7 @@ def get_evaluate_metrics_aggregation_fn(args, val_metrics):
         metrics.update({"val_avg_mean_{}".format(m): mean_metric("val_mean_{}".format(m)) for m in val_metrics})
         return metrics
     return evaluate_metrics_aggregation_fn
+
+
+# the reference defines the tree-energy losses in this module (flower_common.py:646-818); re-exported under the same names
+from .tree_energy import MScaleRecurveTreeEnergyLoss, TreeEnergyLoss  # noqa: E402,F401

@@ -37,8 +37,7 @@ class TreeEnergyLoss(nn.Module):
             tree = self.mst_layers(high_feats)
             AS = self.tree_filter_layers(feature_in=AS, embed_in=high_feats, tree=tree, low_tree=False)
         tree_loss = (rois * torch.abs(prob - AS)).sum()
-        if N > 0:
-            tree_loss = tree_loss / N
+        tree_loss = tree_loss / N.clamp(min=1)        # `if N > 0: tree_loss /= N` without a host sync (N = 0 => sum = 0)
         return weight * tree_loss, AS
 
 
@@ -62,6 +61,5 @@ class MScaleRecurveTreeEnergyLoss(nn.Module):
             cur = self.tree_filter_layers(feature_in=cur, embed_in=hf, tree=tree, low_tree=False)
             outs.append(cur)
         tree_loss = (rois * torch.abs(prob - outs[2])).sum()
-        if N > 0:
-            tree_loss = tree_loss / N
+        tree_loss = tree_loss / N.clamp(min=1)        # `if N > 0: tree_loss /= N` without a host sync (N = 0 => sum = 0)
         return weight * tree_loss, outs[0], outs[1], outs[2]

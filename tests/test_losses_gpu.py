@@ -150,3 +150,73 @@ def test_tree_energy_losses_against_oracle():
     l2, AS = TreeEnergyLoss()(p2, img.to(DEV), None, rois.to(DEV), 1.0)
     r2, ASr = T.tree_energy_loss(preds.clone().requires_grad_(True), img, rois, 1.0)
     assert abs(l2.item() - r2.item()) < 2e-5 and (AS.detach().cpu() - ASr.detach()).abs().max().item() < 5e-5
+
+
+def test_ours_procedure_first_iteration_against_oracle_and_graph_replay():
+    """flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours.MyClient: the loss terms of the first iteration (pCE, tree energy,
+    gated CRF) vs the CPU oracle evaluated on the oracle network with the same seeded state and dropout masks; then the
+    captured hipGraph must reproduce the eager run."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours import MyClient
+    from fedicra_amd.flower_pCE_2D import _GraphStep
+    from fedicra_amd.networks.unet import UNet_MultiHead, set_compute_dtype
+    from oracle import tree_ref as T
+    from oracle.gatedcrf_ref import gated_crf_loss
+    from oracle.losses_ref import pce_loss
+    from oracle.unet_ref import RefUNet, seeded_state
+    from helpers import loader
+    batches = loader(2, 4, 64, cid=0)
+
+    def args_(**kw):
+        a = argparse.Namespace(strategy="FedAvg", amp=0, model="unet_multihead", cid=0, min_num_clients=1, num_classes=2,
+                               img_class="faz", base_lr=0.01, max_iterations=30000, iters=4, rep_iters=3, alpha=0.5,
+                               snapshot_path=None, use_graph=False, tree_loss_weight=0.1)
+        a.__dict__.update(kw)
+        return a
+
+    def mk():
+        m = UNet_MultiHead(1, 2)
+        seeded_state(m, 2022)
+        return set_compute_dtype(m.cuda(), "fp32")
+
+    # ---- oracle: forward in train mode with pinned masks, the three loss terms
+    b = batches[0]
+    ref = RefUNet(1, 2, heads=3)
+    seeded_state(ref, 2022)
+    ref.train()
+    torch.manual_seed(3)
+    x = b["image"].unsqueeze(1)
+    o = ref(x)
+    ce_ref = pce_loss(o[0], b["label"], 2)
+    tree_ref = T.mscale_recurve_tree_energy_loss(o[0], x.repeat(1, 3, 1, 1), o[6], o[7], o[8], b["label"] == 2, 0.1)[0]
+    crf_ref = gated_crf_loss(torch.softmax(o[0], 1), [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, x)[0]
+    # ---- HIP, eager, same masks
+    net = mk()
+    args = args_()
+    client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+    client.model.train()
+    client._ensure_optimizer().reset_round()
+    ops.set_dropout_mask_provider(lambda shape, p: torch.empty(shape).bernoulli_(1 - p))
+    try:
+        torch.manual_seed(3)
+        rec = _GraphStep()
+        client._iteration(*client._stage(b), rec)
+    finally:
+        ops.set_dropout_mask_provider(None)
+    assert abs(rec.loss_ce.item() - ce_ref.item()) < 1e-5
+    assert abs(rec.loss_crf.item() - crf_ref.item()) < 2e-5 * max(1.0, abs(crf_ref.item()))
+    assert abs(rec.loss_tree.item() - tree_ref.item()) < 1e-4 * max(1.0, abs(tree_ref.item())), (rec.loss_tree.item(), tree_ref.item())
+    # ---- graph replay == eager over 4 iterations (device RNG dropout)
+    finals, losses = [], []
+    for use_graph in (False, True):
+        a2 = args_(use_graph=use_graph)
+        ops.manual_seed(1)
+        net2 = mk()
+        c2 = MyClient(a2, MyModel(a2, net2, batches, batches), batches, batches)
+        c2._train({"iter_global": 4, "iters": 4, "eval_iters": 8, "batch_size": 4, "stage": "fit"})
+        finals.append(net2.flat_state.clone())
+        losses.append(list(c2.last_losses))
+    assert all(np.isfinite(losses[0])) and np.allclose(losses[0][:2], losses[1][:2], atol=2e-5), (losses[0], losses[1])
+    assert np.allclose(losses[0], losses[1], atol=5e-3)
