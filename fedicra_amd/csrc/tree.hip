@@ -275,38 +275,85 @@ __global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float*
   }
 }
 
-// ---- recursions: one workgroup per (image, channel); the nodes of one BFS level are independent
-__global__ __launch_bounds__(256) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const int* __restrict__ sidx, const int* __restrict__ schild,
-                                                           const int* __restrict__ levels, int C, int V,
-                                                           float* __restrict__ out) {
-  const int b = blockIdx.x, c = blockIdx.y;
+// ---- recursions: one workgroup per (image, channel); the nodes of one BFS level are independent.
+// The trees are deep and thin (256^2 images: 1200-2100 levels of ~40 nodes), so a recursion is a chain of L dependent
+// steps and its speed is the latency of ONE step.  Two things keep a step short: the value a node needs from the
+// neighbouring level (its parent's / its children's result) is kept in LDS (`lvl`, double-buffered by level parity;
+// levels wider than TREE_CAP fall back to global memory), and everything that does NOT depend on the previous level
+// (indices, weights, inputs of the next level) is loaded into registers one level ahead, before the barrier.
+#define TREE_CAP 4096
+#define TREE_RT 256      // threads of a recursion workgroup
+
+__global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const int* __restrict__ sidx, const int* __restrict__ schild,
+                                                               const int* __restrict__ levels, int C, int V,
+                                                               float* __restrict__ out) {
+  __shared__ float lvl[2][TREE_CAP];
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   const int* si = sidx + (size_t)b * V;
-  const int* sc = schild + (size_t)b * V * 4;
+  const int4* sc = reinterpret_cast<const int4*>(schild + (size_t)b * V * 4);
   const int* lv = levels + (size_t)b * (V + 2);
   const float* wb = w + (size_t)b * V;
   const float* xb = x ? x + ((size_t)b * C + c) * V : nullptr;
   float* ob = out + ((size_t)b * C + c) * V;
   const int L = lv[0];
+  // registers of the node this thread handles in the level being processed (first 256 nodes of a level)
+  int4 ch = make_int4(0, 0, 0, 0);
+  float xin = 0.f, wch[4] = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch = [&](int l) {
+    if (l < 0) return;
+    const int i = lv[1 + l] + tid;
+    if (i < lv[2 + l]) {
+      ch = sc[i];
+      xin = xb ? xb[si[i]] : 1.0f;
+      wch[0] = ch.x > 0 ? wb[ch.x] : 0.f;
+      wch[1] = ch.y > 0 ? wb[ch.y] : 0.f;
+      wch[2] = ch.z > 0 ? wb[ch.z] : 0.f;
+      wch[3] = ch.w > 0 ? wb[ch.w] : 0.f;
+    }
+  };
+  prefetch(L - 1);
   for (int l = L - 1; l >= 0; --l) {
     const int lo = lv[1 + l], hi = lv[2 + l];
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const int clo = hi, chi = l + 1 < L ? lv[3 + l] : hi;        // the children live in level l+1 = [hi, lv[3+l])
+    const float* below = lvl[(l + 1) & 1];
+    float* mine = lvl[l & 1];
+    const bool cached = chi - clo <= TREE_CAP;
+    auto child_val = [&](int cpos) { return cached ? below[cpos - clo] : ob[cpos]; };
+    {
+      const int i = lo + tid;
+      if (i < hi) {
+        float s = xin;
+        if (ch.x > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.x), wch[0]));
+        if (ch.y > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.y), wch[1]));
+        if (ch.z > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.z), wch[2]));
+        if (ch.w > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.w), wch[3]));
+        ob[i] = s;
+        if (tid < TREE_CAP) mine[tid] = s;
+      }
+    }
+    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {     // wide levels: the rest without prefetch
+      const int4 c4 = sc[i];
       float s = xb ? xb[si[i]] : 1.0f;
+      const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
       for (int q = 0; q < 4; ++q) {
-        const int ch = sc[i * 4 + q];
-        if (ch <= 0) break;
-        s = __fadd_rn(s, __fmul_rn(ob[ch], wb[ch]));
+        if (cc[q] <= 0) break;
+        s = __fadd_rn(s, __fmul_rn(child_val(cc[q]), wb[cc[q]]));
       }
       ob[i] = s;
+      if (i - lo < TREE_CAP) mine[i - lo] = s;
     }
+    prefetch(l - 1);
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void tree_prop_down_kernel(const float* __restrict__ xs, const float* __restrict__ w,
-                                                             const int* __restrict__ sidx, const int* __restrict__ spar,
-                                                             const int* __restrict__ levels, int C, int V,
-                                                             float* __restrict__ out) {
-  const int b = blockIdx.x, c = blockIdx.y;
+
+__global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __restrict__ xs, const float* __restrict__ w,
+                                                                 const int* __restrict__ sidx, const int* __restrict__ spar,
+                                                                 const int* __restrict__ levels, int C, int V,
+                                                                 float* __restrict__ out) {
+  __shared__ float lvl[2][TREE_CAP];
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   const int* si = sidx + (size_t)b * V;
   const int* sp = spar + (size_t)b * V;
   const int* lv = levels + (size_t)b * (V + 2);
@@ -314,27 +361,54 @@ __global__ __launch_bounds__(256) void tree_prop_down_kernel(const float* __rest
   const float* xb = xs + ((size_t)b * C + c) * V;
   float* ob = out + ((size_t)b * C + c) * V;
   const int L = lv[0];
+  int p = 0, vtx = 0;
+  float xi = 0.f, wi = 0.f;
+  auto prefetch = [&](int l) {
+    if (l >= L) return;
+    const int i = lv[1 + l] + tid;
+    if (i < lv[2 + l]) {
+      p = sp[i];
+      vtx = si[i];
+      xi = xb[i];
+      wi = i == 0 ? 0.f : wb[i];                 // the root's edge weight counts as 0 (refine.cu:43-46)
+    }
+  };
+  prefetch(0);
   for (int l = 0; l < L; ++l) {
     const int lo = lv[1 + l], hi = lv[2 + l];
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
-      if (i == 0) {
-        ob[si[0]] = xb[0];                          // the root's edge weight counts as 0 (refine.cu:43-46)
-      } else {
-        const float wi = wb[i];
-        ob[si[i]] = __fadd_rn(__fmul_rn(xb[i], __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(ob[si[sp[i]]], wi));
+    const int plo = l > 0 ? lv[l] : 0;                           // the parents live in level l-1 = [lv[l], lo)
+    const float* above = lvl[(l + 1) & 1];
+    float* mine = lvl[l & 1];
+    const bool cached = lo - plo <= TREE_CAP;
+    auto parent_val = [&](int ppos) { return l == 0 ? 0.f : (cached ? above[ppos - plo] : ob[si[ppos]]); };
+    {
+      const int i = lo + tid;
+      if (i < hi) {
+        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(parent_val(p), wi));
+        ob[vtx] = v;
+        if (tid < TREE_CAP) mine[tid] = v;
       }
     }
+    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {
+      const float w2 = wb[i];
+      const float v = __fadd_rn(__fmul_rn(xb[i], __fsub_rn(1.0f, __fmul_rn(w2, w2))), __fmul_rn(parent_val(sp[i]), w2));
+      ob[si[i]] = v;
+      if (i - lo < TREE_CAP) mine[i - lo] = v;
+    }
+    prefetch(l + 1);
     __syncthreads();
   }
 }
+
 // refine.cu:136-199: grad[cur] = in_grad[cur]*(out_data[par] - w*in_data[cur]) + in_data[cur]*(G[par] - w*in_grad[cur]),
 // G = in_grad propagated root->leaf in place.  in_data/out_data have Cd channels (channel k % Cd), gradients Cg.
-__global__ __launch_bounds__(256) void tree_grad_rec_kernel(const float* __restrict__ in_data, float* __restrict__ in_grad,
-                                                            const float* __restrict__ out_data, const float* __restrict__ w,
-                                                            const int* __restrict__ sidx, const int* __restrict__ spar,
-                                                            const int* __restrict__ levels, int Cd, int Cg, int V,
-                                                            float* __restrict__ grad) {
-  const int b = blockIdx.x, k = blockIdx.y;
+__global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __restrict__ in_data, float* __restrict__ in_grad,
+                                                                const float* __restrict__ out_data,
+                                                                const float* __restrict__ w, const int* __restrict__ sidx,
+                                                                const int* __restrict__ spar, const int* __restrict__ levels,
+                                                                int Cd, int Cg, int V, float* __restrict__ grad) {
+  __shared__ float lvl[2][TREE_CAP];
+  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
   const int Cmax = Cd > Cg ? Cd : Cg;
   const int* si = sidx + (size_t)b * V;
   const int* sp = spar + (size_t)b * V;
@@ -345,18 +419,52 @@ __global__ __launch_bounds__(256) void tree_grad_rec_kernel(const float* __restr
   float* igb = in_grad + ((size_t)b * Cg + k % Cg) * V;
   float* gb = grad + ((size_t)b * Cmax + k) * V;
   const int L = lv[0];
+  int p = 0;
+  float wi = 0.f, ig = 0.f, id = 0.f, od = 0.f;
+  auto prefetch = [&](int l) {
+    if (l >= L) return;
+    const int i = lv[1 + l] + tid;
+    if (i < lv[2 + l] && i > 0) {
+      p = sp[i];
+      wi = wb[i];
+      ig = igb[i];                 // not yet propagated: level l is only written when level l is processed
+      id = idb[i];
+      od = odb[si[p]];
+    }
+  };
+  prefetch(0);
   for (int l = 0; l < L; ++l) {
     const int lo = lv[1 + l], hi = lv[2 + l];
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
-      if (i == 0) {
-        gb[0] = 0.f;
-      } else {
-        const int p = sp[i];
-        const float wi = wb[i], ig = igb[i], id = idb[i], gp = igb[p];     // igb[p]: already propagated (previous level)
-        gb[i] = ig * (odb[si[p]] - wi * id) + id * (gp - wi * ig);
-        igb[i] = ig * (1.0f - wi * wi) + gp * wi;
+    const int plo = l > 0 ? lv[l] : 0;
+    const float* above = lvl[(l + 1) & 1];
+    float* mine = lvl[l & 1];
+    const bool cached = lo - plo <= TREE_CAP;
+    auto parent_g = [&](int ppos) { return cached ? above[ppos - plo] : igb[ppos]; };
+    {
+      const int i = lo + tid;
+      if (i < hi) {
+        float G;
+        if (i == 0) {
+          gb[0] = 0.f;
+          G = igb[0];                                              // the root's gradient stays as aggregated
+        } else {
+          const float gp = parent_g(p);
+          gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
+          G = ig * (1.0f - wi * wi) + gp * wi;
+          igb[i] = G;
+        }
+        if (tid < TREE_CAP) mine[tid] = G;
       }
     }
+    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {
+      const int pp = sp[i];
+      const float w2 = wb[i], g2 = igb[i], d2 = idb[i], gp = parent_g(pp);
+      gb[i] = g2 * (odb[si[pp]] - w2 * d2) + d2 * (gp - w2 * g2);
+      const float G = g2 * (1.0f - w2 * w2) + gp * w2;
+      igb[i] = G;
+      if (i - lo < TREE_CAP) mine[i - lo] = G;
+    }
+    prefetch(l + 1);
     __syncthreads();
   }
 }
@@ -425,7 +533,7 @@ extern "C" int fi_tree_aggr_up(const float* x, const float* w, const int* sorted
                                const int* levels, int B, int C, int V, float* out, void* stream) {
   if (!w || !sorted_index || !sorted_child || !levels || !out) return FI_ERR_NULL;
   if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
-  hipLaunchKernelGGL(tree_aggr_up_kernel, dim3(B, C), dim3(256), 0, (hipStream_t)stream, x, w, sorted_index, sorted_child,
+  hipLaunchKernelGGL(tree_aggr_up_kernel, dim3(B, C), dim3(TREE_RT), 0, (hipStream_t)stream, x, w, sorted_index, sorted_child,
                      levels, C, V, out);
   FI_CHECK_LAUNCH();
   return 0;
@@ -434,7 +542,7 @@ extern "C" int fi_tree_prop_down(const float* x_sorted, const float* w, const in
                                  const int* levels, int B, int C, int V, float* out, void* stream) {
   if (!x_sorted || !w || !sorted_index || !sorted_parent || !levels || !out) return FI_ERR_NULL;
   if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
-  hipLaunchKernelGGL(tree_prop_down_kernel, dim3(B, C), dim3(256), 0, (hipStream_t)stream, x_sorted, w, sorted_index,
+  hipLaunchKernelGGL(tree_prop_down_kernel, dim3(B, C), dim3(TREE_RT), 0, (hipStream_t)stream, x_sorted, w, sorted_index,
                      sorted_parent, levels, C, V, out);
   FI_CHECK_LAUNCH();
   return 0;
@@ -444,7 +552,7 @@ extern "C" int fi_tree_grad_rec(const float* in_data, float* in_grad, const floa
                                 int V, float* grad, void* stream) {
   if (!in_data || !in_grad || !out_data || !w || !sorted_index || !sorted_parent || !levels || !grad) return FI_ERR_NULL;
   if (B < 1 || Cd < 1 || Cg < 1 || V < 1) return FI_ERR_SHAPE;
-  hipLaunchKernelGGL(tree_grad_rec_kernel, dim3(B, Cd > Cg ? Cd : Cg), dim3(256), 0, (hipStream_t)stream, in_data, in_grad,
+  hipLaunchKernelGGL(tree_grad_rec_kernel, dim3(B, Cd > Cg ? Cd : Cg), dim3(TREE_RT), 0, (hipStream_t)stream, in_data, in_grad,
                      out_data, w, sorted_index, sorted_parent, levels, Cd, Cg, V, grad);
   FI_CHECK_LAUNCH();
   return 0;
