@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -480,6 +480,15 @@ def gatedcrf_fwd(y_nhwc, feat_nhwc, radius, weights, sigma_xy, sigma_sample, pro
     arr = lambda v: (C.c_float * nk)(*[float(t) for t in v])
     _chk(lib().fi_gatedcrf_fwd(ptr(y_nhwc), ptr(_dev(feat_nhwc)), N, H, W, Cc, F_, int(radius), nk, arr(weights),
                                arr(sigma_xy), arr(sigma_sample), ptr(prod), ptr(acc), stream()), "fi_gatedcrf_fwd")
+
+
+def augment2d(src_img, src_lab, ip, dp, out_img, out_lab, img_cval, lab_cval):
+    n, Cc, H, W = _dev(src_img).shape
+    B = ip.shape[0]
+    assert src_img.dtype == torch.float32 and src_lab.dtype == torch.uint8 and ip.dtype == torch.int32
+    assert dp.dtype == torch.float64 and tuple(out_img.shape) == (B, Cc, H, W) and tuple(out_lab.shape) == (B, H, W)
+    _chk(lib().fi_augment2d(ptr(src_img), ptr(src_lab), ptr(_dev(ip)), ptr(_dev(dp)), ptr(out_img), ptr(out_lab), B, Cc, H, W,
+                            C.c_float(img_cval), int(lab_cval), stream()), "fi_augment2d")
 
 
 def seg_borders(logits_hwc, gt_u8, k, pred_list, gt_list, counts):

@@ -263,6 +263,19 @@ int fi_seg_borders(const float* logits, const uint8_t* gt, int H, int W, int C, 
 int fi_surface_distances(const int* from_list, const int* to_list, const int* counts, int from_index, int to_index,
                          int W, int max_from, double* out, void* stream);
 
+/* Training-time augmentation of a batch drawn from an HBM-resident data set
+ * (/root/reference/code/dataloaders/dataset.py:190-256: RandomGenerator = random_rot_flip then random_rotate, each
+ * optional per sample), as ONE gather: out[b] = rotate(flip(rot90(src[ip[b][0]], k), axis), angle).
+ *   src_img fp32 [n][C][H][W], src_lab uint8 [n][H][W] -> out_img fp32 [B][C][H][W], out_lab uint8 [B][H][W]
+ *   ip int32 [B][4] = { source sample, k of np.rot90 (0..3; -1: no rot/flip), spatial flip axis (0 rows, 1 columns),
+ *                       rotate (0/1) }
+ *   dp fp64  [B][6] = { m00, m01, m10, m11, off0, off1 } of scipy.ndimage.rotate(order=0, reshape=False): the input
+ *                     coordinate of output pixel (i,j) is ((0 + i*m0) + j*m1) + off in fp64 WITHOUT contraction,
+ *                     outside [0, len-1] -> cval (img_cval / lab_cval), else floor(x + 0.5) -- bit-exact with scipy.
+ * Odd k needs H == W (rot90 would change the shape): the caller checks, the entry cannot see ip. */
+int fi_augment2d(const float* src_img, const uint8_t* src_lab, const int* ip, const double* dp, float* out_img,
+                 uint8_t* out_lab, int B, int C, int H, int W, float img_cval, int lab_cval, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ----------------
  * torch.optim.AdamW(betas, eps, weight_decay, amsgrad=False) as created at flower_pCE_2D.py:55.
  * All scalars live on the device so that a captured hipGraph can be replayed:

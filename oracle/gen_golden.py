@@ -340,9 +340,33 @@ def g10_gatedcrf():
     save("g10_gatedcrf.npz", **d)
 
 
+def g11_augment():
+    """Training-time augmentation (section 8f-3): the reference's RandomGenerator, seeded, on small images."""
+    import random
+    import dataloaders.dataset as D
+    rng = np.random.default_rng(11)
+    d = {}
+    for name, cls_, shape in [("faz", "faz", (33, 33)), ("odoc", "odoc", (3, 24, 24)), ("polyp", "polyp", (3, 20, 20))]:
+        n = 24
+        imgs = rng.random((n,) + shape, dtype=np.float32)
+        labs = rng.integers(0, D_NCLS[cls_] + 1, (n,) + shape[-2:]).astype(np.uint8)
+        random.seed(100 + len(name))
+        np.random.seed(200 + len(name))
+        gen = D.RandomGenerator(list(shape[-2:]), img_class=cls_)
+        outs = [gen({"image": imgs[i], "label": labs[i]}) for i in range(n)]
+        d[f"{name}/image"], d[f"{name}/label"] = imgs, labs
+        d[f"{name}/out_image"] = np.stack([o["image"].numpy() for o in outs])
+        d[f"{name}/out_label"] = np.stack([o["label"].numpy() for o in outs])
+        d[f"{name}/seeds"] = np.array([100 + len(name), 200 + len(name)])
+    save("g11_augment.npz", **d)
+
+
+D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment"]
     for w in which:
         globals()[w]()

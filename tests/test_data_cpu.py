@@ -1,0 +1,90 @@
+"""Host logic of the data path: RNG consumption, gather tables, directory layout.  CPU only."""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import augment_ref as A
+
+
+def test_random_generator_draws_consume_rng_like_the_reference():
+    """Same seeds -> the draws of oracle.augment_ref.draw (itself pinned to the reference's outputs by g11)."""
+    from fedicra_amd.dataloaders import RandomGenerator
+    for cls_ in ("faz", "odoc", "polyp"):
+        random.seed(5)
+        np.random.seed(6)
+        want = [A.draw(cls_) for _ in range(200)]
+        tail = (random.random(), np.random.randint(0, 1 << 30))
+        random.seed(5)
+        np.random.seed(6)
+        gen = RandomGenerator([32, 32], cls_)
+        assert [gen.draw() for _ in range(200)] == want
+        assert (random.random(), np.random.randint(0, 1 << 30)) == tail
+        assert {d[0] for d in want} == {-1, 0, 1, 2, 3} and {d[1] for d in want} == {0, 1}
+
+
+def test_gather_tables_match_scipys_rotation_parameters():
+    from fedicra_amd.dataloaders import RandomGenerator
+    draws = [(-1, 0, None), (2, 1, -45), (1, 0, 44), (3, 1, 0), (0, 0, None)]
+    ip, dp = RandomGenerator.params([4, 3, 2, 1, 0], draws, 37, 37)
+    assert ip.tolist() == [[4, -1, 0, 0], [3, 2, 1, 1], [2, 1, 0, 1], [1, 3, 1, 1], [0, 0, 0, 0]]
+    for b, (_, _, ang) in enumerate(draws):
+        if ang is None:
+            assert not dp[b].any()
+        else:
+            M, off = A.rot_params(ang, 37, 37)
+            np.testing.assert_array_equal(dp[b], [M[0, 0], M[0, 1], M[1, 0], M[1, 1], off[0], off[1]])
+    with pytest.raises(ValueError):
+        RandomGenerator.params([0], [(1, 0, None)], 40, 28)          # odd quarter turn of a non-square image
+    RandomGenerator.params([0], [(2, 0, 10)], 40, 28)
+
+
+def test_base_datasets_layout_and_errors(tmp_path, monkeypatch):
+    """DomainN/{train,test}/*.h5 listing (dataset.py:98-175), train label = sup_type, val label = 'mask' (:86-96)."""
+    from fedicra_amd.dataloaders import BaseDataSets
+    store = {}
+    for d in range(1, 6):
+        for split, n in (("train", 3), ("test", 2)):
+            os.makedirs(tmp_path / f"Domain{d}" / split)
+            for i in range(n):
+                p = tmp_path / f"Domain{d}" / split / f"s{i}.h5"
+                p.write_bytes(b"")
+                store[str(p)] = {"image": np.full((4, 4), d + 0.1 * i), "mask": np.full((4, 4), 1, np.uint8),
+                                 "scribble": np.full((4, 4), 2, np.uint8)}
+
+    class File(dict):
+        def __init__(self, path, mode):
+            super().__init__(store[os.path.normpath(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    tr = BaseDataSets(str(tmp_path), "train", None, "client2", "scribble", "faz")
+    va = BaseDataSets(str(tmp_path), "val", None, "client2", "scribble", "faz")
+    assert len(tr) == 3 and len(va) == 2 and all(s.startswith("Domain2/train/") for s in tr.sample_list)
+    assert tr[0]["label"].max() == 2 and va[0]["label"].max() == 1 and tr[1]["idx"] == 1
+    assert len(BaseDataSets(str(tmp_path), "train", None, "client_all", "scribble", "faz")) == 15
+    with pytest.raises(KeyError):
+        BaseDataSets(str(tmp_path), "train", None, "client9", "scribble", "faz")
+    with pytest.raises(NotImplementedError):
+        BaseDataSets(str(tmp_path), "train", None, "client1", "random_walker", "faz")
+    monkeypatch.setitem(sys.modules, "h5py", None)                    # import h5py -> ImportError
+    with pytest.raises(ImportError, match="h5py"):
+        BaseDataSets(str(tmp_path), "train", None, "client1", "scribble", "faz")
+
+
+def test_two_stream_batch_sampler():
+    from fedicra_amd.dataloaders import TwoStreamBatchSampler
+    np.random.seed(0)
+    s = TwoStreamBatchSampler(list(range(10)), list(range(100, 104)), batch_size=4, secondary_batch_size=1)
+    batches = list(s)
+    assert len(s) == 3 and len(batches) == 3
+    assert all(len(b) == 4 and sum(x >= 100 for x in b) == 1 for b in batches)
+    assert len({x for b in batches for x in b if x < 100}) == 9

@@ -1,0 +1,128 @@
+"""GPU parity of the HBM-resident data path: the augmentation gather against the CPU oracle
+(numpy rot90/flip + the scipy-pinned nearest-neighbour rotation), the reference-generated fixture, and a torch
+DataLoader(num_workers=0) over the oracle transform.  Bit-exact throughout (byte / index work)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_ref as A
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _set(cls_, n, shape, seed):
+    rng = np.random.default_rng(seed)
+    imgs = rng.random((n,) + shape, dtype=np.float32)
+    labs = rng.integers(0, A.ROT_CVAL[cls_][1] + 1, (n,) + shape[-2:]).astype(np.uint8)
+    return imgs, labs
+
+
+@pytest.mark.parametrize("cls_,shape", [("faz", (256, 256)), ("faz", (33, 33)), ("odoc", (3, 48, 48)), ("polyp", (3, 20, 20))])
+def test_augment_gather_every_parameter_combination(cls_, shape):
+    """All 4 quarter turns x 2 flip axes x {no rotation, every angle in [-45, 45)} -- one launch, vs the oracle."""
+    from fedicra_amd.dataloaders import BaseDataSets, RandomGenerator
+    imgs, labs = _set(cls_, 5, shape, 3)
+    gen = RandomGenerator(list(shape[-2:]), cls_)
+    res = BaseDataSets.from_arrays(imgs, labs, img_class=cls_).resident(DEV)
+    draws = [(k, ax, ang) for k in (-1, 0, 1, 2, 3) for ax in (0, 1) for ang in [None] + list(range(-45, 45))
+             if not (k == -1 and ax == 1)]
+    srcs = [i % 5 for i in range(len(draws))]
+    out_i, out_l = gen.apply(res, srcs, draws)
+    out_i, out_l = out_i.cpu().numpy(), out_l.cpu().numpy()
+    for b, (s, d) in enumerate(zip(srcs, draws)):
+        wi, wl = A.apply(imgs[s], labs[s], cls_, *d)
+        np.testing.assert_array_equal(out_i[b], wi, err_msg=str(d))
+        np.testing.assert_array_equal(out_l[b], wl, err_msg=str(d))
+
+
+def test_augment_non_square_rotation_and_half_turn():
+    from fedicra_amd.dataloaders import BaseDataSets, RandomGenerator
+    imgs, labs = _set("faz", 2, (40, 28), 4)
+    gen = RandomGenerator([40, 28], "faz")
+    res = BaseDataSets.from_arrays(imgs, labs, img_class="faz").resident(DEV)
+    draws = [(k, ax, ang) for k in (-1, 0, 2) for ax in (0, 1) for ang in (None, -45, -13, 0, 7, 44)]
+    out_i, out_l = gen.apply(res, [b % 2 for b in range(len(draws))], draws)
+    for b, d in enumerate(draws):
+        wi, wl = A.apply(imgs[b % 2], labs[b % 2], "faz", *d)
+        np.testing.assert_array_equal(out_i[b].cpu().numpy(), wi)
+        np.testing.assert_array_equal(out_l[b].cpu().numpy(), wl)
+    with pytest.raises(ValueError):
+        gen.apply(res, [0], [(3, 0, None)])
+
+
+def test_random_generator_reproduces_the_reference_fixture(golden):
+    """Per-sample protocol, the reference's seeds -> the reference's RandomGenerator outputs (g11)."""
+    from fedicra_amd.dataloaders import RandomGenerator
+    g = golden("g11_augment.npz")
+    for name in ("faz", "odoc", "polyp"):
+        random.seed(int(g[f"{name}/seeds"][0]))
+        np.random.seed(int(g[f"{name}/seeds"][1]))
+        gen = RandomGenerator(list(g[f"{name}/image"].shape[-2:]), name)
+        for i in range(g[f"{name}/image"].shape[0]):
+            out = gen({"image": g[f"{name}/image"][i], "label": g[f"{name}/label"][i]})
+            assert out["image"].dtype == torch.float32 and out["label"].dtype == torch.uint8
+            np.testing.assert_array_equal(out["image"].cpu().numpy(), g[f"{name}/out_image"][i])
+            np.testing.assert_array_equal(out["label"].cpu().numpy(), g[f"{name}/out_label"][i])
+
+
+def test_device_loader_equals_a_torch_dataloader_over_the_oracle_transform():
+    """Shuffled, augmented epochs: DeviceLoader vs torch DataLoader(shuffle=True, num_workers=0) whose dataset applies
+    the oracle transform -- same torch / python / numpy seeds, two epochs, ragged last batch."""
+    from torch.utils.data import DataLoader, Dataset
+    from fedicra_amd.dataloaders import BaseDataSets, DeviceLoader, RandomGenerator
+    imgs, labs = _set("faz", 29, (64, 64), 9)
+
+    class RefSet(Dataset):
+        def __len__(self):
+            return len(imgs)
+
+        def __getitem__(self, i):
+            out, _ = A.random_generator({"image": imgs[i], "label": labs[i]}, "faz")
+            return {"image": torch.from_numpy(out["image"]), "label": torch.from_numpy(out["label"]), "idx": i}
+
+    def seed():
+        torch.manual_seed(3)
+        random.seed(4)
+        np.random.seed(5)
+
+    seed()
+    want = [b for _ in range(2) for b in DataLoader(RefSet(), batch_size=12, shuffle=True, num_workers=0)]
+    seed()
+    ds = BaseDataSets.from_arrays(imgs, labs, split="train", transform=RandomGenerator([64, 64], "faz"), img_class="faz")
+    loader = DeviceLoader(ds, batch_size=12, shuffle=True, device=DEV)
+    got = [b for _ in range(2) for b in loader]
+    assert len(loader) == 3 and len(got) == len(want) == 6 and got[2]["image"].shape == (5, 64, 64)
+    for a, b in zip(got, want):
+        assert a["idx"].tolist() == b["idx"].tolist()
+        assert torch.equal(a["image"].cpu(), b["image"]) and torch.equal(a["label"].cpu(), b["label"])
+    val = DeviceLoader(BaseDataSets.from_arrays(imgs, labs, split="val", img_class="faz"), batch_size=1, device=DEV)
+    first = next(iter(val))
+    assert len(val) == 29 and torch.equal(first["image"].cpu(), torch.from_numpy(imgs[:1]))
+
+
+def test_trainer_runs_on_a_device_loader():
+    """flower_pCE_2D.MyClient._train fed by the resident loader (stands where the DataLoader stands, :303-306): the
+    captured training step consumes the loader's device batches; the loss falls on a learnable phantom."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.dataloaders import BaseDataSets, DeviceLoader, RandomGenerator
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from fedicra_amd.synth import phantom_batch
+    x, y, _ = phantom_batch(24, 64, 1, 2, cid=0, labeled_frac=0.2)
+    ds = BaseDataSets.from_arrays(x, y, split="train", transform=RandomGenerator([64, 64], "faz"), img_class="faz")
+    args = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=0, min_num_clients=1, num_classes=2,
+                              img_class="faz", base_lr=0.01, max_iterations=30000, iters=12, rep_iters=3, alpha=0.5,
+                              snapshot_path=None, use_graph=True)
+    ops.manual_seed(1)
+    torch.manual_seed(0)
+    net = UNet(1, 2).cuda()
+    tl = DeviceLoader(ds, batch_size=12, shuffle=True, device=DEV)
+    client = MyClient(args, MyModel(args, net, tl, tl), tl, tl)
+    loss0, _ = client._train({"iter_global": 0, "iters": 2, "eval_iters": 1, "batch_size": 12, "stage": 1})
+    loss1, _ = client._train({"iter_global": 1, "iters": 12, "eval_iters": 1, "batch_size": 12, "stage": 1})
+    assert np.isfinite(loss0) and np.isfinite(loss1) and loss1 < loss0
