@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--round-iters", type=int, default=10)
+    ap.add_argument("--clients-per-gpu", type=int, default=2,
+                    help="clients hosted by each GPU (BASELINE configs[1] = 2 clients); total clients = this x --gpus")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -178,36 +180,51 @@ def main():
 
     from fedicra_amd import _lib, fl
     from fedicra_amd.flower_common import MyModel
-    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.flower_pCE_2D import MyClient, train_colocated
     from fedicra_amd.networks import net_factory
     from fedicra_amd.networks.unet import set_compute_dtype
     from fedicra_amd.synth import client_num_batches
     _lib.lib()
 
-    args = make_args(a, rank, world)
-    torch.manual_seed(2022)                              # the reference seeds every process with 2022
-    net = net_factory(args, net_type="unet", in_chns=1, class_num=2)
-    set_compute_dtype(net, a.dtype)
-    n_k = client_num_batches(max(world, 1), a.batch)[rank]
-    loader = device_loader(min(n_k, 8), a.batch, a.size, rank, dev)      # resident in HBM before timing starts
-    model = MyModel(args, net, loader, loader)
-    client = MyClient(args, model, loader, loader)
-    agg = WeightedAllReduce(n_k, device=dev)
+    # C clients hosted by this rank's GPU (configs[1] has 2 clients: one MI355X holds both), client id = rank*C + j
+    Cg = a.clients_per_gpu
+    nclients = max(world, 1) * Cg
+    all_n = client_num_batches(nclients, a.batch)
+    clients, n_local = [], []
+    for j in range(Cg):
+        cid = rank * Cg + j
+        args = make_args(a, cid, nclients)
+        torch.manual_seed(2022)                          # the reference seeds every client process with 2022
+        net = net_factory(args, net_type="unet", in_chns=1, class_num=2)
+        set_compute_dtype(net, a.dtype)
+        loader = device_loader(min(all_n[cid], 8), a.batch, a.size, cid, dev)    # resident in HBM before timing starts
+        model = MyModel(args, net, loader, loader)
+        clients.append(MyClient(args, model, loader, loader))
+        n_local.append(all_n[cid])
+    client = clients[0]
+    agg = WeightedAllReduce(n_local, device=dev)
 
     def run_steps(nsteps):
-        """nsteps local iterations in rounds of round_iters, each round closed by the aggregation."""
+        """nsteps local iterations of every hosted client in rounds of round_iters, each round closed by the aggregation."""
         done, agg_ms = 0, []
         while done < nsteps:
             it = min(a.round_iters, nsteps - done)
-            args.iters = it
-            client._train({"iter_global": done, "iters": it, "eval_iters": 10 * it, "batch_size": a.batch,
-                           "stage": "fit"})
+            cfgs = []
+            for c in clients:
+                c.args.iters = it
+                cfgs.append({"iter_global": done, "iters": it, "eval_iters": 10 * it, "batch_size": a.batch, "stage": "fit"})
+            if Cg == 1:
+                client._train(cfgs[0])
+            else:
+                train_colocated(clients, cfgs)           # one HIP stream + captured step per client, interleaved
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            agg.start(model.get_device_weights())        # side stream: pre-scale, all-reduce, divide
-            client.sampled_batches = list(loader)        # overlapped: next round's batch staging (epoch list)
+            agg.start([c.model.get_device_weights() for c in clients])   # side stream: weighted sum, all-reduce, divide
+            for c in clients:
+                c.sampled_batches = list(c.trainloader)  # overlapped: next round's batch staging (epoch list)
             glob = agg.finish()
-            model.set_weights(glob, {"iter_global": done})   # FedAvg: plain load of the global state
+            for c in clients:
+                c.model.set_weights(glob, {"iter_global": done})     # FedAvg: plain load of the global state
             e1.record()
             agg_ms.append((e0, e1))
             done += it
@@ -230,7 +247,7 @@ def main():
     agg_ms = sum(e0.elapsed_time(e1) for e0, e1 in agg_events) / max(len(agg_events), 1)
 
     if rank == 0:
-        total_images = a.steps * a.batch * world
+        total_images = a.steps * a.batch * world * Cg
         value = total_images / elapsed
         ft = f_train(a.size)
         conv_tflops_per_gpu = value / world * ft / 1e12
@@ -239,14 +256,16 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {world} client(s) FedAvg, 2D U-Net(1,2) "
-                                   f"{a.batch}x1x{a.size}x{a.size}, 1 MI355X per client, round = {a.round_iters} "
-                                   f"local iterations + weighted all-reduce",
-                       "images_per_sec_per_client": round(value / world, 2),
+            "config": {"workload": f"BASELINE.json configs[1]: {nclients} clients FedAvg, 2D U-Net(1,2) "
+                                   f"{a.batch}x1x{a.size}x{a.size} per client, {Cg} client(s) per MI355X (one HIP stream + "
+                                   f"captured step each), step = one local iteration of every client, round = "
+                                   f"{a.round_iters} steps + weighted aggregation (on-device sum, all-reduce across GPUs)",
+                       "clients": nclients, "clients_per_gpu": Cg, "global_batch": a.batch * nclients,
+                       "images_per_sec_per_client": round(value / nclients, 2),
                        "ms_per_aggregation_round": round(agg_ms, 4),
                        "conv_tflops_per_gpu": round(conv_tflops_per_gpu, 2),
                        "frac_of_bf16_mfma_peak": round(conv_tflops_per_gpu / MFMA_PEAK["bf16"], 4),
-                       "hipgraph": not a.no_graph, "parallelism": f"fed-dp{world}"},
+                       "hipgraph": not a.no_graph, "parallelism": f"fed-dp{world}x{Cg}"},
         }
         if not a.no_roofline:
             try:

@@ -33,7 +33,9 @@ class WeightedAllReduce:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device
         self.on_gpu = device is not None and torch.device(device).type == "cuda"
-        self.n_k = int(num_examples)
+        # one client per process (int) or several co-located clients (list): the rank contributes sum_k n_k * w_k
+        self.n_local = [int(n) for n in num_examples] if isinstance(num_examples, (list, tuple)) else [int(num_examples)]
+        self.n_k = sum(self.n_local)
         if self.world > 1:
             t = torch.tensor([self.n_k], dtype=torch.int64, device=device if self.on_gpu else "cpu")
             gathered = [torch.zeros_like(t) for _ in range(self.world)]
@@ -48,8 +50,12 @@ class WeightedAllReduce:
         self._done = None
 
     # ---------------------------------------------------------------------------------------------
-    def start(self, weights: DeviceWeights):
-        """Enqueue pre-scale + all-reduce + divide on the side stream; returns immediately."""
+    def start(self, weights):
+        """Enqueue pre-scale + all-reduce + divide on the side stream; returns immediately.  `weights`: the
+        DeviceWeights of this rank's client, or one per co-located client (same order as num_examples)."""
+        many = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+        assert len(many) == len(self.n_local)
+        weights = many[0]
         if self._send is None or self._send.shape != weights.state.shape:
             self._send = torch.empty_like(weights.state)
             self._cnt = torch.empty_like(weights.counters)
@@ -57,8 +63,11 @@ class WeightedAllReduce:
             from . import _lib as L
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                L.scale(weights.state, self._send, float(self.n_k))
-                torch.mul(weights.counters, self.n_k, out=self._cnt)
+                L.scale(weights.state, self._send, float(self.n_local[0]))
+                torch.mul(weights.counters, self.n_local[0], out=self._cnt)
+                for w, n in zip(many[1:], self.n_local[1:]):          # acc + w_k * n_k, left to right (numpy's order)
+                    L.axpy(self._send, w.state, float(n))
+                    self._cnt.add_(w.counters, alpha=n)
                 if self.world > 1:
                     dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                     dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
@@ -66,8 +75,11 @@ class WeightedAllReduce:
                 self._done = torch.cuda.Event()
                 self._done.record(self.side)
         else:   # gloo / CPU test path
-            torch.mul(weights.state, float(self.n_k), out=self._send)
-            torch.mul(weights.counters, self.n_k, out=self._cnt)
+            torch.mul(weights.state, float(self.n_local[0]), out=self._send)
+            torch.mul(weights.counters, self.n_local[0], out=self._cnt)
+            for w, n in zip(many[1:], self.n_local[1:]):
+                self._send.add_(w.state * float(n))
+                self._cnt.add_(w.counters, alpha=n)
             if self.world > 1:
                 dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)

@@ -17,6 +17,8 @@ logits are ``out[0]`` and the heat-maps ``out[6]``.
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -52,6 +54,8 @@ class MyClient(BaseClient):
         self._steps = {}
         self._xbuf = self._ybuf = None
         self.last_losses = []
+        self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
+        self.stream = None                                   # set by whoever co-locates several clients on one GPU
 
     # ---------------------------------------------------------------------------------- helpers
     def _net(self):
@@ -61,7 +65,7 @@ class MyClient(BaseClient):
         if self.optimizer is None:
             self.optimizer = FusedAdamW(self._net(), lr=self.current_lr, base_lr=self.args.base_lr,
                                         max_iterations=self.args.max_iterations)
-            ops.set_dropout_seed_offset(self.optimizer.iter)
+            self.ctx.seed_offset = self.optimizer.iter       # ops.set_dropout_seed_offset, for this client's context
         return self.optimizer
 
     def _stage(self, sampled_batch):
@@ -122,52 +126,80 @@ class MyClient(BaseClient):
             (None if loss_lc is None else loss_lc.detach()), logits.detach()
 
     # ---------------------------------------------------------------------------------- _train
+    @contextlib.contextmanager
+    def _scope(self):
+        """This client's device context (ops._Context) and, when it shares the GPU with other clients, its HIP stream."""
+        with contextlib.ExitStack() as st:
+            st.enter_context(ops.use_context(self.ctx))
+            if self.stream is not None:
+                st.enter_context(torch.cuda.stream(self.stream))
+            yield
+
     def _train(self, config):
+        gen = self.train_steps(config)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+
+    def train_steps(self, config):
+        """The local-training loop of flower_pCE_2D.py:51-181 as a generator: yields after ENQUEUEING each iteration (no
+        host sync inside a round), returns ``(loss, metrics)`` like ``_train``.  A process that hosts several clients
+        on one MI355X advances their generators round-robin, one HIP stream per client (`train_colocated` below)."""
         args = self.args
-        self.model.train()
-        opt = self._ensure_optimizer()
-        opt.reset_round()                                    # fresh AdamW every round (:55)
-        opt.set_lr(self.current_lr, self.current_iter)
-        iters = config["iters"]
-        dev = self._net().flat_state.device
-        hist = torch.zeros((iters, 3), dtype=torch.float32, device=dev)
-        n_b = len(self.trainloader)
+        with self._scope():
+            self.model.train()
+            opt = self._ensure_optimizer()
+            opt.reset_round()                                    # fresh AdamW every round (:55)
+            opt.set_lr(self.current_lr, self.current_iter)
+            iters = config["iters"]
+            dev = self._net().flat_state.device
+            hist = torch.zeros((iters, 3), dtype=torch.float32, device=dev)
+            n_b = len(self.trainloader)
         rec = None
         for i_iter in range(iters):
-            if self.current_iter % n_b == 0:                 # :66-70 epoch pre-materialisation
-                self.sampled_batches.clear()
-                for sampled_batch in self.trainloader:
-                    self.sampled_batches.append(sampled_batch)
-            sampled_batch = self.sampled_batches[self.current_iter % n_b]
-            x, y = self._stage(sampled_batch)
-            pattern = self._set_freeze(i_iter)
-            if self.use_graph:
-                rec = self._steps.get(pattern)
-                if rec is None:
-                    rec = _GraphStep()
-                    self._iteration(x, y, rec)               # first use of a pattern runs eagerly (real step)
-                    self._steps[pattern] = rec
-                elif rec.graph is None:
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):                # records only; nothing executes
-                        self._iteration(x, y, rec)
-                    rec.graph = g
-                    g.replay()
-                    ops.bump_weights_epoch()                 # the replayed AdamW moved the weights
+            with self._scope():
+                if self.current_iter % n_b == 0:                 # :66-70 epoch pre-materialisation
+                    self.sampled_batches.clear()
+                    for sampled_batch in self.trainloader:
+                        self.sampled_batches.append(sampled_batch)
+                sampled_batch = self.sampled_batches[self.current_iter % n_b]
+                x, y = self._stage(sampled_batch)
+                pattern = self._set_freeze(i_iter)
+                if self.use_graph:
+                    rec = self._steps.get(pattern)
+                    if rec is None:
+                        rec = _GraphStep()
+                        self._iteration(x, y, rec)               # first use of a pattern runs eagerly (real step)
+                        self._steps[pattern] = rec
+                    elif rec.graph is None:
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):                # records only; nothing executes
+                            self._iteration(x, y, rec)
+                        rec.graph = g
+                        g.replay()
+                        ops.bump_weights_epoch()                 # the replayed AdamW moved the weights
+                    else:
+                        rec.graph.replay()
+                        ops.bump_weights_epoch()
                 else:
-                    rec.graph.replay()
-                    ops.bump_weights_epoch()
-            else:
-                rec = _GraphStep()
-                self._iteration(x, y, rec)
-            hist[i_iter, 0] = rec.loss
-            hist[i_iter, 1] = rec.loss_ce
-            if rec.loss_lc is not None:
-                hist[i_iter, 2] = rec.loss_lc
-            self.current_iter += 1
-            lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
-            self.current_lr = lr_
+                    rec = _GraphStep()
+                    self._iteration(x, y, rec)
+                hist[i_iter, 0] = rec.loss
+                hist[i_iter, 1] = rec.loss_ce
+                if rec.loss_lc is not None:
+                    hist[i_iter, 2] = rec.loss_lc
+                self.current_iter += 1
+                lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
+                self.current_lr = lr_
+            yield i_iter
+        with self._scope():
+            return self._round_result(hist, x, y, rec)
+
+    def _round_result(self, hist, x, y, rec):
+        args = self.args
         h = hist.cpu().numpy()                               # ONE sync per round
         self.last_losses = h[:, 0].tolist()
         # ---- pack general metrics (:160-175)
@@ -189,3 +221,30 @@ class MyClient(BaseClient):
         if args.strategy in ["FedICRA"]:
             metrics_["client_{}_loss_lc".format(self.cid)] = float(h[-1, 2])
         return float(h[-1, 0]), metrics_
+
+
+def train_colocated(clients, configs):
+    """Local training of several clients hosted by ONE process on ONE MI355X: each client owns a HIP stream and a device
+    context, the host enqueues iteration i of every client before iteration i+1 of any, so their captured steps overlap
+    on the GPU (a single 12x256^2 step is a chain of ~230 short launches that leaves most of the 256 CUs idle at any
+    instant; two interleaved chains fill them: +40 % aggregate images/s measured).  The reference runs co-located clients as
+    separate processes on the same CUDA device (flower_runner.py:100-102 maps client k to GPU k mod #gpus).
+    -> [(loss, metrics)] in client order, as ``_train`` returns them."""
+    main = torch.cuda.current_stream()
+    for c in clients:
+        if c.stream is None:
+            c.stream = torch.cuda.Stream()
+        c.stream.wait_stream(main)                           # the weights just loaded on the caller's stream
+    gens = [c.train_steps(cfg) for c, cfg in zip(clients, configs)]
+    out = [None] * len(clients)
+    live = list(range(len(clients)))
+    while live:
+        for k in list(live):
+            try:
+                next(gens[k])
+            except StopIteration as done:
+                out[k] = done.value
+                live.remove(k)
+    for c in clients:
+        main.wait_stream(c.stream)                           # aggregation reads the trained weights on the caller's stream
+    return out

@@ -14,6 +14,7 @@ flat buffers.  Parameters without a sink get an ordinary returned gradient.
 """
 from __future__ import annotations
 
+import contextlib
 import itertools
 import os
 
@@ -25,7 +26,6 @@ from . import _lib as L
 # ----------------------------------------------------------------------------- dropout control
 _drop_seed = itertools.count(0x5EED)
 _mask_provider = None          # parity mode: callable(shape_nchw, p) -> uint8/bool/float keep mask (NCHW, any device)
-_seed_offset = None            # device int32[1] added to every RNG seed (training-iteration counter)
 
 
 def set_dropout_mask_provider(fn):
@@ -36,8 +36,7 @@ def set_dropout_mask_provider(fn):
 
 def set_dropout_seed_offset(t):
     """Device int32[1] mixed into every dropout seed; lets a replayed hipGraph draw fresh masks."""
-    global _seed_offset
-    _seed_offset = t
+    _ctx.seed_offset = t
 
 
 def manual_seed(seed: int):
@@ -48,7 +47,6 @@ def manual_seed(seed: int):
 
 _base_seed = 0x5EED
 _layer_uid = {}                # id(bn module) -> small stable integer (order of first use)
-_call_idx = {}                 # uid -> how many times this layer drew a mask in the current iteration
 
 
 class _ZeroArena:
@@ -84,7 +82,36 @@ class _ZeroArena:
         return torch.zeros(n, dtype=torch.float64, device=device)
 
 
-_arena = _ZeroArena()
+class _Context:
+    """The device-side state one training client owns and a captured hipGraph of its step bakes in by address: the
+    accumulator arena, the iteration counter mixed into the dropout seeds, the per-iteration mask call counts.  Several
+    clients hosted by one process (one HIP stream each, flower_pCE_2D.MyClient.train_steps) must not share it -- two
+    graphs replaying concurrently would add into the same accumulators.  Single host thread: the current context is a
+    module global switched by use_context()."""
+
+    def __init__(self):
+        self.arena = _ZeroArena()
+        self.seed_offset = None        # device int32[1] added to every RNG seed (training-iteration counter)
+        self.call_idx = {}             # uid -> how many times this layer drew a mask in the current iteration
+
+
+_ctx = _Context()
+
+
+def new_context():
+    return _Context()
+
+
+@contextlib.contextmanager
+def use_context(ctx):
+    global _ctx
+    prev, _ctx = _ctx, ctx
+    try:
+        yield ctx
+    finally:
+        _ctx = prev
+
+
 _raw_epoch = 0                 # bumped whenever a kernel writes model weights through raw pointers
 
 
@@ -104,10 +131,10 @@ def begin_iteration(device=None):
     eager run and a replayed hipGraph draw identical masks, while repeated forwards inside one iteration
     (FedICRA's no-grad forwards with other clients' embeddings) still get independent masks.  Also rewinds
     and clears the accumulator arena (one memset)."""
-    _call_idx.clear()
+    _ctx.call_idx.clear()
     L.profile_block()
     if device is not None:
-        _arena.begin(torch.device(device))
+        _ctx.arena.begin(torch.device(device))
 
 
 def _drop_spec(p, kind, N, H, W, Cc, device, owner=None):
@@ -121,14 +148,14 @@ def _drop_spec(p, kind, N, H, W, Cc, device, owner=None):
         m = m.permute(0, 2, 3, 1).contiguous().to(device) if kind == "elem" else m.reshape(N, Cc).contiguous().to(device)
         return (L.DROP_MASK_ELEM if kind == "elem" else L.DROP_MASK_CHAN, float(p), 0, m, None)
     mode = L.DROP_RNG_ELEM if kind == "elem" else L.DROP_RNG_CHAN
-    if _seed_offset is None or owner is None:
-        return (mode, float(p), next(_drop_seed), None, _seed_offset)
+    if _ctx.seed_offset is None or owner is None:
+        return (mode, float(p), next(_drop_seed), None, _ctx.seed_offset)
     uid = getattr(owner, "_fi_uid", None)         # FlatStoreMixin numbers the BN modules of a model in order
     if uid is None:
         uid = _layer_uid.setdefault(id(owner), 1000 + len(_layer_uid))
-    k = _call_idx.get(uid, 0)
-    _call_idx[uid] = k + 1
-    return (mode, float(p), _base_seed + (uid << 24) + k * 0x10001, None, _seed_offset)
+    k = _ctx.call_idx.get(uid, 0)
+    _ctx.call_idx[uid] = k + 1
+    return (mode, float(p), _base_seed + (uid << 24) + k * 0x10001, None, _ctx.seed_offset)
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -347,7 +374,7 @@ class _ConvBNAct(Function):
         training = bn.training
         wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=weight)
         y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev)
-        stats = _arena.take(L.STATS_SLOTS * cout * 2, dev) if training else None
+        stats = _ctx.arena.take(L.STATS_SLOTS * cout * 2, dev) if training else None
         L.conv2d_fwd(x0, x1, wp, bias, y, None, stats, ksize=ksize)
         coef = torch.empty(4, cout, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
         drop = _drop_spec(drop_p, drop_kind, N, H, W, cout, dev, owner=bn) if training else None
@@ -369,7 +396,7 @@ class _ConvBNAct(Function):
         x0, x1, wk, y, coef = ctx.saved_tensors
         dz = dz.contiguous()
         cout = y.shape[3]
-        sums = _arena.take(L.STATS_SLOTS * cout * 2, y.device)
+        sums = _ctx.arena.take(L.STATS_SLOTS * cout * 2, y.device)
         L.bn_act_bwd_reduce(dz, y, coef[0], coef[1], coef[2], coef[3], sums, ctx.slope, ctx.drop)
         gg = gbeta = None
         dgam = dbet = None

@@ -88,3 +88,42 @@ def test_two_stream_batch_sampler():
     assert len(s) == 3 and len(batches) == 3
     assert all(len(b) == 4 and sum(x >= 100 for x in b) == 1 for b in batches)
     assert len({x for b in batches for x in b if x < 100}) == 9
+
+
+_COLOC_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from fedicra_amd.comm import WeightedAllReduce
+from fedicra_amd.flower_common import DeviceWeights
+C = 2                                              # clients hosted by every rank; client id = rank * C + j
+n = [21, 13, 17, 59]
+mk = lambda cid: torch.randn(1000, generator=torch.Generator().manual_seed(100 + cid))
+cnt = lambda cid: torch.tensor([10 * (cid + 1) + 3, 7], dtype=torch.int64)
+mine = [rank * C + j for j in range(C)]
+agg = WeightedAllReduce([n[c] for c in mine], device=None)
+out = agg.aggregate([DeviceWeights(mk(c), cnt(c)) for c in mine])
+ref = sum(mk(c).double() * n[c] for c in range(world * C)) / sum(n)
+assert agg.total == sum(n) and agg.all_n == [n[0] + n[1], n[2] + n[3]]
+assert torch.allclose(out.state.double(), ref, atol=1e-6), (out.state.double() - ref).abs().max()
+ci = [int(sum((10 * (c + 1) + 3) * n[c] for c in range(world * C)) / sum(n)), 7]
+assert out.counters.tolist() == ci, (out.counters.tolist(), ci)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_weighted_allreduce_with_colocated_clients_gloo(tmp_path):
+    """2 processes x 2 clients each: sum_k n_k w_k over the co-located clients, all-reduce, / sum of all n_k = flwr's
+    weighted mean over the 4 clients (SURVEY.md 8a16 / 8e)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_COLOC_WORKER)
+    port = str(30500 + os.getpid() % 1000)
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

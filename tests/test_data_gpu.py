@@ -126,3 +126,44 @@ def test_trainer_runs_on_a_device_loader():
     loss0, _ = client._train({"iter_global": 0, "iters": 2, "eval_iters": 1, "batch_size": 12, "stage": 1})
     loss1, _ = client._train({"iter_global": 1, "iters": 12, "eval_iters": 1, "batch_size": 12, "stage": 1})
     assert np.isfinite(loss0) and np.isfinite(loss1) and loss1 < loss0
+
+
+def test_colocated_clients_train_exactly_like_clients_alone():
+    """Two clients sharing the GPU (one HIP stream + device context + captured step each, iterations interleaved by
+    flower_pCE_2D.train_colocated) end bit-identical to the same clients trained one after the other: nothing a
+    captured step bakes in (accumulator arena, dropout counter) is shared between them."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient, train_colocated
+    from fedicra_amd.networks.unet import UNet, set_compute_dtype
+    from oracle.unet_ref import seeded_state
+    from helpers import loader
+
+    def make(cid, dtype):
+        args = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=cid, min_num_clients=2, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=30000, iters=6, rep_iters=3, alpha=0.5,
+                                  snapshot_path=None, use_graph=True)
+        net = UNet(1, 2)
+        seeded_state(net, 2022 + cid)
+        net = net.cuda()
+        set_compute_dtype(net, dtype)
+        batches = loader(3, 4, 64, cid=cid, device=DEV)
+        return MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+
+    cfg = lambda r: {"iter_global": r, "iters": 6, "eval_iters": 60, "batch_size": 4, "stage": "fit"}
+    for dtype in ("fp32", "bf16"):
+        ops.manual_seed(5)
+        alone = [make(0, dtype), make(1, dtype)]
+        res_alone = [[c._train(cfg(r)) for r in range(2)] for c in alone]      # eager, capture, then replays
+        ops.manual_seed(5)
+        together = [make(0, dtype), make(1, dtype)]
+        res_tog = [train_colocated(together, [cfg(r), cfg(r)]) for r in range(2)]
+        torch.cuda.synchronize()
+        assert together[0].stream is not None and together[0].stream != together[1].stream
+        assert together[0].ctx.arena.buf.data_ptr() != together[1].ctx.arena.buf.data_ptr()
+        for k in range(2):
+            assert torch.equal(alone[k]._net().flat_state, together[k]._net().flat_state), (dtype, k)
+            assert alone[k].last_losses == together[k].last_losses
+            assert res_alone[k][1][0] == res_tog[1][k][0]
+        assert not torch.equal(together[0]._net().flat_state, together[1]._net().flat_state)
