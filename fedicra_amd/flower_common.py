@@ -190,6 +190,29 @@ class MyModel(nn.Module):
             x = sampled_batch["image"]
         return x.to(dev), sampled_batch["label"].to(dev)
 
+    def _ala_model(self, net, local_keys):
+        """The reference deep-copies the model on every set_weights (:498,503); here ONE copy is kept and its flat state
+        refreshed from the live model (a single device copy), so that the captured ALA iteration -- which bakes in the
+        copy's buffers, the mixing weights, the old-local snapshot and the staging buffers -- survives across rounds."""
+        st = getattr(self, "_ala", None)
+        if st is None or st["src"] is not net:
+            temp = copy.deepcopy(net)
+            for n, p in temp.named_parameters():              # :542-546
+                p.requires_grad = n in local_keys
+            s, e = net.param_ranges(local_keys)[0]
+            dev = net.flat_params.device
+            ctx = ops.new_context()
+            st = {"src": net, "temp": temp, "w": torch.ones(e - s, dtype=torch.float32, device=dev),
+                  "old": torch.empty_like(net.flat_params), "iter": torch.zeros(1, dtype=torch.int32, device=dev),
+                  "ctx": ctx, "x": None, "y": None, "graph": None, "warm": False, "loss": None}
+            ctx.seed_offset = st["iter"]
+            self.__dict__["_ala"] = st                        # not a submodule: keep it out of state_dict()
+        temp = st["temp"]
+        temp.flat_state.copy_(net.flat_state)                 # parameters AND BatchNorm running statistics
+        temp.flat_counters.copy_(net.flat_counters)
+        temp.train(net.training)
+        return temp
+
     def set_weights(self, weights, config):
         if self.args.strategy not in ["FedICRA"]:
             self._load_global(weights)                       # flower_common.py:627-633
@@ -211,34 +234,67 @@ class MyModel(nn.Module):
         ranges = net.param_ranges(local_keys)
         assert len(ranges) == 1, "decoder parameters are contiguous in the flat buffer"
         s, e = ranges[0]
-        temp = copy.deepcopy(net)                             # :503 (own flat buffers, same train/eval mode)
-        for n, p in temp.named_parameters():                  # :542-546
-            p.requires_grad = n in local_keys
-        w = torch.ones(e - s, dtype=torch.float32, device=glob.device)     # re-initialised on every call (quirk 3)
+        temp = self._ala_model(net, local_keys)               # :503 deepcopy + :542-546 requires_grad, cached across calls
+        st = self._ala
+        w = st["w"]
+        w.fill_(1.0)                                          # re-initialised on every call (quirk 3)
+        st["old"].copy_(old_local)
+        old_local = st["old"]                                 # static address: the captured iteration reads it
         tp, tg = temp.flat_params, temp.flat_grads
         tp[s:e].copy_(old_local[s:e])                         # temp = global + (local - global) * 1
         losses, count = [], 0
         ncls = self.args.num_classes
-        while True:
-            loss = None
-            for sampled_batch in self.trainloader:            # :566-602
-                x, y = self._batch(sampled_batch)
-                ops.begin_iteration(x.device)
-                temp.zero_grad()
-                out = temp(x)[0]
-                loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
-                loss.backward()
-                # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel)
-                L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta)
-                ops.bump_weights_epoch()                  # temp's weights were rewritten through raw pointers
-            losses.append(float(loss.item()))
-            count += 1
-            print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,
-                  self.start_phase)
-            if not self.start_phase:                          # :611-612
-                break
-            if len(losses) > num_pre_loss and np.std(losses[-num_pre_loss:]) < threshold:      # :615
-                break
+        use_graph = bool(getattr(self.args, "use_graph", False)) and ops._mask_provider is None
+
+        def iteration(x, y):
+            """One ALA batch (:566-602): device work only, hipGraph-capturable."""
+            ops.begin_iteration(x.device)
+            temp.zero_grad()
+            out = temp(x)[0]
+            loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
+            loss.backward()
+            ops.flush_wgrad()
+            # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel)
+            L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta)
+            st["iter"].add_(1)                                # fresh dropout masks for the next batch, replay included
+            return loss
+
+        with ops.use_context(st["ctx"]):
+            while True:
+                loss = None
+                for sampled_batch in self.trainloader:        # :566-602
+                    x, y = self._batch(sampled_batch)
+                    if not use_graph:
+                        loss = iteration(x, y)
+                        ops.bump_weights_epoch()              # temp's weights were rewritten through raw pointers
+                        continue
+                    if st["x"] is None or st["x"].shape != x.shape:
+                        st["x"], st["y"] = torch.empty_like(x), torch.empty_like(y)
+                        st["graph"], st["warm"] = None, False
+                    st["x"].copy_(x, non_blocking=True)
+                    st["y"].copy_(y, non_blocking=True)
+                    if not st["warm"]:                        # first batch ever: eager (allocations, operand packs)
+                        st["loss"] = iteration(st["x"], st["y"])
+                        st["warm"] = True
+                    elif st["graph"] is None:
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            st["loss"] = iteration(st["x"], st["y"])
+                        st["graph"] = g
+                        g.replay()
+                    else:
+                        st["graph"].replay()
+                    ops.bump_weights_epoch()
+                    loss = st["loss"]
+                losses.append(float(loss.item()))             # one host sync per ALA epoch (the reference: per batch)
+                count += 1
+                print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,
+                      self.start_phase)
+                if not self.start_phase:                      # :611-612
+                    break
+                if len(losses) > num_pre_loss and np.std(losses[-num_pre_loss:]) < threshold:      # :615
+                    break
         self.start_phase = False
         glob[s:e].copy_(tp[s:e])                              # :623-624
         self.fedaa_weights = w

@@ -176,7 +176,9 @@ class MyClient(BaseClient):
                     elif rec.graph is None:
                         torch.cuda.synchronize()
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):                # records only; nothing executes
+                        # thread_local: only this thread's calls are policed during the capture -- RCCL's watchdog
+                        # thread polls events of its own and must not invalidate it (multi-GPU runs)
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # records only; nothing executes
                             self._iteration(x, y, rec)
                         rec.graph = g
                         g.replay()

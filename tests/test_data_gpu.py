@@ -167,3 +167,54 @@ def test_colocated_clients_train_exactly_like_clients_alone():
             assert alone[k].last_losses == together[k].last_losses
             assert res_alone[k][1][0] == res_tog[1][k][0]
         assert not torch.equal(together[0]._net().flat_state, together[1]._net().flat_state)
+
+
+def test_ala_captured_iteration_matches_reference_golden_and_the_eager_path(golden):
+    """FedICRA set_weights (a4) with the ALA batch captured into a hipGraph (args.use_graph): (1) eval mode, against the
+    reference's own set_weights (golden g7) on the first call (converge loop), a second call (cached model + graph reused
+    across rounds) and the identical-global early-out; (2) train mode with the device dropout RNG: bit-identical to the
+    eager path, ALA epoch losses included."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.networks.unet import UNet_LC
+    from oracle.unet_ref import RefUNetLC, seeded_state
+    from oracle import fed_ref
+    from helpers import assert_ck, loader
+    from test_unet_gpu import _args, _mk
+    g = golden("g7_ala.npz")
+    K, cid = 3, 1
+    batches = loader(3, 4, 64, cid=cid)
+    donor = RefUNetLC(1, 2, 1, K, K, cid)
+    seeded_state(donor, 200)
+    glob = fed_ref.get_weights(donor)
+    seeded_state(donor, 300)
+    glob2 = fed_ref.get_weights(donor)
+    args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K, use_graph=True)
+    net = _mk(UNet_LC, 1, 2, 1, K, K, cid, seed=100, lc=True).eval()
+    model = MyModel(args, net, batches, batches)
+    model.eval()
+    model.set_weights(glob, {"iter_global": 60})
+    assert model._ala["graph"] is not None and len(model.ala_epoch_losses) == int(g["eval/first_epochs"])
+    assert len(net.state_dict()) == 144, "the cached ALA copy must not leak into the wire format"
+    for k, v in net.state_dict().items():
+        assert_ck(v.double().cpu(), g["eval/first/" + k], rtol=2e-4, atol=2e-5, what=k)
+    graph = model._ala["graph"]
+    model.set_weights(glob2, {"iter_global": 70})
+    assert model._ala["graph"] is graph and len(model.ala_epoch_losses) == 1
+    for k, v in net.state_dict().items():
+        assert_ck(v.double().cpu(), g["eval/second/" + k], rtol=2e-4, atol=2e-5, what=k)
+    model.set_weights(glob2, {"iter_global": 80})
+    assert_ck(net.state_dict()["decoder.out_conv.weight"].cpu(), g["eval/third_out_conv_ck"], rtol=1e-6, atol=1e-7)
+    finals = []
+    for use_graph in (False, True):
+        ops.manual_seed(9)
+        a = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K, use_graph=use_graph)
+        n = _mk(UNet_LC, 1, 2, 1, K, K, cid, seed=100, lc=True).train()
+        m = MyModel(a, n, batches, batches)
+        m.train()
+        m.start_phase = False                                  # one epoch per call
+        m.set_weights(glob, {"iter_global": 60})
+        m.set_weights(glob2, {"iter_global": 70})
+        finals.append((n.flat_state.clone(), list(m.ala_epoch_losses), m.fedaa_weights.clone()))
+    assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][2], finals[1][2]) and 0.0 <= float(finals[1][2].min()) and float(finals[1][2].max()) <= 1.0
