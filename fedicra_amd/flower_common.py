@@ -33,6 +33,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import fl, ops
+from .flat import _as_view
 
 VAL_METRICS = ["dice", "hd95", "recall", "precision", "jc", "specificity", "ravd"]     # flower_common.py:121
 PERSONALIZED_FL = ["FedICRA"]
@@ -169,7 +170,19 @@ class MyModel(nn.Module):
     # -- weights I/O ----------------------------------------------------------------------------
     def get_weights(self, config=None):
         """List of numpy arrays in state_dict order (flower_common.py:488-489) -- the Flower wire format."""
-        return [val.detach().cpu().numpy() for _, val in self.model.state_dict().items()]
+        net = self.model
+        if not hasattr(net, "_fi_offsets"):
+            return [val.detach().cpu().numpy() for _, val in net.state_dict().items()]
+        # the reference pays one D2H sync per array (136-160 of them); the flat store needs two copies in total
+        host, cnt = net.flat_state.detach().cpu(), net.flat_counters.cpu()
+        out, ci = [], 0
+        for k, v in net.state_dict().items():
+            if v.is_floating_point():
+                out.append(_as_view(host, net._fi_offsets[k], v).numpy())
+            else:
+                out.append(cnt[ci].numpy())
+                ci += 1
+        return out
 
     def get_device_weights(self) -> DeviceWeights:
         return DeviceWeights(self.model.flat_state, self.model.flat_counters)
@@ -178,9 +191,29 @@ class MyModel(nn.Module):
         if isinstance(weights, DeviceWeights):
             self.model.flat_state.copy_(weights.state)
             self.model.flat_counters.copy_(weights.counters)
-        else:
+        elif not hasattr(self.model, "_fi_offsets"):
             sd = OrderedDict((k, torch.tensor(v)) for k, v in zip(self.model.state_dict().keys(), weights))
             self.model.load_state_dict(sd, strict=False)      # int64 buffers: float64 -> truncation (quirk 6)
+        else:
+            # same pairing and conversions as load_state_dict(zip(keys, tensors), strict=False), assembled on the host
+            # and uploaded with two copies instead of one per key
+            net = self.model
+            host = torch.empty(net.flat_state.shape, dtype=torch.float32).copy_(net.flat_state)
+            cnt = net.flat_counters.cpu().clone()
+            ci = 0
+            for (k, v), arr in zip(net.state_dict().items(), weights):
+                t = torch.as_tensor(np.asarray(arr))
+                if tuple(t.shape) != tuple(v.shape):
+                    raise RuntimeError("size mismatch for {}: copying a param with shape {} from checkpoint, the shape in "
+                                       "current model is {}.".format(k, tuple(t.shape), tuple(v.shape)))
+                if v.is_floating_point():
+                    _as_view(host, net._fi_offsets[k], v).copy_(t)
+                else:
+                    cnt[ci] = t.to(torch.int64)               # float64 -> int64 truncation (quirk 6)
+                    ci += 1
+            net.flat_state.copy_(host)
+            net.flat_counters.copy_(cnt)
+            ops.bump_weights_epoch()
 
     def _batch(self, sampled_batch):
         dev = self.model.flat_state.device
@@ -297,7 +330,7 @@ class MyModel(nn.Module):
                     break
         self.start_phase = False
         glob[s:e].copy_(tp[s:e])                              # :623-624
-        self.fedaa_weights = w
+        self.fedaa_weights = w.clone()                        # w itself is the captured iteration's static buffer
         self.ala_epoch_losses = losses
 
 

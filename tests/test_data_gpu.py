@@ -218,3 +218,39 @@ def test_ala_captured_iteration_matches_reference_golden_and_the_eager_path(gold
         finals.append((n.flat_state.clone(), list(m.ala_epoch_losses), m.fedaa_weights.clone()))
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
     assert torch.equal(finals[0][2], finals[1][2]) and 0.0 <= float(finals[1][2].min()) and float(finals[1][2].max()) <= 1.0
+
+
+def test_wire_format_roundtrip_on_the_device_uses_the_flat_store():
+    """a2/a3: get_weights = the reference's list of arrays in state_dict order (values, shapes, dtypes), produced from
+    ONE device-to-host copy of the flat state; set_weights(list) pairs arrays with keys like load_state_dict(strict=
+    False), truncates float64 counters to int64, rejects a wrong shape, and uploads with one copy."""
+    import argparse
+    import time
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.networks.unet import UNet_LC_MultiHead
+    torch.manual_seed(1)
+    net = UNet_LC_MultiHead(1, 2, 1, 8, 8, 3).cuda()
+    args = argparse.Namespace(strategy="FedAvg", amp=0, cid=3, num_classes=2, img_class="faz")
+    mm = MyModel(args, net, [], [])
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ws = mm.get_weights(None)
+    t1 = time.perf_counter()
+    assert len(ws) == len(sd) == 160
+    for a, (k, b) in zip(ws, sd.items()):
+        assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), k
+    new = [np.asarray(a * 0.5 + 1.0, dtype=np.float64) if a.dtype == np.float32 else np.float64(5.9) for a in ws]
+    t2 = time.perf_counter()
+    mm.set_weights(new, {})
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for (k, v), a in zip(net.state_dict().items(), new):
+        want = torch.from_numpy(a).to(v.dtype) if v.is_floating_point() else torch.tensor(5, dtype=torch.int64)
+        assert torch.equal(v.cpu(), want), k
+    print(f"get_weights {1e3 * (t1 - t0):.2f} ms, set_weights {1e3 * (t3 - t2):.2f} ms (160 arrays, 9.4 MB)")
+    bad = list(new)
+    bad[0] = bad[0][:-1]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        mm.set_weights(bad, {})
+    mm.set_weights(new[:10], {})                               # strict=False: a short list loads its prefix only
