@@ -30,12 +30,14 @@ class TreeEnergyLoss(nn.Module):
         preds = preds.float()
         low_feats, rois, N, size = _prep(preds, low_feats, unlabeled_ROIs)
         prob = torch.softmax(preds, dim=1)
-        tree = self.mst_layers(low_feats)
-        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=tree)
+        guides = [low_feats]
         if high_feats is not None:
             high_feats = F.interpolate(high_feats.float(), size=size, mode="bilinear", align_corners=False)
-            tree = self.mst_layers(high_feats)
-            AS = self.tree_filter_layers(feature_in=AS, embed_in=high_feats, tree=tree, low_tree=False)
+            guides.append(high_feats)
+        trees = self.mst_layers.forward_many(guides)         # independent of the filter chain: built side by side
+        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=trees[0])
+        if high_feats is not None:
+            AS = self.tree_filter_layers(feature_in=AS, embed_in=high_feats, tree=trees[1], low_tree=False)
         tree_loss = (rois * torch.abs(prob - AS)).sum()
         tree_loss = tree_loss / N.clamp(min=1)        # `if N > 0: tree_loss /= N` without a host sync (N = 0 => sum = 0)
         return weight * tree_loss, AS
@@ -51,13 +53,13 @@ class MScaleRecurveTreeEnergyLoss(nn.Module):
         preds = preds.float()
         low_feats, rois, N, size = _prep(preds, low_feats, unlabeled_ROIs)
         prob = torch.softmax(preds, dim=1)
-        tree = self.mst_layers(low_feats)
-        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=tree)
+        # the reference dereferences AS_1..AS_3 unconditionally at the end: all three maps are required
+        highs = [F.interpolate(hf.float(), size=size, mode="bilinear", align_corners=False)
+                 for hf in (high_feats_1, high_feats_2, high_feats_3)]
+        trees = self.mst_layers.forward_many([low_feats] + highs)     # the 4 trees do not depend on the filter chain
+        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=trees[0])
         outs, cur = [], AS
-        for hf in (high_feats_1, high_feats_2, high_feats_3):
-            # the reference dereferences AS_1..AS_3 unconditionally at the end: all three maps are required
-            hf = F.interpolate(hf.float(), size=size, mode="bilinear", align_corners=False)
-            tree = self.mst_layers(hf)
+        for hf, tree in zip(highs, trees[1:]):
             cur = self.tree_filter_layers(feature_in=cur, embed_in=hf, tree=tree, low_tree=False)
             outs.append(cur)
         tree_loss = (rois * torch.abs(prob - outs[2])).sum()

@@ -29,9 +29,46 @@ class Tree:
         return self.edges.shape
 
 
+_side_streams = {}
+
+
+def _parallel(*branches):
+    """Run independent launch sequences as parallel branches: branch 0 on the current stream, the others on side HIP
+    streams forked from / joined to it (inside a stream capture they become parallel branches of the hipGraph).  A tree
+    recursion is a chain of ~1500 dependent steps on a few dozen workgroups, so two of them side by side cost the time
+    of one.  Outputs are allocated by the caller, before the fork."""
+    if len(branches) == 1 or not torch.cuda.is_available():
+        for b in branches:
+            b()
+        return
+    cur = torch.cuda.current_stream()
+    pool = _side_streams.setdefault(cur.device.index, [])
+    while len(pool) < len(branches) - 1:
+        pool.append(torch.cuda.Stream(device=cur.device))
+    for b, s in zip(branches[1:], pool):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            b()
+    branches[0]()
+    for _, s in zip(branches[1:], pool):
+        cur.wait_stream(s)
+
+
 def _f32c(t):
     t = t if t.dtype == torch.float32 else t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _bfs(tree, B, dev):
+    """Breadth-first order of a spanning tree: sorted index / parent / children per node and the level boundaries."""
+    V = tree.H * tree.W
+    with torch.no_grad():
+        sidx = torch.empty((B, V), dtype=torch.int32, device=dev)
+        spar = torch.empty((B, V), dtype=torch.int32, device=dev)
+        schild = torch.empty((B, V, 4), dtype=torch.int32, device=dev)
+        levels = torch.empty((B, V + 2), dtype=torch.int32, device=dev)
+        L.tree_bfs(tree.edges, tree.H, tree.W, sidx, spar, schild, levels)
+    return sidx, spar, schild, levels
 
 
 class MinimumSpanningTree(nn.Module):
@@ -54,6 +91,21 @@ class MinimumSpanningTree(nn.Module):
             L.tree_mst(weight, H, W, edges)
         return Tree(edges, H, W)
 
+    def forward_many(self, guides):
+        """The spanning trees AND breadth-first orders of several guidance maps, built side by side (they are independent:
+        the multi-scale loss needs four of them before its filter chain starts).  -> [Tree] with `.bfs` attached."""
+        trees = [None] * len(guides)
+
+        def build(i):
+            def run():
+                t = self.forward(guides[i])
+                t.bfs = _bfs(t, guides[i].shape[0], guides[i].device)
+                trees[i] = t
+            return run
+
+        _parallel(*[build(i) for i in range(len(guides))])
+        return trees
+
 
 class _Refine(Function):
     """refine_forward / refine_backward_feature / refine_backward_weight (src/refine/refine.cu:201-370)."""
@@ -66,10 +118,16 @@ class _Refine(Function):
         aggr = torch.empty_like(feature_in)
         wup = torch.empty((B, 1, V), dtype=torch.float32, device=dev)
         wsum = torch.empty((B, 1, V), dtype=torch.float32, device=dev)
-        L.tree_aggr_up(feature_in, edge_weight, sidx, schild, levels, up)
-        L.tree_prop_down(up, edge_weight, sidx, spar, levels, aggr)
-        L.tree_aggr_up(None, edge_weight, sidx, schild, levels, wup)
-        L.tree_prop_down(wup, edge_weight, sidx, spar, levels, wsum)
+
+        def features():
+            L.tree_aggr_up(feature_in, edge_weight, sidx, schild, levels, up)
+            L.tree_prop_down(up, edge_weight, sidx, spar, levels, aggr)
+
+        def normaliser():
+            L.tree_aggr_up(None, edge_weight, sidx, schild, levels, wup)
+            L.tree_prop_down(wup, edge_weight, sidx, spar, levels, wsum)
+
+        _parallel(features, normaliser)
         out = aggr / wsum
         ctx.save_for_backward(edge_weight, sidx, spar, schild, levels, out, aggr, up, wsum, wup)
         ctx.low_tree = low_tree
@@ -82,18 +140,26 @@ class _Refine(Function):
         B, C, V = g.shape
         gn = (g / wsum).contiguous()
         gn_up = torch.empty_like(gn)
-        L.tree_aggr_up(gn, edge_weight, sidx, schild, levels, gn_up)
         grad_feature = torch.empty_like(gn)
-        L.tree_prop_down(gn_up, edge_weight, sidx, spar, levels, grad_feature)
         if ctx.low_tree:
+            L.tree_aggr_up(gn, edge_weight, sidx, schild, levels, gn_up)
+            L.tree_prop_down(gn_up, edge_weight, sidx, spar, levels, grad_feature)
             return grad_feature, None, None, None, None, None, None
         fg = (gn * out).contiguous()
         fg_up = torch.empty_like(fg)
-        L.tree_aggr_up(fg, edge_weight, sidx, schild, levels, fg_up)
         g_all = torch.empty_like(gn)
         g_norm = torch.empty_like(gn)
-        L.tree_grad_rec(up, gn_up, aggr, edge_weight, sidx, spar, levels, g_all)           # gn_up is propagated in place
-        L.tree_grad_rec(wup, fg_up, wsum, edge_weight, sidx, spar, levels, g_norm)
+
+        def through_features():
+            L.tree_aggr_up(gn, edge_weight, sidx, schild, levels, gn_up)
+            L.tree_prop_down(gn_up, edge_weight, sidx, spar, levels, grad_feature)
+            L.tree_grad_rec(up, gn_up, aggr, edge_weight, sidx, spar, levels, g_all)       # gn_up is propagated in place
+
+        def through_normaliser():
+            L.tree_aggr_up(fg, edge_weight, sidx, schild, levels, fg_up)
+            L.tree_grad_rec(wup, fg_up, wsum, edge_weight, sidx, spar, levels, g_norm)
+
+        _parallel(through_features, through_normaliser)
         grad_weight = (g_all - g_norm).sum(1)
         return grad_feature, grad_weight, None, None, None, None, None
 
@@ -136,12 +202,7 @@ class TreeFilter2D(nn.Module):
         B, C, H, W = ori_shape
         V = H * W
         dev = feature_in.device
-        with torch.no_grad():
-            sidx = torch.empty((B, V), dtype=torch.int32, device=dev)
-            spar = torch.empty((B, V), dtype=torch.int32, device=dev)
-            schild = torch.empty((B, V, 4), dtype=torch.int32, device=dev)
-            levels = torch.empty((B, V + 2), dtype=torch.int32, device=dev)
-            L.tree_bfs(tree.edges, tree.H, tree.W, sidx, spar, schild, levels)
+        sidx, spar, schild, levels = getattr(tree, "bfs", None) or _bfs(tree, B, dev)
         emb = _f32c(embed_in).reshape(B, embed_in.shape[1], V)
         inv_sigma = 1.0 / self.sigma if low_tree else 1.0
         if low_tree:

@@ -49,6 +49,34 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         print(f"K={K}: {dt / reps * 1e3:.3f} ms per round of K steps, {K * a.batch * reps / dt:.0f} images/s aggregate")
+        # host cost of one graph launch (enqueue only), and the same K chains driven by K host threads
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for r in range(20):
+                graphs[0].replay()
+        th = (time.perf_counter() - t0) / 20
+        torch.cuda.synchronize()
+        import threading
+
+        def work(g, s):
+            with torch.cuda.stream(s):
+                for r in range(reps):
+                    g.replay()
+            s.synchronize()
+
+        for _ in range(2):
+            torch.cuda.synchronize()
+            ts = [threading.Thread(target=work, args=(g, s)) for g, s in zip(graphs[:K], streams[:K])]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(f"      host enqueue of one graph launch {th * 1e3:.3f} ms; {K} host threads: {dt / reps * 1e3:.3f} ms per round, "
+              f"{K * a.batch * reps / dt:.0f} images/s aggregate")
 
 
 main()
