@@ -277,18 +277,84 @@ __global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float*
 
 // ---- recursions: one workgroup per (image, channel); the nodes of one BFS level are independent.
 // The trees are deep and thin (256^2 images: 1200-2100 levels of ~40 nodes), so a recursion is a chain of L dependent
-// steps and its speed is the latency of ONE step.  Two things keep a step short: the value a node needs from the
-// neighbouring level (its parent's / its children's result) is kept in LDS (`lvl`, double-buffered by level parity;
-// levels wider than TREE_CAP fall back to global memory), and everything that does NOT depend on the previous level
-// (indices, weights, inputs of the next level) is loaded into registers one level ahead, before the barrier.
+// steps and its speed is the latency of ONE step.  A step touches nothing but LDS:
+//   * the value a node needs from the neighbouring level (its parent's result / its children's contributions) is kept in
+//     `lvl`, double-buffered by level parity (levels wider than TREE_CAP fall back to global memory);
+//   * everything that does NOT depend on the previous level -- the node's indices, edge weight and inputs, including
+//     the gathered ones (x[sorted_index[i]], out_data[sorted_index[parent]]) -- is a function of the node's BFS
+//     position alone, and a pass visits the positions monotonically.  NodeRing streams those records through an LDS
+//     ring in chunks of TREE_CH nodes: a chunk's global loads are issued one chunk (~12 levels, ~2.5 us) before its
+//     first node is needed and committed to the ring when the pass reaches it, so neither the load latency nor the
+//     dependent gather hop is ever on the chain.  A level wider than a chunk takes the direct path (global loads).
 #define TREE_CAP 4096
 #define TREE_RT 256      // threads of a recursion workgroup
+#define TREE_CH 512      // nodes per streamed chunk
+#define TREE_RING (2 * TREE_CH)
+
+// Barrier between two levels when everything the next level reads from this one went through LDS: wait for the LDS
+// queue only.  __syncthreads() also waits for the level's global STORES to be acknowledged (~0.5 us) -- needed only when
+// the next level falls back to reading this level's results from global memory (level wider than TREE_CAP).
+__device__ __forceinline__ void level_barrier(bool through_global) {
+  if (through_global) {
+    __syncthreads();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+template <int NW>
+struct NodeRing {
+  static constexpr int PER = TREE_CH / TREE_RT;
+  uint32_t (*ring)[TREE_RING];      // [NW][TREE_RING] in LDS
+  uint32_t pend[PER][NW];
+  int V, tid, next;                 // next = index of the chunk waiting in `pend`
+  bool up;                          // up: chunk k = [V-(k+1)CH, V-kCH);  down: chunk k = [kCH, (k+1)CH)
+  __device__ __forceinline__ int chunk_lo(int k) const { return up ? V - (k + 1) * TREE_CH : k * TREE_CH; }
+  template <class F> __device__ __forceinline__ void issue(int k, F&& load) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = chunk_lo(k) + tid + j * TREE_RT;
+      if (i >= 0 && i < V) load(i, pend[j]);
+    }
+  }
+  __device__ __forceinline__ void commit(int k) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = chunk_lo(k) + tid + j * TREE_RT;
+      if (i >= 0 && i < V) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) ring[q][i & (TREE_RING - 1)] = pend[j][q];
+      }
+    }
+  }
+  // make [lo, hi) resident (hi - lo <= TREE_CH); returns true when the ring was written (caller must barrier)
+  template <class F> __device__ __forceinline__ bool ensure(int lo, int hi, F&& load) {
+    bool wrote = false;
+    while (up ? lo < V - next * TREE_CH : hi > next * TREE_CH) {
+      commit(next);
+      ++next;
+      issue(next, load);
+      wrote = true;
+    }
+    return wrote;
+  }
+  template <class F> __device__ __forceinline__ void start(F&& load) {
+    next = 0;
+    issue(0, load);
+    commit(0);
+    next = 1;
+    issue(1, load);
+  }
+  __device__ __forceinline__ uint32_t get(int q, int i) const { return ring[q][i & (TREE_RING - 1)]; }
+  __device__ __forceinline__ float getf(int q, int i) const { return __uint_as_float(get(q, i)); }
+};
 
 __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const int* __restrict__ sidx, const int* __restrict__ schild,
                                                                const int* __restrict__ levels, int C, int V,
                                                                float* __restrict__ out) {
-  __shared__ float lvl[2][TREE_CAP];
+  __shared__ float lvl[2][TREE_CAP];           // a node's CONTRIBUTION to its parent: value * own edge weight
+  __shared__ uint32_t ringmem[6][TREE_RING];   // children (4), x[sorted_index[i]], w[i]
   const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   const int* si = sidx + (size_t)b * V;
   const int4* sc = reinterpret_cast<const int4*>(schild + (size_t)b * V * 4);
@@ -297,54 +363,58 @@ __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __re
   const float* xb = x ? x + ((size_t)b * C + c) * V : nullptr;
   float* ob = out + ((size_t)b * C + c) * V;
   const int L = lv[0];
-  // registers of the node this thread handles in the level being processed (first 256 nodes of a level)
-  int4 ch = make_int4(0, 0, 0, 0);
-  float xin = 0.f, wch[4] = {0.f, 0.f, 0.f, 0.f};
-  auto prefetch = [&](int l) {
-    if (l < 0) return;
-    const int i = lv[1 + l] + tid;
-    if (i < lv[2 + l]) {
-      ch = sc[i];
-      xin = xb ? xb[si[i]] : 1.0f;
-      wch[0] = ch.x > 0 ? wb[ch.x] : 0.f;
-      wch[1] = ch.y > 0 ? wb[ch.y] : 0.f;
-      wch[2] = ch.z > 0 ? wb[ch.z] : 0.f;
-      wch[3] = ch.w > 0 ? wb[ch.w] : 0.f;
-    }
+  auto load = [&](int i, uint32_t* r) {
+    const int4 ch = sc[i];
+    r[0] = ch.x, r[1] = ch.y, r[2] = ch.z, r[3] = ch.w;
+    r[4] = __float_as_uint(xb ? xb[si[i]] : 1.0f);
+    r[5] = __float_as_uint(wb[i]);
   };
-  prefetch(L - 1);
+  NodeRing<6> nr;
+  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = true;
+  nr.start(load);
+  __syncthreads();
+  int lo_next = lv[L], hi_next = lv[L + 1], chi_next = lv[L + 1];       // level L-1 = [lv[L], lv[L+1]), no children
+  int lo_ahead = L >= 2 ? lv[L - 1] : 0;
   for (int l = L - 1; l >= 0; --l) {
-    const int lo = lv[1 + l], hi = lv[2 + l];
-    const int clo = hi, chi = l + 1 < L ? lv[3 + l] : hi;        // the children live in level l+1 = [hi, lv[3+l])
+    const int lo = lo_next, hi = hi_next;
+    const int clo = hi, chi = chi_next;                          // the children live in level l+1 = [hi, lv[3+l])
+    chi_next = hi, hi_next = lo, lo_next = lo_ahead;             // level boundaries slide; the new one is loaded a level ahead
+    if (l >= 2) lo_ahead = lv[l - 1];
     const float* below = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
     const bool cached = chi - clo <= TREE_CAP;
-    auto child_val = [&](int cpos) { return cached ? below[cpos - clo] : ob[cpos]; };
-    {
-      const int i = lo + tid;
-      if (i < hi) {
-        float s = xin;
-        if (ch.x > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.x), wch[0]));
-        if (ch.y > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.y), wch[1]));
-        if (ch.z > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.z), wch[2]));
-        if (ch.w > 0) s = __fadd_rn(s, __fmul_rn(child_val(ch.w), wch[3]));
+    const bool streamed = hi - lo <= TREE_CH;
+    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
+    if (streamed && cached) {
+      // fast path: LDS in, LDS out (+ a fire-and-forget store).  Kept free of any global LOAD so that no s_waitcnt
+      // vmcnt lands on the chain (vmcnt also counts the stores and the chunk loads in flight).
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        const int c0 = (int)nr.get(0, i), c1 = (int)nr.get(1, i), c2 = (int)nr.get(2, i), c3 = (int)nr.get(3, i);
+        float s = nr.getf(4, i);
+        const float wi = nr.getf(5, i);
+        // four independent LDS reads in flight (slot 0 stands in for "no child"), one wait
+        const float v0 = below[c0 > 0 ? c0 - clo : 0], v1 = below[c1 > 0 ? c1 - clo : 0];
+        const float v2 = below[c2 > 0 ? c2 - clo : 0], v3 = below[c3 > 0 ? c3 - clo : 0];
+        if (c0 > 0) s = __fadd_rn(s, v0);
+        if (c1 > 0) s = __fadd_rn(s, v1);
+        if (c2 > 0) s = __fadd_rn(s, v2);
+        if (c3 > 0) s = __fadd_rn(s, v3);
         ob[i] = s;
-        if (tid < TREE_CAP) mine[tid] = s;
+        mine[i - lo] = __fmul_rn(s, wi);
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        const int4 c4 = sc[i];
+        const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        float s = xb ? xb[si[i]] : 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cc[q] > 0) s = __fadd_rn(s, cached ? below[cc[q] - clo] : __fmul_rn(ob[cc[q]], wb[cc[q]]));
+        ob[i] = s;
+        if (i - lo < TREE_CAP) mine[i - lo] = __fmul_rn(s, wb[i]);
       }
     }
-    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {     // wide levels: the rest without prefetch
-      const int4 c4 = sc[i];
-      float s = xb ? xb[si[i]] : 1.0f;
-      const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
-      for (int q = 0; q < 4; ++q) {
-        if (cc[q] <= 0) break;
-        s = __fadd_rn(s, __fmul_rn(child_val(cc[q]), wb[cc[q]]));
-      }
-      ob[i] = s;
-      if (i - lo < TREE_CAP) mine[i - lo] = s;
-    }
-    prefetch(l - 1);
-    __syncthreads();
+    level_barrier(hi - lo > TREE_CAP);
   }
 }
 
@@ -353,6 +423,7 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
                                                                  const int* __restrict__ levels, int C, int V,
                                                                  float* __restrict__ out) {
   __shared__ float lvl[2][TREE_CAP];
+  __shared__ uint32_t ringmem[4][TREE_RING];   // parent position, vertex, x_sorted[i], w[i]
   const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   const int* si = sidx + (size_t)b * V;
   const int* sp = spar + (size_t)b * V;
@@ -361,42 +432,48 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
   const float* xb = xs + ((size_t)b * C + c) * V;
   float* ob = out + ((size_t)b * C + c) * V;
   const int L = lv[0];
-  int p = 0, vtx = 0;
-  float xi = 0.f, wi = 0.f;
-  auto prefetch = [&](int l) {
-    if (l >= L) return;
-    const int i = lv[1 + l] + tid;
-    if (i < lv[2 + l]) {
-      p = sp[i];
-      vtx = si[i];
-      xi = xb[i];
-      wi = i == 0 ? 0.f : wb[i];                 // the root's edge weight counts as 0 (refine.cu:43-46)
-    }
+  auto load = [&](int i, uint32_t* r) {
+    r[0] = (uint32_t)sp[i];
+    r[1] = (uint32_t)si[i];
+    r[2] = __float_as_uint(xb[i]);
+    r[3] = __float_as_uint(i == 0 ? 0.f : wb[i]);      // the root's edge weight counts as 0 (refine.cu:43-46)
   };
-  prefetch(0);
+  NodeRing<4> nr;
+  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = false;
+  nr.start(load);
+  __syncthreads();
+  int plo_next = 0, lo_next = lv[1], hi_next = lv[2];
+  int hi_ahead = L >= 2 ? lv[3] : 0;
   for (int l = 0; l < L; ++l) {
-    const int lo = lv[1 + l], hi = lv[2 + l];
-    const int plo = l > 0 ? lv[l] : 0;                           // the parents live in level l-1 = [lv[l], lo)
+    const int lo = lo_next, hi = hi_next;
+    const int plo = plo_next;                                    // the parents live in level l-1 = [lv[l], lo)
+    plo_next = lo, lo_next = hi, hi_next = hi_ahead;
+    if (l + 2 < L) hi_ahead = lv[4 + l];
     const float* above = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
     const bool cached = lo - plo <= TREE_CAP;
-    auto parent_val = [&](int ppos) { return l == 0 ? 0.f : (cached ? above[ppos - plo] : ob[si[ppos]]); };
-    {
-      const int i = lo + tid;
-      if (i < hi) {
-        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(parent_val(p), wi));
+    const bool streamed = hi - lo <= TREE_CH;
+    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
+    if (streamed && cached) {
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        const int p = (int)nr.get(0, i), vtx = (int)nr.get(1, i);
+        const float xi = nr.getf(2, i), wi = nr.getf(3, i);
+        const float pv = l == 0 ? 0.f : above[p - plo];
+        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
         ob[vtx] = v;
-        if (tid < TREE_CAP) mine[tid] = v;
+        mine[i - lo] = v;
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        const int p = sp[i];
+        const float xi = xb[i], wi = i == 0 ? 0.f : wb[i];
+        const float pv = l == 0 ? 0.f : (cached ? above[p - plo] : ob[si[p]]);
+        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
+        ob[si[i]] = v;
+        if (i - lo < TREE_CAP) mine[i - lo] = v;
       }
     }
-    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {
-      const float w2 = wb[i];
-      const float v = __fadd_rn(__fmul_rn(xb[i], __fsub_rn(1.0f, __fmul_rn(w2, w2))), __fmul_rn(parent_val(sp[i]), w2));
-      ob[si[i]] = v;
-      if (i - lo < TREE_CAP) mine[i - lo] = v;
-    }
-    prefetch(l + 1);
-    __syncthreads();
+    level_barrier(hi - lo > TREE_CAP);
   }
 }
 
@@ -408,6 +485,7 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
                                                                 const int* __restrict__ spar, const int* __restrict__ levels,
                                                                 int Cd, int Cg, int V, float* __restrict__ grad) {
   __shared__ float lvl[2][TREE_CAP];
+  __shared__ uint32_t ringmem[5][TREE_RING];   // parent position, w[i], in_grad[i], in_data[i], out_data[sorted_index[parent]]
   const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
   const int Cmax = Cd > Cg ? Cd : Cg;
   const int* si = sidx + (size_t)b * V;
@@ -419,53 +497,67 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
   float* igb = in_grad + ((size_t)b * Cg + k % Cg) * V;
   float* gb = grad + ((size_t)b * Cmax + k) * V;
   const int L = lv[0];
-  int p = 0;
-  float wi = 0.f, ig = 0.f, id = 0.f, od = 0.f;
-  auto prefetch = [&](int l) {
-    if (l >= L) return;
-    const int i = lv[1 + l] + tid;
-    if (i < lv[2 + l] && i > 0) {
-      p = sp[i];
-      wi = wb[i];
-      ig = igb[i];                 // not yet propagated: level l is only written when level l is processed
-      id = idb[i];
-      od = odb[si[p]];
-    }
+  // in_grad[i] is only rewritten (propagated) when node i itself is processed, and a chunk is always loaded before the
+  // pass reaches it: the streamed copy is the not-yet-propagated value the formula wants (the entry point guarantees one
+  // workgroup per gradient channel: Cd == Cg or Cd == 1).
+  auto load = [&](int i, uint32_t* r) {
+    const int p = i > 0 ? sp[i] : 0;
+    r[0] = (uint32_t)p;
+    r[1] = __float_as_uint(wb[i]);
+    r[2] = __float_as_uint(igb[i]);
+    r[3] = __float_as_uint(idb[i]);
+    r[4] = __float_as_uint(i > 0 ? odb[si[p]] : 0.f);
   };
-  prefetch(0);
+  NodeRing<5> nr;
+  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = false;
+  nr.start(load);
+  __syncthreads();
+  int plo_next = 0, lo_next = lv[1], hi_next = lv[2];
+  int hi_ahead = L >= 2 ? lv[3] : 0;
   for (int l = 0; l < L; ++l) {
-    const int lo = lv[1 + l], hi = lv[2 + l];
-    const int plo = l > 0 ? lv[l] : 0;
+    const int lo = lo_next, hi = hi_next;
+    const int plo = plo_next;
+    plo_next = lo, lo_next = hi, hi_next = hi_ahead;
+    if (l + 2 < L) hi_ahead = lv[4 + l];
     const float* above = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
     const bool cached = lo - plo <= TREE_CAP;
-    auto parent_g = [&](int ppos) { return cached ? above[ppos - plo] : igb[ppos]; };
-    {
-      const int i = lo + tid;
-      if (i < hi) {
-        float G;
+    const bool streamed = hi - lo <= TREE_CH;
+    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
+    if (streamed && cached) {
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        const float ig = nr.getf(2, i);
+        float G = ig;                                              // the root's gradient stays as aggregated
         if (i == 0) {
           gb[0] = 0.f;
-          G = igb[0];                                              // the root's gradient stays as aggregated
         } else {
-          const float gp = parent_g(p);
+          const int p = (int)nr.get(0, i);
+          const float wi = nr.getf(1, i), id = nr.getf(3, i), od = nr.getf(4, i);
+          const float gp = above[p - plo];
           gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
           G = ig * (1.0f - wi * wi) + gp * wi;
           igb[i] = G;
         }
-        if (tid < TREE_CAP) mine[tid] = G;
+        mine[i - lo] = G;
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += TREE_RT) {
+        float G;
+        if (i == 0) {
+          gb[0] = 0.f;
+          G = igb[0];
+        } else {
+          const int p = sp[i];
+          const float wi = wb[i], ig = igb[i], id = idb[i], od = odb[si[p]];
+          const float gp = cached ? above[p - plo] : igb[p];
+          gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
+          G = ig * (1.0f - wi * wi) + gp * wi;
+          igb[i] = G;
+        }
+        if (i - lo < TREE_CAP) mine[i - lo] = G;
       }
     }
-    for (int i = lo + tid + TREE_RT; i < hi; i += TREE_RT) {
-      const int pp = sp[i];
-      const float w2 = wb[i], g2 = igb[i], d2 = idb[i], gp = parent_g(pp);
-      gb[i] = g2 * (odb[si[pp]] - w2 * d2) + d2 * (gp - w2 * g2);
-      const float G = g2 * (1.0f - w2 * w2) + gp * w2;
-      igb[i] = G;
-      if (i - lo < TREE_CAP) mine[i - lo] = G;
-    }
-    prefetch(l + 1);
-    __syncthreads();
+    level_barrier(hi - lo > TREE_CAP);
   }
 }
 
@@ -552,6 +644,7 @@ extern "C" int fi_tree_grad_rec(const float* in_data, float* in_grad, const floa
                                 int V, float* grad, void* stream) {
   if (!in_data || !in_grad || !out_data || !w || !sorted_index || !sorted_parent || !levels || !grad) return FI_ERR_NULL;
   if (B < 1 || Cd < 1 || Cg < 1 || V < 1) return FI_ERR_SHAPE;
+  if (Cd != Cg && Cd != 1) return FI_ERR_UNSUPPORTED;     // in_grad is propagated in place: one workgroup per gradient channel
   hipLaunchKernelGGL(tree_grad_rec_kernel, dim3(B, Cd > Cg ? Cd : Cg), dim3(TREE_RT), 0, (hipStream_t)stream, in_data, in_grad,
                      out_data, w, sorted_index, sorted_parent, levels, Cd, Cg, V, grad);
   FI_CHECK_LAUNCH();

@@ -233,7 +233,8 @@ int fi_gatedcrf_fwd(const float* y, const float* feat, int N, int H, int W, int 
  * fi_tree_aggr_up  : out[i] = x[sorted_index[i]] + sum_child out[child]*w[child]   (x == NULL: 1)   refine.cu:70-134
  * fi_tree_prop_down: out[sorted_index[i]] = x[i]*(1 - w[i]^2) + out[parent vertex]*w[i], w[root] := 0 refine.cu:19-68
  * fi_tree_grad_rec : edge-weight gradient recursion, in_grad propagated in place                    refine.cu:136-199
- *   (in_data / in_grad sorted, out_data original order; Cd data channels, Cg gradient channels, grad [B][max][V] sorted). */
+ *   (in_data / in_grad sorted, out_data original order; Cd data channels, Cg gradient channels, grad [B][max][V] sorted;
+ *   Cd == Cg or Cd == 1 -- in_grad is propagated in place by one workgroup per gradient channel, else FI_ERR_UNSUPPORTED). */
 long fi_tree_mst_workspace(int H, int W);
 int fi_tree_grid_weights(const float* fm, int B, int C, int H, int W, float* weight, void* stream);
 int fi_tree_mst(const float* weight, int B, int H, int W, int* edge_out, void* workspace, long workspace_bytes,
