@@ -14,6 +14,7 @@
 //                            (image, channel), all nodes of a BFS level in parallel, one barrier per level
 // Layouts: per-image planes [B][C][V] fp32 (V = H*W, row-major pixels) -- the loss works on NCHW fp32 tensors.
 #include "common.h"
+#include <cstdlib>
 
 #define TREE_THREADS 1024
 
@@ -223,6 +224,125 @@ __global__ __launch_bounds__(TREE_THREADS) void tree_bfs_kernel(const int* __res
     __syncthreads();
   }
   if (tid == 0) lv[0] = nlev;
+}
+
+// ---- breadth-first order with the whole traversal state in LDS (the path fi_tree_bfs takes whenever it fits: images
+// up to ~512^2).  A level of the global-memory kernel above is a chain of three dependent global round trips
+// (position -> vertex -> adjacency) plus five full barriers, ~1.9 us; the trees are 1200-2100 levels deep.  Here
+//   * the adjacency of a grid tree is 4 bits per vertex (up, down, left, right) -- V/2 bytes, 32 KB for 256^2 -- built in
+//     LDS with atomicOr straight from the edge list; the neighbours are cur-W, cur+W, cur-1, cur+1;
+//   * the current and the next frontier (vertex, parent vertex per position) are double-buffered in LDS;
+//   * the outputs (sorted_index / parent / children, level boundaries) are fire-and-forget global stores, and the barriers
+//     between levels wait for the LDS queue only.
+// A level wider than the frontier buffer is served from the global outputs already written (behind a full barrier).
+// Children are emitted in the same order (up, down, left, right, minus the parent): identical output.
+#define BFS_T 256
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(BFS_T) void tree_bfs_lds_kernel(const int* __restrict__ edges, int* __restrict__ sidx,
+                                                             int* __restrict__ spar, int* __restrict__ schild,
+                                                             int* __restrict__ levels, int H, int W, int cap) {
+  extern __shared__ uint32_t dyn[];
+  const int V = H * W, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nw = (V + 7) / 8;
+  uint32_t* mask = dyn;                               // 4 bits per vertex
+  int* fv = reinterpret_cast<int*>(dyn + nw);         // [2][cap] vertex of every position of the level
+  int* fp = fv + 2 * cap;                             // [2][cap] vertex of its parent
+  const int* ed = edges + (size_t)b * (V - 1) * 2;
+  int* si = sidx + (size_t)b * V;
+  int* sp = spar + (size_t)b * V;
+  int* sc = schild + (size_t)b * V * 4;
+  int* lv = levels + (size_t)b * (V + 2);
+  for (int i = tid; i < nw; i += BFS_T) mask[i] = 0u;
+  {
+    int4* sc4 = reinterpret_cast<int4*>(sc);
+    for (int i = tid; i < V; i += BFS_T) sc4[i] = make_int4(0, 0, 0, 0);
+  }
+  __syncthreads();                                    // the zeroed children must land before any child slot is written
+  for (int i0 = tid; i0 < V - 1; i0 += 4 * BFS_T) {     // four edge loads in flight per thread
+    int2 e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * BFS_T;
+      e[u] = i < V - 1 ? reinterpret_cast<const int2*>(ed)[i] : make_int2(-1, -1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e[u].x < 0) continue;
+      const int a = min(e[u].x, e[u].y), c = max(e[u].x, e[u].y);
+      const uint32_t ba = c == a + W ? 2u : 8u, bc = c == a + W ? 1u : 4u;    // a: down / right, c: up / left
+      atomicOr(&mask[a >> 3], ba << ((a & 7) * 4));
+      atomicOr(&mask[c >> 3], bc << ((c & 7) * 4));
+    }
+  }
+  if (tid == 0) {
+    si[0] = 0, sp[0] = 0, lv[1] = 0;
+    fv[0] = 0, fp[0] = -1;
+  }
+  lds_barrier();
+  // The traversal itself is run by ONE wavefront: a level has ~40 nodes, and a single wave needs no barrier at all
+  // (its LDS operations are ordered), while the prefix sum over the 0..4 children per node is three ballots.
+  if (wv != 0) return;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int lo = 0, hi = 1, nlev = 0;
+  bool in_lds = true;                                 // the current level's frontier is in fv/fp[nlev & 1]
+  while (lo < hi) {
+    const int* cv = fv + (nlev & 1) * cap;
+    const int* cp = fp + (nlev & 1) * cap;
+    int* nv = fv + ((nlev + 1) & 1) * cap;
+    int* np_ = fp + ((nlev + 1) & 1) * cap;
+    int next = hi;
+    // 64 positions; called from two separate branches so that the LDS-fed one contains no global load (a merged value
+    // would put an s_waitcnt vmcnt -- i.e. a wait for the stores in flight -- on every level)
+    auto chunk = [&](int i, int cur, int pv) {
+      int kids[4], nk = 0;
+      if (i < hi) {
+        const uint32_t m = (mask[cur >> 3] >> ((cur & 7) * 4)) & 15u;
+        if ((m & 1u) && cur - W != pv) kids[nk++] = cur - W;
+        if ((m & 2u) && cur + W != pv) kids[nk++] = cur + W;
+        if ((m & 4u) && cur - 1 != pv) kids[nk++] = cur - 1;
+        if ((m & 8u) && cur + 1 != pv) kids[nk++] = cur + 1;
+      }
+      const unsigned long long b0 = __ballot(nk & 1), b1 = __ballot(nk & 2), b2 = __ballot(nk & 4);
+      const int off = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+      const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      for (int q = 0; q < nk; ++q) {
+        const int pos = next + off + q;
+        si[pos] = kids[q];
+        sp[pos] = i;
+        sc[i * 4 + q] = pos;
+        if (pos - hi < cap) nv[pos - hi] = kids[q], np_[pos - hi] = cur;
+      }
+      next += total;
+    };
+    if (in_lds) {
+      for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < hi;
+        chunk(i, ok ? cv[i - lo] : 0, ok ? cp[i - lo] : -1);
+      }
+    } else {
+      // a level wider than the frontier buffer: re-read what this wave stored (device-scope loads: not through a stale L1)
+      __threadfence();
+      for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < hi;
+        const int cur = ok ? __hip_atomic_load(si + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int pv = -1;
+        if (ok && i > 0) {
+          const int pp = __hip_atomic_load(sp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pv = __hip_atomic_load(si + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        chunk(i, cur, pv);
+      }
+    }
+    ++nlev;
+    if (lane == 0) lv[1 + nlev] = hi;
+    lo = hi;
+    hi = next;
+    in_lds = hi - lo <= cap;
+  }
+  if (lane == 0) lv[0] = nlev;
 }
 
 // ---- tree edge weights (sorted order) and their gradient w.r.t. the embedding
@@ -597,8 +717,24 @@ extern "C" int fi_tree_bfs(const int* edges, int B, int H, int W, int* sorted_in
                            int* levels, int* adjacency_workspace, void* stream) {
   if (!edges || !sorted_index || !sorted_parent || !sorted_child || !levels || !adjacency_workspace) return FI_ERR_NULL;
   if (B < 1 || H < 2 || W < 2) return FI_ERR_SHAPE;
-  hipLaunchKernelGGL(tree_bfs_kernel, dim3(B), dim3(TREE_THREADS), 0, (hipStream_t)stream, edges, sorted_index, sorted_parent,
-                     sorted_child, levels, adjacency_workspace, H, W);
+  const long V = (long)H * W;
+  const int cap = 2048;
+  const long lds = ((V + 7) / 8) * 4 + 4L * cap * 4;
+  const char* force = getenv("FI_TREE_BFS_GLOBAL");       // tests: exercise the global-memory kernel on small images too
+  if (lds <= 150 * 1024 && !(force && force[0] == '1')) { // adjacency bit-mask + both frontiers fit in LDS
+    static bool raised = false;                           // > 64 KB of dynamic LDS has to be allowed once per process
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tree_bfs_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e != hipSuccess) return (int)e;
+      raised = true;
+    }
+    hipLaunchKernelGGL(tree_bfs_lds_kernel, dim3(B), dim3(BFS_T), (size_t)lds, (hipStream_t)stream, edges, sorted_index,
+                       sorted_parent, sorted_child, levels, H, W, cap);
+  } else {
+    hipLaunchKernelGGL(tree_bfs_kernel, dim3(B), dim3(TREE_THREADS), 0, (hipStream_t)stream, edges, sorted_index, sorted_parent,
+                       sorted_child, levels, adjacency_workspace, H, W);
+  }
   FI_CHECK_LAUNCH();
   return 0;
 }

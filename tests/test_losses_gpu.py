@@ -85,13 +85,22 @@ def test_tree_mst_is_the_references_tree(case):
     sidx = torch.empty((B, V), dtype=torch.int32, device=DEV)
     spar, schild = torch.empty_like(sidx), torch.empty((B, V, 4), dtype=torch.int32, device=DEV)
     levels = torch.empty((B, V + 2), dtype=torch.int32, device=DEV)
-    L.tree_bfs(tree.edges, H, W, sidx, spar, schild, levels)
-    for b in range(B):
-        rs, rp, rc, rl = T.bfs(edges[b], V, W)
-        assert np.array_equal(sidx[b].cpu().numpy(), rs) and np.array_equal(spar[b].cpu().numpy(), rp)
-        assert np.array_equal(schild[b].cpu().numpy(), rc)
-        lv = levels[b].cpu().numpy()
-        assert lv[0] == len(rl) - 1 and list(lv[1:2 + lv[0]]) == rl
+    import os
+    for force_global in ("0", "1"):              # the LDS-resident traversal and the global-memory kernel behind it
+        os.environ["FI_TREE_BFS_GLOBAL"] = force_global
+        try:
+            for t in (sidx, spar, schild, levels):
+                t.fill_(-7)
+            L.tree_bfs(tree.edges, H, W, sidx, spar, schild, levels)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("FI_TREE_BFS_GLOBAL", None)
+        for b in range(B):
+            rs, rp, rc, rl = T.bfs(edges[b], V, W)
+            assert np.array_equal(sidx[b].cpu().numpy(), rs) and np.array_equal(spar[b].cpu().numpy(), rp)
+            assert np.array_equal(schild[b].cpu().numpy(), rc)
+            lv = levels[b].cpu().numpy()
+            assert lv[0] == len(rl) - 1 and list(lv[1:2 + lv[0]]) == rl
 
 
 @pytest.mark.parametrize("low_tree", [True, False])
