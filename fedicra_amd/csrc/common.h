@@ -27,6 +27,10 @@ template <> struct DT<bf16_t> {
 };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() additionally waits
+// for every global load AND store of the wave (vmcnt(0)); after an epilogue's stores that is ~1 us of store-ack latency.
+__device__ __forceinline__ void fi_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }

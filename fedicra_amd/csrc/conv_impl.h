@@ -428,7 +428,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   }
   FI_TR(4);
   if (a.stats) {
-    __syncthreads();  // LDS reuse: all MFMA reads are done
+    // LDS reuse: all MFMA reads are done.  LDS-only barriers here: __syncthreads() would also wait (vmcnt(0)) until the
+    // output stores just issued are acknowledged -- ~1 us during which the workgroup holds its registers and LDS.
+    fi_lds_barrier();
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = q;
         }
       }
-    __syncthreads();
+    fi_lds_barrier();
     if (tid < BN * 2) {
       const int c = tid >> 1, which = tid & 1;
       const int co = ct * BN + c;
