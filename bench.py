@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # TFLOP/s dense (guide: 2.5 PF bf16, 157.3 TF fp32-input MFMA)
+MFMA_PEAK = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}   # TFLOP/s dense (guide: 2.5 PF bf16, 157.3 TF fp32-input MFMA)
 
 # conv-only algorithmic FLOPs per image, UNet(1,2): F_train = 3*F_fwd - first-layer dgrad
 F_FWD_256 = 5.8615e9
@@ -114,7 +114,7 @@ def roofline_pass(client, a, dtype_name):
     avg_ms = dom["ms"] / calls
     flops, nbytes = dom["flops"] / calls, dom["bytes"] / calls
     ai = flops / max(nbytes, 1.0)
-    mf_peak = MFMA_PEAK["bf16" if dtype_name == "bf16" else "f32"]
+    mf_peak = MFMA_PEAK[{"bf16": "bf16", "fp16": "fp16"}.get(dtype_name, "f32")]
     ridge = mf_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     if flops > 0 and ai >= ridge:
         bound, ach, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, mf_peak, "TFLOP/s"
@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--round-iters", type=int, default=10)
@@ -255,7 +255,7 @@ def main():
             "metric": "images/sec (2D U-Net local training, all clients) ; ms/aggregation round in config",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: {nclients} clients FedAvg, 2D U-Net(1,2) "
                                    f"{a.batch}x1x{a.size}x{a.size} per client, {Cg} client(s) per MI355X (one HIP stream + "
                                    f"captured step each), step = one local iteration of every client, round = "

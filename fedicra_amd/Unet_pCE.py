@@ -40,7 +40,7 @@ def train(args, snapshot_path=None, trainloader=None, valloader=None, model=None
     dev = model.flat_params.device
     if amp:
         scaler = GradScaler()
-        set_compute_dtype(model, "bf16")
+        set_compute_dtype(model, getattr(args, "amp_dtype", "fp16"))
     model.train()
     opt = FusedSGD(model, lr=base_lr, base_lr=base_lr, max_iterations=max_iterations, momentum=0.9, weight_decay=1e-4)
     opt.iter.fill_(-1)          # advance_lr() increments first: starting at -1 gives lr = f(iter_num BEFORE increment)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfedicra_hip.so")
 LIB_PATH = os.environ.get("FEDICRA_HIP_LIB", LIB_PATH)        # another build of the same C ABI (kernel A/B runs)
 
-FI_F32, FI_BF16 = 0, 1
+FI_F32, FI_BF16, FI_F16 = 0, 1, 2
 STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
@@ -73,6 +73,8 @@ def dt(t: torch.dtype) -> int:
         return FI_F32
     if t == torch.bfloat16:
         return FI_BF16
+    if t == torch.float16:
+        return FI_F16
     raise FiError(f"unsupported dtype {t}")
 
 

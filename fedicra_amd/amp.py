@@ -1,10 +1,12 @@
 """`--amp 1` of the reference (autocast + torch.cuda.amp.GradScaler: /root/reference/code/flower_pCE_2D.py:47-48,104,
 143-146; flower_common.py:466-468,576-584), MI355X-native.
 
-* ``autocast(enabled=amp)`` maps to the reduced-precision compute mode of the HIP path: bf16 storage / operands with fp32
-  MFMA accumulation, fp32 statistics, losses, master weights and optimizer (`set_compute_dtype(model, "bf16")`).  CDNA4
-  runs bf16 and fp16 MFMA at the same rate; bf16 keeps fp32's exponent range, so under-/overflow -- the reason fp16
-  autocast needs a scaler -- does not arise in the forward pass.
+* ``autocast(enabled=amp)`` maps to the reduced-precision compute mode of the HIP path: 16-bit storage / MFMA operands
+  with fp32 accumulation, fp32 statistics, losses, master weights and optimizer.  The default is **fp16**
+  (`set_compute_dtype(model, "fp16")`, FI_F16 kernels), the dtype the reference's ``torch.cuda.amp.autocast`` uses: its
+  5 exponent bits are why the scaler below exists -- a scaled gradient that leaves fp16's range becomes inf, the step
+  is skipped and the scale halved.  ``args.amp_dtype = "bf16"`` selects bf16 instead (same MFMA rate on CDNA4, fp32's
+  exponent range: the scaler then never fires); bench.py's performance mode is bf16 without a scaler.
 * ``GradScaler`` keeps the reference's control flow and state machine exactly (scale(loss).backward(); step(optimizer);
   update(): init_scale 2**16, x2 after 2000 clean steps, x0.5 and a SKIPPED optimizer step when a gradient is inf/NaN),
   with scale / growth tracker / found-inf flag resident on the device, so the whole iteration stays hipGraph-capturable.

@@ -7,6 +7,8 @@
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16_t;                  // IEEE half: the storage type of the reference's autocast path
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define FI_WAVE 64
@@ -31,16 +33,26 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 // for every global load AND store of the wave (vmcnt(0)); after an epilogue's stores that is ~1 us of store-ack latency.
 __device__ __forceinline__ void fi_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <> struct DT<f16_t> {
+  static constexpr int VG = 8, KSTEP = 32, KV = 8;
+  typedef uint4 vec_t;
+  typedef f16x8 frag_t;
+};
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }      // overflow -> inf (GradScaler's signal)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // wave-wide sum via xor shuffles (64 lanes)

@@ -13,6 +13,12 @@ int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_bf16_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_bf16_k3(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_fwd_f16_k1(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_f16_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
+int fi_conv_wgrad_f16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_f16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_f16_k1(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_quad_f16_k3(int th, const WgradArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -51,7 +57,7 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
   if (!d || !x0 || !w || !y0) return FI_ERR_NULL;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1 || d->co1 < 0) return FI_ERR_SHAPE;
   if ((d->c1 > 0 && !x1) || (d->co1 > 0 && !y1)) return FI_ERR_NULL;
@@ -125,6 +131,7 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
 #endif
   hipStream_t st = (hipStream_t)stream;
   if (f32) return d->ksize == 3 ? fi_conv_fwd_f32_k3(th, nf, ck, a, st) : fi_conv_fwd_f32_k1(th, nf, ck, a, st);
+  if (d->dtype == FI_F16) return d->ksize == 3 ? fi_conv_fwd_f16_k3(th, nf, ck, a, st) : fi_conv_fwd_f16_k1(th, nf, ck, a, st);
   return d->ksize == 3 ? fi_conv_fwd_bf16_k3(th, nf, ck, a, st) : fi_conv_fwd_bf16_k1(th, nf, ck, a, st);
 }
 
@@ -137,7 +144,7 @@ struct WgradPlan {
 };
 static int plan_wgrad(const FiConv* d, WgradPlan* p) {
   if (!d) return FI_ERR_NULL;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1) return FI_ERR_SHAPE;
   const int cin = d->c0 + d->c1, cout = d->co0;
@@ -286,10 +293,14 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   if (p.quad) {
     if (d->dtype == FI_F32)
       r = d->ksize == 3 ? fi_conv_wgrad_quad_f32_k3(p.th, a, st) : fi_conv_wgrad_quad_f32_k1(p.th, a, st);
+    else if (d->dtype == FI_F16)
+      r = d->ksize == 3 ? fi_conv_wgrad_quad_f16_k3(p.th, a, st) : fi_conv_wgrad_quad_f16_k1(p.th, a, st);
     else
       r = d->ksize == 3 ? fi_conv_wgrad_quad_bf16_k3(p.th, a, st) : fi_conv_wgrad_quad_bf16_k1(p.th, a, st);
   } else if (d->dtype == FI_F32) {
     r = d->ksize == 3 ? fi_conv_wgrad_f32_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_f32_k1(p.th, p.nfo, p.nfi, a, st);
+  } else if (d->dtype == FI_F16) {
+    r = d->ksize == 3 ? fi_conv_wgrad_f16_k3(p.th, p.nfo, p.nfi, a, st) : fi_conv_wgrad_f16_k1(p.th, p.nfo, p.nfi, a, st);
   } else {
     r = d->ksize == 3 ? fi_conv_wgrad_bf16_k3(p.th, p.nfo, p.nfi, a, st)
                       : fi_conv_wgrad_bf16_k1(p.th, p.nfo, p.nfi, a, st);

@@ -571,6 +571,30 @@ template <> struct WgFrag<bf16_t> {
   }
 };
 
+template <> struct WgFrag<f16_t> {
+  // same transpose read as bf16: ds_read_b64_tr_b16 moves 16-bit lanes, whatever they encode
+  static __device__ __forceinline__ f16x8 load(const f16_t* tile, int rowlen, int stride, int ks, int r, int s,
+                                                int chan, int kg, int li) {
+    const f16_t* p0 = tile + ((2 * ks + r) * rowlen + 4 * kg + (li >> 2) + s) * stride + chan + 4 * (li & 3);
+    const f16_t* p1 = p0 + rowlen * stride;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    union {
+      s16x4_t h[2];
+      f16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+  }
+  static __device__ __forceinline__ f16x8 ones() {
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (f16_t)1.0f;
+    return v;
+  }
+};
+
 template <typename T, int KS, int TH, int NFO, int NFI, bool VECX, bool VECD>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;

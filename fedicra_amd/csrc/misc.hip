@@ -133,6 +133,9 @@ extern "C" int fi_ce_bwd(const float* logits, const uint8_t* labels, long M, int
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(grid_for(M, 256 * 2)), dim3(256), 0, st, logits, labels, M, C,
                        ignore_index, acc, gscale, (bf16_t*)dlogits);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(ce_bwd_kernel<f16_t>, dim3(grid_for(M, 256 * 2)), dim3(256), 0, st, logits, labels, M, C,
+                       ignore_index, acc, gscale, (f16_t*)dlogits);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -549,6 +552,8 @@ extern "C" int fi_global_avgmax(int dtype, const void* x, float* avg, float* mx,
     hipLaunchKernelGGL(global_avgmax_kernel<float>, g, b, 0, st, (const float*)x, avg, mx, amax, HW, C);
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(global_avgmax_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, avg, mx, amax, HW, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(global_avgmax_kernel<f16_t>, g, b, 0, st, (const f16_t*)x, avg, mx, amax, HW, C);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -577,6 +582,9 @@ extern "C" int fi_channel_gate_fwd(int dtype, const void* x, const float* h, voi
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(channel_gate_fwd_kernel<bf16_t>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, st,
                        (const bf16_t*)x, h, (bf16_t*)y, n, HW, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(channel_gate_fwd_kernel<f16_t>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, st,
+                       (const f16_t*)x, h, (f16_t*)y, n, HW, C);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -625,6 +633,9 @@ extern "C" int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, con
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(channel_gate_bwd_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, (const bf16_t*)dy, h, amax,
                        davg, dmx, (bf16_t*)dx, dh, HW, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(channel_gate_bwd_kernel<f16_t>, g, b, 0, st, (const f16_t*)x, (const f16_t*)dy, h, amax,
+                       davg, dmx, (f16_t*)dx, dh, HW, C);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale, const float* shift, void* z,
                              void* stream) {
   if (!d || !y || !scale || !shift || !z) return FI_ERR_NULL;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   {
     const int vg = d->dtype == FI_F32 ? 4 : 8;
     if (d->C % vg || d->C / vg > 256 || 256 % (d->C / vg)) return FI_ERR_SHAPE;   // CV must divide the block
@@ -246,6 +246,12 @@ extern "C" int fi_bn_act_fwd(const FiBnAct* d, const void* y, const float* scale
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const bf16_t*)y,
                        scale, shift, (bf16_t*)z, nvec, d->C, d->slope, dr);
+  } else if (d->dtype == FI_F16) {
+    if (d->C % 8) return FI_ERR_SHAPE;
+    const long nvec = d->pixels * (d->C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+    hipLaunchKernelGGL(bn_act_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const f16_t*)y,
+                       scale, shift, (f16_t*)z, nvec, d->C, d->slope, dr);
   } else {
     return FI_ERR_DTYPE;
   }
@@ -347,7 +353,7 @@ extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void
   const DropSpec dr = make_drop(d);
   hipStream_t st = (hipStream_t)stream;
   const int VG = d->dtype == FI_F32 ? 4 : 8;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   if (d->C % VG) return FI_ERR_SHAPE;
   const int CV = d->C / VG;
   if (CV > 256 || 256 % CV) return FI_ERR_SHAPE;
@@ -356,6 +362,9 @@ extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void
   if (d->dtype == FI_F32)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
                        (const float*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+  else if (d->dtype == FI_F16)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)dz,
+                       (const f16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
   else
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
                        (const bf16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
@@ -467,7 +476,7 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
                                    int training, void* dy, float* dgamma, float* dbeta, int accumulate_param,
                                    void* stream) {
   if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   {
     const int vg = d->dtype == FI_F32 ? 4 : 8;
     if (d->C % vg || d->C / vg > 256 || 256 % (d->C / vg) || d->C > 512) return FI_ERR_SHAPE;   // CV divides the block; LDS fold holds 512 channels
@@ -485,6 +494,8 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
                      d->slope, dr)
   if (d->dtype == FI_F32) {
     if (hoist) FI_APPLY(float, true); else FI_APPLY(float, false);
+  } else if (d->dtype == FI_F16) {
+    if (hoist) FI_APPLY(f16_t, true); else FI_APPLY(f16_t, false);
   } else {
     if (hoist) FI_APPLY(bf16_t, true); else FI_APPLY(bf16_t, false);
   }
@@ -588,6 +599,12 @@ extern "C" int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, 
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const bf16_t*)x,
                        (bf16_t*)y, N, H, W, C);
+  } else if (dtype == FI_F16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+    hipLaunchKernelGGL(maxpool_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const f16_t*)x,
+                       (f16_t*)y, N, H, W, C);
   } else {
     return FI_ERR_DTYPE;
   }
@@ -612,6 +629,12 @@ static int maxpool_bwd_impl(int dtype, const void* x, const void* dy, const void
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)add, (bf16_t*)dx, N, H, W, C);
+  } else if (dtype == FI_F16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * (H / 2) * (W / 2) * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+    hipLaunchKernelGGL(maxpool_bwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
+                       (const f16_t*)x, (const f16_t*)dy, (const f16_t*)add, (f16_t*)dx, N, H, W, C);
   } else {
     return FI_ERR_DTYPE;
   }
@@ -803,6 +826,12 @@ extern "C" int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
                        (const bf16_t*)x, (bf16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
+  } else if (dtype == FI_F16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * 4 * h * w * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+    hipLaunchKernelGGL(upsample_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
+                       (const f16_t*)x, (f16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
   } else {
     return FI_ERR_DTYPE;
   }
@@ -826,6 +855,12 @@ extern "C" int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int
     if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
     hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for((long)N * h * ((w * (C / 8) + 63) / 64), 4)), dim3(256), 0, st, (const bf16_t*)dy,
                        (bf16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
+  } else if (dtype == FI_F16) {
+    if (C % 8) return FI_ERR_SHAPE;
+    const long nvec = (long)N * h * w * (C / 8);
+    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+    hipLaunchKernelGGL(upsample_bwd_kernel<f16_t>, dim3(grid_for((long)N * h * ((w * (C / 8) + 63) / 64), 4)), dim3(256), 0, st, (const f16_t*)dy,
+                       (f16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
   } else {
     return FI_ERR_DTYPE;
   }
@@ -864,6 +899,9 @@ extern "C" int fi_pack_weights(const float* src, void* dst, int cout, int kk, in
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (bf16_t*)dst, cout,
                        kk, cin, mode);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(pack_weights_kernel<f16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (f16_t*)dst, cout,
+                       kk, cin, mode);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -888,6 +926,12 @@ extern "C" int fi_cast(const void* src, int sd, void* dst, int dd, long n, void*
     hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
   else if (sd == FI_BF16 && dd == FI_BF16)
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else if (sd == FI_F32 && dd == FI_F16)
+    hipLaunchKernelGGL((cast_kernel<float, f16_t>), g, b, 0, st, (const float*)src, (f16_t*)dst, n);
+  else if (sd == FI_F16 && dd == FI_F32)
+    hipLaunchKernelGGL((cast_kernel<f16_t, float>), g, b, 0, st, (const f16_t*)src, (float*)dst, n);
+  else if (sd == FI_F16 && dd == FI_F16)
+    hipLaunchKernelGGL((cast_kernel<f16_t, f16_t>), g, b, 0, st, (const f16_t*)src, (f16_t*)dst, n);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -931,6 +975,9 @@ extern "C" int fi_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, in
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (bf16_t*)dst, N, C,
                        H, W);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, src, (f16_t*)dst, N, C,
+                       H, W);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -946,6 +993,9 @@ extern "C" int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, in
                        N, C, H, W);
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)src, dst,
+                       N, C, H, W);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const f16_t*)src, dst,
                        N, C, H, W);
   else
     return FI_ERR_DTYPE;
@@ -1006,6 +1056,8 @@ extern "C" int fi_pack_weights_multi(const long long* table, int ntensors, int d
     hipLaunchKernelGGL(pack_weights_multi_kernel<float>, g, b, 0, (hipStream_t)stream, table);
   else if (dtype == FI_BF16)
     hipLaunchKernelGGL(pack_weights_multi_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, table);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(pack_weights_multi_kernel<f16_t>, g, b, 0, (hipStream_t)stream, table);
   else
     return FI_ERR_DTYPE;
   FI_CHECK_LAUNCH();
@@ -1111,7 +1163,7 @@ extern "C" int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const d
                                float momentum, float eps, int training, float* coef, void* stream) {
   if (!d || !y || !z || !gamma || !beta || !running_mean || !running_var || !coef) return FI_ERR_NULL;
   if (training && !stats) return FI_ERR_NULL;
-  if (d->dtype != FI_F32 && d->dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   const int vg = d->dtype == FI_F32 ? 4 : 8;
   if (d->C % vg || d->C > 512 || 256 % (d->C / vg)) return FI_ERR_SHAPE;
   const long nvec = d->pixels * (d->C / vg);
@@ -1124,6 +1176,10 @@ extern "C" int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const d
     hipLaunchKernelGGL(bn_fused_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const float*)y,
                        (float*)z, stats, (double)d->pixels, gamma, beta, running_mean, running_var, nbt, momentum,
                        eps, training, coef, nvec, d->C, d->slope, dr);
+  else if (d->dtype == FI_F16)
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
+                       (const f16_t*)y, (f16_t*)z, stats, (double)d->pixels, gamma, beta, running_mean,
+                       running_var, nbt, momentum, eps, training, coef, nvec, d->C, d->slope, dr);
   else
     hipLaunchKernelGGL(bn_fused_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
                        (const bf16_t*)y, (bf16_t*)z, stats, (double)d->pixels, gamma, beta, running_mean,

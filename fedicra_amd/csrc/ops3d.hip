@@ -211,12 +211,15 @@ extern "C" int fi_maxpool3d_fwd(int dtype, const void* x, void* y, int N, int D,
   if ((D & 1) || (H & 1) || (W & 1)) return FI_ERR_SHAPE;
   hipStream_t st_ = (hipStream_t)stream;
   const int vg = dtype == FI_F32 ? 4 : 8;
-  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (dtype != FI_F32 && dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_DTYPE;
   if (C % vg) return FI_ERR_SHAPE;
   const long nvec = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / vg);
   if (dtype == FI_F32)
     hipLaunchKernelGGL((maxpool3d_kernel<float, false>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x,
                        (const float*)nullptr, (float*)y, N, D, H, W, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL((maxpool3d_kernel<f16_t, false>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const f16_t*)x,
+                       (const f16_t*)nullptr, (f16_t*)y, N, D, H, W, C);
   else
     hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, false>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
                        (const bf16_t*)nullptr, (bf16_t*)y, N, D, H, W, C);
@@ -230,12 +233,15 @@ extern "C" int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* 
   if ((D & 1) || (H & 1) || (W & 1)) return FI_ERR_SHAPE;
   hipStream_t st_ = (hipStream_t)stream;
   const int vg = dtype == FI_F32 ? 4 : 8;
-  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (dtype != FI_F32 && dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_DTYPE;
   if (C % vg) return FI_ERR_SHAPE;
   const long nvec = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / vg);
   if (dtype == FI_F32)
     hipLaunchKernelGGL((maxpool3d_kernel<float, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x,
                        (const float*)dy, (float*)dx, N, D, H, W, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL((maxpool3d_kernel<f16_t, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const f16_t*)x,
+                       (const f16_t*)dy, (f16_t*)dx, N, D, H, W, C);
   else
     hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
                        (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, C);
@@ -247,12 +253,15 @@ extern "C" int fi_upsample3d2x_fwd(int dtype, const void* x, void* y, int N, int
   if (!x || !y) return FI_ERR_NULL;
   hipStream_t st_ = (hipStream_t)stream;
   const int vg = dtype == FI_F32 ? 4 : 8;
-  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (dtype != FI_F32 && dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_DTYPE;
   if (C % vg) return FI_ERR_SHAPE;
   const long nvec = (long)N * 8 * d * h * w * (C / vg);
   if (dtype == FI_F32)
     hipLaunchKernelGGL(upsample3d_fwd_kernel<float>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x, (float*)y,
                        N, d, h, w, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(upsample3d_fwd_kernel<f16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const f16_t*)x,
+                       (f16_t*)y, N, d, h, w, C);
   else
     hipLaunchKernelGGL(upsample3d_fwd_kernel<bf16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
                        (bf16_t*)y, N, d, h, w, C);
@@ -264,12 +273,15 @@ extern "C" int fi_upsample3d2x_bwd(int dtype, const void* dy, void* dx, int N, i
   if (!dy || !dx) return FI_ERR_NULL;
   hipStream_t st_ = (hipStream_t)stream;
   const int vg = dtype == FI_F32 ? 4 : 8;
-  if (dtype != FI_F32 && dtype != FI_BF16) return FI_ERR_DTYPE;
+  if (dtype != FI_F32 && dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_DTYPE;
   if (C % vg) return FI_ERR_SHAPE;
   const long nvec = (long)N * d * h * w * (C / vg);
   if (dtype == FI_F32)
     hipLaunchKernelGGL(upsample3d_bwd_kernel<float>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)dy,
                        (float*)dx, N, d, h, w, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(upsample3d_bwd_kernel<f16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const f16_t*)dy,
+                       (f16_t*)dx, N, d, h, w, C);
   else
     hipLaunchKernelGGL(upsample3d_bwd_kernel<bf16_t>, dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)dy,
                        (bf16_t*)dx, N, d, h, w, C);

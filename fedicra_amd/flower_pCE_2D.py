@@ -47,7 +47,9 @@ class MyClient(BaseClient):
             from .amp import GradScaler
             from .networks.unet import set_compute_dtype
             self.scaler = GradScaler()
-            set_compute_dtype(model.model, "bf16")           # autocast(enabled=True): reduced-precision compute (amp.py)
+            # autocast(enabled=True): fp16 storage / operands like the reference's torch.cuda.amp (amp.py); bf16 -- the same
+            # MFMA rate on CDNA4, fp32's exponent range -- with args.amp_dtype = "bf16"
+            set_compute_dtype(model.model, getattr(args, "amp_dtype", "fp16"))
         self.best_performance = 0.0
         self.use_graph = bool(getattr(args, "use_graph", False))
         self.optimizer = None

@@ -29,7 +29,8 @@ from ..flat import FlatStoreMixin
 FEATURE_CHNS = [16, 32, 64, 128, 256]
 DROPOUT = [0.05, 0.1, 0.2, 0.3, 0.5]
 
-_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+           "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}
 
 
 def default_compute_dtype():

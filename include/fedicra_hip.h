@@ -28,6 +28,7 @@ extern "C" {
 
 #define FI_F32 0
 #define FI_BF16 1
+#define FI_F16 2 /* IEEE half storage, fp32 accumulation: the reference's autocast dtype (flower_pCE_2D.py:104) */
 
 #define FI_OK 0
 #define FI_ERR_DTYPE (-1)

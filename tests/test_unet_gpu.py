@@ -97,10 +97,12 @@ def test_unet_lc_forward_and_quirks(golden):
         assert_ck(o[i].float().cpu(), g[f"mh_eval_aux{i-6}_ck"], rtol=2e-5, atol=1e-5, what=f"aux{i-6}")
 
 
-def test_unet_bf16_mode_close_to_fp32(golden):
+@pytest.mark.parametrize("dtype,bound", [("bf16", 0.15), ("fp16", 0.02)])
+def test_unet_bf16_mode_close_to_fp32(golden, dtype, bound):
+    """16-bit storage modes against the reference's fp32 logits: bf16 (8 significant bits) and fp16 (11)."""
     from fedicra_amd.networks.unet import UNet
     g = golden("g2_unet_fwd.npz")
-    m = _mk(UNet, 1, 2, dtype="bf16").eval()
+    m = _mk(UNet, 1, 2, dtype=dtype).eval()
     x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
     with torch.no_grad():
         lg = m(x)[0]
@@ -108,8 +110,8 @@ def test_unet_bf16_mode_close_to_fp32(golden):
     assert lg.dtype == torch.float32
     err = (lg.cpu() - ref).abs().max().item()
     agree = (lg.cpu().argmax(1) == ref.argmax(1)).float().mean().item()
-    print(f"bf16 eval logits: max err {err:.3e}, argmax agreement {agree:.5f}")
-    assert err < 0.15 and agree > 0.99
+    print(f"{dtype} eval logits: max err {err:.3e}, argmax agreement {agree:.5f}")
+    assert err < bound and agree > 0.99
 
 
 def _args(**kw):
@@ -461,10 +463,13 @@ def test_evaluate_dice_matches_oracle():
     assert abs(met["val_1_dice"] - tot / 6) < 1e-4
 
 
-def test_amp_gradscaler_matches_reference_state_machine():
-    """`--amp 1` (a19): loss scaling by a power of two is exact, so a clean AMP run reproduces the plain bf16 run; an
-    inf/NaN gradient skips the optimizer step (parameters, moments and step count untouched), halves the scale and
-    clears the flag -- torch.cuda.amp.GradScaler's state machine, held on the device."""
+@pytest.mark.parametrize("amp_dtype", ["fp16", "bf16"])
+def test_amp_gradscaler_matches_reference_state_machine(amp_dtype):
+    """`--amp 1` (a19): autocast = 16-bit storage (fp16 like the reference's torch.cuda.amp, or bf16), GradScaler's state
+    machine held on the device.  Loss scaling by a power of two is exact in bf16 (fp32's exponent range), so a clean AMP
+    run reproduces the plain bf16 run; in fp16 it only changes which tiny gradients survive, so the runs agree to fp16
+    accuracy.  An inf/NaN gradient skips the optimizer step (parameters, moments and step count untouched), halves the
+    scale and clears the flag."""
     from fedicra_amd import ops
     from fedicra_amd.amp import GradScaler
     from fedicra_amd.flower_common import MyModel
@@ -475,22 +480,25 @@ def test_amp_gradscaler_matches_reference_state_machine():
     finals, losses = [], []
     for amp in (False, True):
         for use_graph in ((False,) if not amp else (False, True)):
-            args = _args(use_graph=use_graph, iters=4, amp=int(amp))
+            args = _args(use_graph=use_graph, iters=4, amp=int(amp), amp_dtype=amp_dtype)
             ops.manual_seed(1)
-            net = _mk(UNet, 1, 2, dtype="bf16")
+            net = _mk(UNet, 1, 2, dtype=amp_dtype)
             client = MyClient(args, MyModel(args, net, batches, batches), batches, batches, amp=amp)
+            assert net.compute_dtype() == {"fp16": torch.float16, "bf16": torch.bfloat16}[amp_dtype]
             client._train({"iter_global": 4, "iters": 4, "eval_iters": 8, "batch_size": 4, "stage": "fit"})
             finals.append(net.flat_state.clone())
             losses.append(list(client.last_losses))
             if amp:
                 assert client.scaler.get_scale() == 65536.0 and int(client.scaler._tracker.item()) == 4
                 # last_losses holds the UNscaled loss like the reference's logging
-    assert np.allclose(losses[0], losses[1], rtol=0, atol=2e-3), (losses[0], losses[1])
-    assert np.allclose(losses[0][:2], losses[1][:2], atol=1e-5)
+    assert np.allclose(losses[0], losses[1], rtol=0, atol=2e-3 if amp_dtype == "bf16" else 6e-3), (losses[0], losses[1])
+    assert abs(losses[0][0] - losses[1][0]) < 1e-6                       # the forward pass does not see the scale
+    if amp_dtype == "bf16":
+        assert np.allclose(losses[0][:2], losses[1][:2], atol=1e-5)
     assert np.allclose(losses[1], losses[2], atol=5e-3)
     # ---- skipped step
     from fedicra_amd.optim import FusedAdamW
-    net = _mk(UNet, 1, 2, dtype="bf16").train()
+    net = _mk(UNet, 1, 2, dtype=amp_dtype).train()
     opt = FusedAdamW(net, lr=0.01, base_lr=0.01, max_iterations=100)
     sc = GradScaler(init_scale=1024.0, growth_interval=2)
     b = batches[0]
@@ -517,6 +525,43 @@ def test_amp_gradscaler_matches_reference_state_machine():
     one_step(False)                                       # two clean steps = growth_interval -> scale doubles
     assert int(opt.steps[0].item()) == 3 and sc.get_scale() == 1024.0
     assert not torch.equal(net.flat_params, before[0])
+
+
+def test_fp16_autocast_overflow_drives_the_scaler():
+    """fp16 for real: a loss scale far too large pushes the scaled gradients out of fp16's range; the kernels then store
+    inf, the unscale pass finds it, the step is skipped and the scale halved -- until the gradients fit and training
+    proceeds (torch.cuda.amp's dynamic loss scaling; with bf16 storage the same run never skips)."""
+    from fedicra_amd import ops
+    from fedicra_amd.amp import GradScaler
+    from fedicra_amd.networks.unet import UNet
+    from fedicra_amd.optim import FusedAdamW
+    from helpers import loader
+    b = loader(1, 4, 64, cid=0)[0]
+    x, y = b["image"].unsqueeze(1).to(DEV), b["label"].to(DEV)
+    outcome = {}
+    for dtype in ("fp16", "bf16"):
+        ops.manual_seed(2)
+        net = _mk(UNet, 1, 2, dtype=dtype).train()
+        opt = FusedAdamW(net, lr=0.01, base_lr=0.01, max_iterations=100)
+        sc = GradScaler(init_scale=2.0 ** 30, growth_interval=1000)
+        first, steps, loss = net.flat_params.clone(), [], None
+        for it in range(24):
+            ops.begin_iteration(x.device)
+            opt.zero_grad()
+            loss = ops.ce_loss(net(x)[0].permute(0, 2, 3, 1), y, 2)
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+            steps.append(int(opt.steps[0].item()))
+        outcome[dtype] = (sc.get_scale(), steps, float(loss.detach()), not torch.equal(first, net.flat_params))
+    scale, steps, loss, moved = outcome["fp16"]
+    assert steps[0] == 0, "the first fp16 steps must be skipped at a 2^30 loss scale"
+    skipped = 24 - steps[-1]
+    assert 2 <= skipped <= 20 and scale == 2.0 ** 30 / 2 ** skipped, (scale, steps)
+    assert steps[-1] > 0 and moved and np.isfinite(loss)
+    assert all(b_ - a_ in (0, 1) for a_, b_ in zip(steps, steps[1:])) and steps[-1] - steps[-4] == 3, steps   # settled
+    scale_b, steps_b, loss_b, moved_b = outcome["bf16"]
+    assert steps_b[-1] == 24 and scale_b == 2.0 ** 30 and moved_b and np.isfinite(loss_b)
 
 
 def test_single_site_trainer_sgd_matches_torch_loop():
