@@ -134,13 +134,15 @@ def roofline_pass(client, a, dtype_name):
             "kernel_time_breakdown_ms_per_iter": {k: round(v / 3.0, 4) for k, v in sorted(breakdown.items())}}
     # HBM traffic cannot be counted from inside the process: it comes from the last committed rocprofv3 PMC run of this
     # same workload (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied -- see the json's header)
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_traffic.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    pmc_path = found[-1] if found else ""                    # the newest committed PMC measurement (tools/pmc_round.sh)
     if dtype_name == "bf16" and a.size == 256 and a.batch == 12 and os.path.exists(pmc_path):
         try:
             fam_pmc = json.load(open(pmc_path))["families"].get(fname)
             if fam_pmc:
                 roof["traffic"] = fam_pmc["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)"
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, bytes per launch)" % os.path.basename(pmc_path)
         except (OSError, ValueError, KeyError):
             pass
     if os.environ.get("FEDICRA_BENCH_VERBOSE"):
