@@ -106,7 +106,11 @@ def init_process_group_from_env(backend: Optional[str] = None):
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"     # 'nccl' IS RCCL on ROCm
-    if backend == "nccl":
+    # test hooks: several ranks on ONE GPU (a 1-GPU box cannot host two RCCL ranks) exchange through gloo instead
+    backend = os.environ.get("FEDICRA_DIST_BACKEND", backend)
+    if "FEDICRA_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["FEDICRA_FORCE_DEVICE"])
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
