@@ -279,3 +279,94 @@ def test_bench_multi_rank_path_on_one_gpu_via_gloo():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["config"]["clients"] == 4 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 20 * 12 * 4 / (d["ms_per_step"] * 20 / 1e3)) < 0.01 * d["value"]
     assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
+
+
+def test_mini_federation_dice_against_the_cpu_oracle():
+    """BASELINE metric (3), end to end: 2 FedAvg clients x 3 rounds x 8 local iterations (fresh AdamW per round, poly LR,
+    weighted aggregation with n_k = #batches, global state loaded into both clients), then `evaluate` -- the HIP path in
+    fp32 against the CPU oracle driven through the same rounds with the same dropout masks.  Round 1 is held to fp32
+    parity; after 48 AdamW steps the reference's own round-off sensitivity (DESIGN.md "parity bar") bounds what two
+    correct implementations can share, so the final Dice is compared at 0.03 and printed."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel, aggregate_device, evaluate
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet, set_compute_dtype
+    from fedicra_amd.synth import phantom_batch
+    from oracle import fed_ref
+    from oracle.losses_ref import eval_case
+    from oracle.unet_ref import RefUNet, seeded_state
+    K, rounds, iters, n_k = 2, 3, 8, [3, 2]
+    data = []
+    for cid in range(K):
+        bs = []
+        for i in range(n_k[cid]):
+            img, weak, _ = phantom_batch(4, 64, 1, 2, cid=cid, index=i, labeled_frac=0.3)
+            bs.append({"image": torch.from_numpy(img), "label": torch.from_numpy(weak)})
+        data.append(bs)
+    vimg, _, vmask = phantom_batch(8, 64, 1, 2, cid=7, dense=True)
+    val = [{"image": torch.from_numpy(vimg[i:i + 1]), "label": torch.from_numpy(vmask[i:i + 1])} for i in range(8)]
+
+    # ---- CPU oracle
+    refs = [RefUNet(1, 2) for _ in range(K)]
+    for r in refs:
+        seeded_state(r, 2022)
+    states = [fed_ref.TrainState(0.01) for _ in range(K)]
+    ref_losses = []
+    for rnd in range(rounds):
+        res = []
+        for cid in range(K):
+            torch.manual_seed(100 * rnd + cid)
+            _, met = fed_ref.local_train(refs[cid], states[cid], data[cid], iters=iters, num_classes=2, base_lr=0.01,
+                                         max_iterations=200)
+            res.append((fed_ref.get_weights(refs[cid]), n_k[cid]))
+            ref_losses.append(float(met["loss"][-1]) if hasattr(met["loss"], "__len__") else float(met["loss"]))
+        glob = fed_ref.fedavg_aggregate(res)
+        for r in refs:
+            fed_ref.set_weights_plain(r, glob)
+    refs[0].eval()
+    ref_dice = 0.0
+    with torch.no_grad():
+        for b in val:
+            pred = refs[0](b["image"].unsqueeze(1))[0].argmax(1)[0].numpy()
+            ref_dice += eval_case(pred, b["label"][0].numpy(), 2)[0]
+    ref_dice /= len(val)
+
+    # ---- HIP path
+    clients = []
+    for cid in range(K):
+        args = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=cid, min_num_clients=K, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=iters, rep_iters=3, alpha=0.5,
+                                  snapshot_path=None, use_graph=False)
+        net = UNet(1, 2)
+        seeded_state(net, 2022)
+        net = net.cuda()
+        set_compute_dtype(net, "fp32")
+        clients.append(MyClient(args, MyModel(args, net, data[cid], data[cid]), data[cid], data[cid]))
+    ops.set_dropout_mask_provider(lambda shape, p: torch.empty(shape).bernoulli_(1 - p))
+    hip_losses = []
+    try:
+        for rnd in range(rounds):
+            res = []
+            for cid in range(K):
+                torch.manual_seed(100 * rnd + cid)
+                last, _ = clients[cid]._train({"iter_global": rnd, "iters": iters, "eval_iters": 99, "batch_size": 4,
+                                               "stage": "fit"})
+                hip_losses.append(last)
+                res.append((clients[cid].model.get_device_weights(), n_k[cid]))
+            glob = aggregate_device(res)
+            for c in clients:
+                c.model.set_weights(glob, {"iter_global": rnd})
+    finally:
+        ops.set_dropout_mask_provider(None)
+    met = evaluate(clients[0].args, clients[0].model.model, val)
+    assert torch.equal(clients[0]._net().flat_state, clients[1]._net().flat_state)      # both hold the global state
+    for a, b in zip(fed_ref.get_weights(refs[0]), clients[0].model.get_weights(None)):
+        assert a.shape == b.shape and a.dtype == b.dtype
+    nbt = int(clients[0]._net().flat_counters[0])
+    assert nbt == int(refs[0].state_dict()["encoder.in_conv.conv_conv.1.num_batches_tracked"]), nbt
+    print(f"mini federation: val_mean_dice HIP {met['val_mean_dice']:.4f} vs CPU oracle {ref_dice:.4f}; last losses per "
+          f"(round, client) HIP {np.round(hip_losses, 4).tolist()} oracle {np.round(ref_losses, 4).tolist()}")
+    assert abs(hip_losses[0] - ref_losses[0]) < 5e-3 and abs(hip_losses[1] - ref_losses[1]) < 5e-3       # round 1
+    assert ref_dice > 0.3, "the phantom task should be learnable in 24 steps per client"
+    assert abs(met["val_mean_dice"] - ref_dice) < 0.03
