@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float*
 //     first node is needed and committed to the ring when the pass reaches it, so neither the load latency nor the
 //     dependent gather hop is ever on the chain.  A level wider than a chunk takes the direct path (global loads).
 #define TREE_CAP 4096
-#define TREE_RT 256      // threads of a recursion workgroup
+#define TREE_RT 256      // threads of a recursion workgroup (one wavefront without any barrier was measured: 26.9 vs
+                         // 19.3 ms for the 4-tree loss -- the chunk loader and the wide levels serialise)
 #define TREE_CH 512      // nodes per streamed chunk
 #define TREE_RING (2 * TREE_CH)
 
@@ -417,9 +418,16 @@ __global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float*
 __device__ __forceinline__ void level_barrier(bool through_global) {
   if (through_global) {
     __syncthreads();
-  } else {
+  } else if (TREE_RT > 64) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    asm volatile("" ::: "memory");           // single wave: the DS queue is in order; only the compiler must not reorder
   }
+}
+
+// fallback paths re-read what an earlier level stored to global memory: device-scope load, never a stale L1 line
+__device__ __forceinline__ float ld_coherent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int NW>
@@ -472,7 +480,7 @@ struct NodeRing {
 __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const int* __restrict__ sidx, const int* __restrict__ schild,
                                                                const int* __restrict__ levels, int C, int V,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, int cap, int chl) {
   __shared__ float lvl[2][TREE_CAP];           // a node's CONTRIBUTION to its parent: value * own edge weight
   __shared__ uint32_t ringmem[6][TREE_RING];   // children (4), x[sorted_index[i]], w[i]
   const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
@@ -502,8 +510,8 @@ __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __re
     if (l >= 2) lo_ahead = lv[l - 1];
     const float* below = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
-    const bool cached = chi - clo <= TREE_CAP;
-    const bool streamed = hi - lo <= TREE_CH;
+    const bool cached = chi - clo <= cap;
+    const bool streamed = hi - lo <= chl;
     if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
     if (streamed && cached) {
       // fast path: LDS in, LDS out (+ a fire-and-forget store).  Kept free of any global LOAD so that no s_waitcnt
@@ -529,19 +537,19 @@ __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __re
         float s = xb ? xb[si[i]] : 1.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (cc[q] > 0) s = __fadd_rn(s, cached ? below[cc[q] - clo] : __fmul_rn(ob[cc[q]], wb[cc[q]]));
+          if (cc[q] > 0) s = __fadd_rn(s, cached ? below[cc[q] - clo] : __fmul_rn(ld_coherent(ob + cc[q]), wb[cc[q]]));
         ob[i] = s;
-        if (i - lo < TREE_CAP) mine[i - lo] = __fmul_rn(s, wb[i]);
+        if (i - lo < cap) mine[i - lo] = __fmul_rn(s, wb[i]);
       }
     }
-    level_barrier(hi - lo > TREE_CAP);
+    level_barrier(hi - lo > cap);
   }
 }
 
 __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __restrict__ xs, const float* __restrict__ w,
                                                                  const int* __restrict__ sidx, const int* __restrict__ spar,
                                                                  const int* __restrict__ levels, int C, int V,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, int cap, int chl) {
   __shared__ float lvl[2][TREE_CAP];
   __shared__ uint32_t ringmem[4][TREE_RING];   // parent position, vertex, x_sorted[i], w[i]
   const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
@@ -571,8 +579,8 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
     if (l + 2 < L) hi_ahead = lv[4 + l];
     const float* above = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
-    const bool cached = lo - plo <= TREE_CAP;
-    const bool streamed = hi - lo <= TREE_CH;
+    const bool cached = lo - plo <= cap;
+    const bool streamed = hi - lo <= chl;
     if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
     if (streamed && cached) {
       for (int i = lo + tid; i < hi; i += TREE_RT) {
@@ -587,13 +595,13 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
       for (int i = lo + tid; i < hi; i += TREE_RT) {
         const int p = sp[i];
         const float xi = xb[i], wi = i == 0 ? 0.f : wb[i];
-        const float pv = l == 0 ? 0.f : (cached ? above[p - plo] : ob[si[p]]);
+        const float pv = l == 0 ? 0.f : (cached ? above[p - plo] : ld_coherent(ob + si[p]));
         const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
         ob[si[i]] = v;
-        if (i - lo < TREE_CAP) mine[i - lo] = v;
+        if (i - lo < cap) mine[i - lo] = v;
       }
     }
-    level_barrier(hi - lo > TREE_CAP);
+    level_barrier(hi - lo > cap);
   }
 }
 
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
                                                                 const float* __restrict__ out_data,
                                                                 const float* __restrict__ w, const int* __restrict__ sidx,
                                                                 const int* __restrict__ spar, const int* __restrict__ levels,
-                                                                int Cd, int Cg, int V, float* __restrict__ grad) {
+                                                                int Cd, int Cg, int V, float* __restrict__ grad, int cap, int chl) {
   __shared__ float lvl[2][TREE_CAP];
   __shared__ uint32_t ringmem[5][TREE_RING];   // parent position, w[i], in_grad[i], in_data[i], out_data[sorted_index[parent]]
   const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
@@ -641,8 +649,8 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
     if (l + 2 < L) hi_ahead = lv[4 + l];
     const float* above = lvl[(l + 1) & 1];
     float* mine = lvl[l & 1];
-    const bool cached = lo - plo <= TREE_CAP;
-    const bool streamed = hi - lo <= TREE_CH;
+    const bool cached = lo - plo <= cap;
+    const bool streamed = hi - lo <= chl;
     if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
     if (streamed && cached) {
       for (int i = lo + tid; i < hi; i += TREE_RT) {
@@ -669,19 +677,30 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
         } else {
           const int p = sp[i];
           const float wi = wb[i], ig = igb[i], id = idb[i], od = odb[si[p]];
-          const float gp = cached ? above[p - plo] : igb[p];
+          const float gp = cached ? above[p - plo] : ld_coherent(igb + p);
           gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
           G = ig * (1.0f - wi * wi) + gp * wi;
           igb[i] = G;
         }
-        if (i - lo < TREE_CAP) mine[i - lo] = G;
+        if (i - lo < cap) mine[i - lo] = G;
       }
     }
-    level_barrier(hi - lo > TREE_CAP);
+    level_barrier(hi - lo > cap);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// test hooks: shrink the LDS level cache / the streamed chunk so that small images exercise the global-memory paths
+static inline int tree_cap() {
+  const char* v = getenv("FI_TREE_CAP");
+  const int n = v ? atoi(v) : TREE_CAP;
+  return n < 1 ? 1 : (n > TREE_CAP ? TREE_CAP : n);
+}
+static inline int tree_chunk() {
+  const char* v = getenv("FI_TREE_CHUNK");
+  const int n = v ? atoi(v) : TREE_CH;
+  return n < 1 ? 1 : (n > TREE_CH ? TREE_CH : n);
+}
 static inline int tree_grid(long work) {
   long b = (work + 255) / 256;
   if (b > 4096) b = 4096;
@@ -762,7 +781,7 @@ extern "C" int fi_tree_aggr_up(const float* x, const float* w, const int* sorted
   if (!w || !sorted_index || !sorted_child || !levels || !out) return FI_ERR_NULL;
   if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
   hipLaunchKernelGGL(tree_aggr_up_kernel, dim3(B, C), dim3(TREE_RT), 0, (hipStream_t)stream, x, w, sorted_index, sorted_child,
-                     levels, C, V, out);
+                     levels, C, V, out, tree_cap(), tree_chunk());
   FI_CHECK_LAUNCH();
   return 0;
 }
@@ -771,7 +790,7 @@ extern "C" int fi_tree_prop_down(const float* x_sorted, const float* w, const in
   if (!x_sorted || !w || !sorted_index || !sorted_parent || !levels || !out) return FI_ERR_NULL;
   if (B < 1 || C < 1 || V < 1) return FI_ERR_SHAPE;
   hipLaunchKernelGGL(tree_prop_down_kernel, dim3(B, C), dim3(TREE_RT), 0, (hipStream_t)stream, x_sorted, w, sorted_index,
-                     sorted_parent, levels, C, V, out);
+                     sorted_parent, levels, C, V, out, tree_cap(), tree_chunk());
   FI_CHECK_LAUNCH();
   return 0;
 }
@@ -782,7 +801,7 @@ extern "C" int fi_tree_grad_rec(const float* in_data, float* in_grad, const floa
   if (B < 1 || Cd < 1 || Cg < 1 || V < 1) return FI_ERR_SHAPE;
   if (Cd != Cg && Cd != 1) return FI_ERR_UNSUPPORTED;     // in_grad is propagated in place: one workgroup per gradient channel
   hipLaunchKernelGGL(tree_grad_rec_kernel, dim3(B, Cd > Cg ? Cd : Cg), dim3(TREE_RT), 0, (hipStream_t)stream, in_data, in_grad,
-                     out_data, w, sorted_index, sorted_parent, levels, Cd, Cg, V, grad);
+                     out_data, w, sorted_index, sorted_parent, levels, Cd, Cg, V, grad, tree_cap(), tree_chunk());
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -103,8 +103,16 @@ def test_tree_mst_is_the_references_tree(case):
             assert lv[0] == len(rl) - 1 and list(lv[1:2 + lv[0]]) == rl
 
 
+@pytest.mark.parametrize("limits", [None, ("8", "512"), ("4096", "16"), ("4", "8")])
 @pytest.mark.parametrize("low_tree", [True, False])
-def test_tree_filter_forward_backward_against_oracle(low_tree):
+def test_tree_filter_forward_backward_against_oracle(low_tree, limits, monkeypatch):
+    if limits is not None:       # shrink the LDS level cache / the streamed chunk: the global-memory fallbacks of the recursions
+        monkeypatch.setenv("FI_TREE_CAP", limits[0])
+        monkeypatch.setenv("FI_TREE_CHUNK", limits[1])
+    _tree_filter_case(low_tree)
+
+
+def _tree_filter_case(low_tree):
     """TreeFilter2D output, d/d feature and (high-level tree) d/d embedding vs the CPU restatement of refine.cu."""
     from fedicra_amd.utils.tree_filter import MinimumSpanningTree, TreeFilter2D
     from oracle import tree_ref as T
