@@ -237,3 +237,40 @@ def test_ours_procedure_first_iteration_against_oracle_and_graph_replay():
         losses.append(list(c2.last_losses))
     assert all(np.isfinite(losses[0])) and np.allclose(losses[0][:2], losses[1][:2], atol=2e-5), (losses[0], losses[1])
     assert np.allclose(losses[0], losses[1], atol=5e-3)
+
+
+def test_readme_training_configuration_runs_captured_and_eager():
+    """The reference README's command (`--procedure ..._Ours --model unet_lc_multihead --strategy FedICRA --alpha 1
+    --rep_iters 3`): pCE + multi-scale tree energy + 0.1 gated CRF + LC loss (no-grad forwards with the other clients'
+    embeddings), head-only then body-only freeze phases -- one captured hipGraph per phase equals eager launches."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours import MyClient
+    from fedicra_amd.networks import net_factory
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from helpers import loader
+    K, cid = 3, 1
+    batches = loader(2, 4, 64, cid=cid, device=DEV)
+    finals, losses = [], []
+    for use_graph in (False, True):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc_multihead", cid=cid, min_num_clients=K,
+                                  num_classes=2, img_class="faz", base_lr=0.01, max_iterations=30000, iters=6, rep_iters=3,
+                                  alpha=1.0, snapshot_path=None, use_graph=use_graph, tree_loss_weight=0.1)
+        torch.manual_seed(2022)
+        ops.manual_seed(4)
+        net = net_factory(args, net_type="unet_lc_multihead", in_chns=1, class_num=2).cuda()
+        set_compute_dtype(net, "fp32")
+        head0 = net.decoder.out_conv.weight.detach().clone()
+        enc0 = net.encoder.in_conv.conv_conv[0].weight.detach().clone()
+        c = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+        c._train({"iter_global": 60, "iters": 6, "eval_iters": 99, "batch_size": 4, "stage": "fit"})
+        c._train({"iter_global": 61, "iters": 6, "eval_iters": 99, "batch_size": 4, "stage": "fit"})
+        assert not torch.equal(head0, net.decoder.out_conv.weight) and not torch.equal(enc0, net.encoder.in_conv.conv_conv[0].weight)
+        finals.append(net.flat_state.clone())
+        losses.append(list(c.last_losses))
+        if use_graph:
+            assert set(c._steps) == {"head", "body"} and all(r.graph is not None for r in c._steps.values())
+    assert np.isfinite(losses[0]).all() and np.isfinite(losses[1]).all()
+    assert np.allclose(losses[0][:2], losses[1][:2], atol=5e-5), (losses[0], losses[1])
+    assert np.allclose(losses[0], losses[1], atol=2e-2), (losses[0], losses[1])
