@@ -214,17 +214,18 @@ def _esz(t):
 
 
 # ------------------------------------------------------------------ thin wrappers
-def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False, y_f32=False, tag="conv_fwd"):
-    """x*: [N,H,W,C] dense NHWC; w: packed [Cout][k*k][Cin] (any shape, dense) in x0.dtype."""
+def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False, y_f32=False, tag="conv_fwd", cout=None):
+    """x*: [N,H,W,C] dense NHWC; w: packed [Cout][k*k][Cin] (any shape, dense) in x0.dtype.  y0 = None with `cout` and
+    `stats` given: statistics-only launch (nothing stored)."""
     _dev(x0)
     N, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
-    co0 = y0.shape[3]
+    co0 = int(cout) if y0 is None else y0.shape[3]
     co1 = 0 if y1 is None else y1.shape[3]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, co0, co1, int(acc0), int(acc1), int(y_f32))
     cin, cout, px = c0 + c1, co0 + co1, N * H * W
     with _timed(tag, (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
-                px * cin * _esz(x0) + px * cout * _esz(y0) + cin * cout * ksize * ksize * _esz(x0)):
+                px * cin * _esz(x0) + (0 if y0 is None else px * cout * _esz(y0)) + cin * cout * ksize * ksize * _esz(x0)):
         _chk(lib().fi_conv2d_fwd(C.byref(d), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y0), ptr(y1), ptr(stats),
                                  stream()), "fi_conv2d_fwd")
 

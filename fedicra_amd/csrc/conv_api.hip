@@ -56,7 +56,8 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
 
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
-  if (!d || !x0 || !w || !y0) return FI_ERR_NULL;
+  if (!d || !x0 || !w) return FI_ERR_NULL;
+  if (!y0 && (!stats || y1)) return FI_ERR_NULL;          // y0 == NULL: statistics-only launch (nothing is stored)
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1 || d->co1 < 0) return FI_ERR_SHAPE;

@@ -365,21 +365,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           const size_t o = pixo * cdst + cofs;
           if (!PLAIN && a.y_f32) {
             float4* yp = reinterpret_cast<float4*>(reinterpret_cast<float*>(ybase) + o);
-            if (accum) {
+            if (accum && ybase) {
               const float4 old = *yp;
               v[0] += old.x;
               v[1] += old.y;
               v[2] += old.z;
               v[3] += old.w;
             }
-            *yp = make_float4(v[0], v[1], v[2], v[3]);
+            if (ybase) *yp = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             union {
               T e[4];
               typename std::conditional<sizeof(T) == 2, uint2, float4>::type q;
             } u;
             T* yp = reinterpret_cast<T*>(ybase) + o;
-            if (!PLAIN && accum) {
+            if (!PLAIN && accum && ybase) {
               u.q = *reinterpret_cast<decltype(u.q)*>(yp);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += to_f32(u.e[r]);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
               u.e[r] = from_f32<T>(v[r]);
               v[r] = to_f32(u.e[r]);
             }
-            *reinterpret_cast<decltype(u.q)*>(yp) = u.q;
+            if (ybase) *reinterpret_cast<decltype(u.q)*>(yp) = u.q;     // NULL destination: statistics-only launch
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -409,13 +409,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
               const int ac = sec ? a.acc1 : a.acc0;
               if (a.y_f32) {
                 float* yp = reinterpret_cast<float*>(yb) + o;
-                if (ac) vv += *yp;
-                *yp = vv;
+                if (ac && yb) vv += *yp;
+                if (yb) *yp = vv;
               } else {
                 T* yp = reinterpret_cast<T*>(yb) + o;
-                if (ac) vv += to_f32(*yp);
+                if (ac && yb) vv += to_f32(*yp);
                 const T q = from_f32<T>(vv);
-                *yp = q;
+                if (yb) *yp = q;
                 vv = to_f32(q);
               }
               ssum[f][r] += vv;

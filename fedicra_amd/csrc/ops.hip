@@ -57,6 +57,14 @@ static inline int grid_for(long work_items, int per_block) {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalize
 // ------------------------------------------------------------------------------------------------
+// running <- (1 - momentum) * running + momentum * batch, products rounded separately: the stand-alone finalize and the
+// fused finalize+apply kernel must move the running statistics identically (ops.conv_bn_stats_only relies on it)
+__device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int c, float momentum, float mu, float unb) {
+  const float keep = 1.f - momentum;
+  rmean[c] = __fadd_rn(__fmul_rn(keep, rmean[c]), __fmul_rn(momentum, mu));
+  rvar[c] = __fadd_rn(__fmul_rn(keep, rvar[c]), __fmul_rn(momentum, unb));
+}
+
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
                                    float* rmean, float* rvar, int64_t* nbt, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean, float* invstd, int C) {
@@ -76,8 +84,7 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
     mu = (float)m;
     istd = (float)(1.0 / sqrt(var + (double)eps));
     const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    bn_running_update(rmean, rvar, c, momentum, mu, (float)unb);
   } else {
     mu = rmean[c];
     istd = 1.0f / sqrtf(rvar[c] + eps);
@@ -1111,8 +1118,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
       coef[2 * C + c] = mu;
       coef[3 * C + c] = istd;
       if (training) {
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        bn_running_update(rmean, rvar, c, momentum, mu, (float)unb);
         if (c == 0 && nbt) nbt[0] += 1;
       }
     }

@@ -162,9 +162,11 @@ class MyModel(nn.Module):
         self.fedaa_weights = None
         self.ala_epoch_losses: List[float] = []
 
-    def forward(self, x, emb_idx=None):
+    def forward(self, x, emb_idx=None, heatmap_only=False):
         if emb_idx is None:
             return self.model(x)
+        if heatmap_only:                                  # LC models only (networks/unet._UNetLCBase.forward)
+            return self.model(x, emb_idx, heatmap_only=True)
         return self.model(x, emb_idx)
 
     # -- weights I/O ----------------------------------------------------------------------------

@@ -112,7 +112,7 @@ class MyClient(BaseClient):
                 if other_client == args.cid:
                     continue
                 with torch.no_grad():
-                    _heatmaps = self.model(x, other_client)[6]
+                    _heatmaps = self.model(x, other_client, heatmap_only=True)[6]   # nothing else of it is read
                 acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], _heatmaps[-1].detach())
             loss_lc = -acc / (args.min_num_clients - 1)
             loss = torch.add(loss, loss_lc, alpha=args.alpha)

@@ -249,7 +249,10 @@ def _dsn_head(cin, n_class):
                          nn.Dropout2d(0.10), nn.Conv2d(512, n_class, kernel_size=1, stride=1, padding=0, bias=False))
 
 
-def _run_head(seq, x):
+def _run_head(seq, x, probe=False):
+    if probe:                       # output unused: only the BatchNorm statistics of the head move (see _UNetLCBase.forward)
+        ops.conv_bn_stats_only(x, None, seq[0], seq[1], seq[3].p, "chan")
+        return None
     z = ops.conv_bn_act(x, None, seq[0], seq[1], 0.0, seq[3].p, "chan")      # ReLU = slope 0; Dropout2d
     return ops.conv2d(z, None, seq[4], y_f32=True)
 
@@ -268,16 +271,17 @@ class _DecoderBase(_FiModule):
         self.up4 = UpBlock(c[1], c[0], c[0], dropout_p=0.0)
         self.out_conv = nn.Conv2d(c[0], self.n_class, kernel_size=3, padding=1)
 
-    def _trunk(self, f):
+    def _trunk(self, f, probe=False):
         x_1 = self.up1._run(f[4], f[3])
         x_2 = self.up2._run(x_1, f[2])
         x_3 = self.up3._run(x_2, f[1])
         x_4 = self.up4._run(x_3, f[0])
-        output = ops.conv2d(x_4, None, self.out_conv, y_f32=True)    # logits always fp32
+        # probe: out_conv has no state, its unused logits are simply not computed
+        output = None if probe else ops.conv2d(x_4, None, self.out_conv, y_f32=True)    # logits always fp32
         return [output, x_1, x_2, x_3, x_4]
 
-    def _run(self, f):
-        return self._trunk(f)
+    def _run(self, f, probe=False):
+        return self._trunk(f, probe)
 
     def forward(self, feature):
         return tuple(self._out(t) for t in self._run([self._in(t) for t in feature]))
@@ -294,9 +298,9 @@ class Decoder_Head(_DecoderBase):
         super().__init__(params)
         self.dsn_head = _dsn_head(self.ft_chns[2], self.n_class)
 
-    def _run(self, f):
-        o = self._trunk(f)
-        return o + [_run_head(self.dsn_head, o[2])]
+    def _run(self, f, probe=False):
+        o = self._trunk(f, probe)
+        return o + [_run_head(self.dsn_head, o[2], probe)]
 
 
 class Decoder_MultiHead(_DecoderBase):
@@ -308,9 +312,10 @@ class Decoder_MultiHead(_DecoderBase):
         self.dsn_head2 = _dsn_head(self.ft_chns[1], self.n_class)
         self.dsn_head3 = _dsn_head(self.ft_chns[0], self.n_class)
 
-    def _run(self, f):
-        o = self._trunk(f)
-        return o + [_run_head(self.dsn_head1, o[2]), _run_head(self.dsn_head2, o[3]), _run_head(self.dsn_head3, o[4])]
+    def _run(self, f, probe=False):
+        o = self._trunk(f, probe)
+        return o + [_run_head(self.dsn_head1, o[2], probe), _run_head(self.dsn_head2, o[3], probe),
+                    _run_head(self.dsn_head3, o[4], probe)]
 
 
 def _params(in_chns, class_num, **extra):
@@ -362,13 +367,20 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         self.decoder = self._decoder_cls(params)
         self._fi_finish_init()
 
-    def forward(self, x, emb_idx=None):
+    def forward(self, x, emb_idx=None, heatmap_only=False):
+        """``heatmap_only`` (train mode, no autograd): the caller reads nothing but the heat-map ``[6]`` -- the LC loss's
+        forwards with the other clients' embeddings (flower_pCE_2D.py:128-139).  Every state change of the full forward
+        still happens (all BatchNorm running statistics and counters, decoder and heads included), but tensors nobody
+        reads are not produced: the heads run their convolution for its statistics only and store nothing (the full-
+        resolution head alone writes, normalises and reduces an 805 MB tensor at 12x256^2), and the logits convolution,
+        which has no state, is skipped.  The skipped entries of the returned list are None."""
         self._fi_refresh_packs(self.compute_dtype())     # all conv operands in one launch, only if weights changed
+        probe = bool(heatmap_only) and self.training and not torch.is_grad_enabled()
         f, h = self.encoder._run(self._in(x), emb_idx)
-        o = self.decoder._run(f)
+        o = self.decoder._run(f, probe)
         hm = [None if t is None else self._out(t) for t in h]
-        return [self._out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + \
-               [self._out(t) for t in o[5:]]
+        out = lambda t: None if t is None else self._out(t)
+        return [out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + [out(t) for t in o[5:]]
 
 
 class UNet_LC(_UNetLCBase):

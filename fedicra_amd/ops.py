@@ -548,6 +548,29 @@ def conv2d(x0, x1, mod, y_f32=False):
     return _Conv.apply(x0, x1, mod.weight, mod.bias, mod, y_f32)
 
 
+def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
+    """The side effects of a train-mode ``BN(conv(x))`` whose OUTPUT nobody reads (no-grad forwards of FedICRA's LC loss
+    through the auxiliary heads, flower_pCE_2D.py:128-139): the convolution runs with its statistics epilogue but stores
+    nothing, and the finalize kernel moves running_mean / running_var / num_batches_tracked exactly as the fused
+    forward would.  Only meaningful without autograd."""
+    assert bn.training and not torch.is_grad_enabled()
+    if _mask_provider is not None and drop_p > 0.0:
+        # parity mode draws masks from the host generator in forward order: the skipped dropout still takes its draw,
+        # or every later mask of the run would shift against the reference's sequence
+        N_, H_, W_, _ = x0.shape
+        _mask_provider((N_, conv.weight.shape[0], H_, W_) if drop_kind == "elem" else (N_, conv.weight.shape[0], 1, 1), drop_p)
+    wk = _krsc(conv.weight)
+    cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+    N, H, W, _ = x0.shape
+    dev = x0.device
+    wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=conv.weight)
+    stats = _ctx.arena.take(L.STATS_SLOTS * cout * 2, dev)
+    L.conv2d_fwd(x0, x1, wp, conv.bias, None, None, stats, ksize=ksize, cout=cout)
+    coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
+    L.bn_finalize(stats, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                  bn.momentum, bn.eps, True, coef[0], coef[1], coef[2], coef[3])
+
+
 def conv_bn_act(x0, x1, conv, bn, slope, drop_p=0.0, drop_kind="elem"):
     return _ConvBNAct.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, conv, bn, float(slope),
                             float(drop_p), drop_kind)

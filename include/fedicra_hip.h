@@ -68,7 +68,10 @@ typedef struct FiConv {
  * bias: fp32 [co0+co1] or NULL.  stats: fp64 [FI_STATS_SLOTS][co0+co1][2], or NULL; when given,
  * per-channel (sum, sum of squares) of the stored output are ATOMICALLY ADDED to one of the slots
  * (caller zeroes the whole buffer; fi_bn_finalize sums the slots) -- the batch statistics
- * BatchNorm2d (unet.py:21) needs, produced in the conv epilogue. */
+ * BatchNorm2d (unet.py:21) needs, produced in the conv epilogue.  y0 == NULL (with stats given, co1 == 0) is a
+ * statistics-only launch: nothing is stored -- a train-mode forward whose output nobody reads still has to move the
+ * BatchNorm running statistics (the no-grad forwards of FedICRA's LC loss through the auxiliary heads,
+ * flower_pCE_2D.py:128-139). */
 #define FI_STATS_SLOTS 8
 int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                   void* y0, void* y1, double* stats, void* stream);

@@ -274,3 +274,45 @@ def test_readme_training_configuration_runs_captured_and_eager():
     assert np.isfinite(losses[0]).all() and np.isfinite(losses[1]).all()
     assert np.allclose(losses[0][:2], losses[1][:2], atol=5e-5), (losses[0], losses[1])
     assert np.allclose(losses[0], losses[1], atol=2e-2), (losses[0], losses[1])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lc_probe_forward_has_the_side_effects_of_the_full_forward(dtype):
+    """`model(x, j, heatmap_only=True)` (the LC loss's no-grad forwards) against the full forward from the same state and
+    dropout seeds: identical heat-map and trunk outputs, the same model state afterwards (to one ulp) -- every BatchNorm
+    running statistic and counter, the heads' included -- while the heads' tensors and the logits are not produced."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.networks import net_factory
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from helpers import loader
+    x = loader(1, 4, 64, cid=1, device=DEV)[0]["image"].unsqueeze(1)
+    args = argparse.Namespace(min_num_clients=4, cid=1)
+    outs, states = [], []
+    for probe in (False, True):
+        torch.manual_seed(2022)
+        ops.manual_seed(3)
+        net = net_factory(args, net_type="unet_lc_multihead", in_chns=1, class_num=2).cuda().train()
+        set_compute_dtype(net, dtype)
+        off = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.set_dropout_seed_offset(off)
+        try:
+            with torch.no_grad():
+                ops.begin_iteration(x.device)
+                o = net(x, 2, heatmap_only=probe)
+        finally:
+            ops.set_dropout_seed_offset(None)
+        outs.append(o)
+        states.append((net.flat_state.clone(), net.flat_counters.clone()))
+    full, probe = outs
+    assert probe[0] is None and probe[7] is None and probe[8] is None and probe[9] is None and full[9] is not None
+    assert torch.equal(full[6][-1], probe[6][-1])
+    for i in range(2, 6):
+        assert torch.equal(full[i], probe[i])
+    assert torch.equal(states[0][1], states[1][1]) and int(states[1][1].min()) == 1
+    # the statistics are fp64 atomic sums: their order differs between a storing and a non-storing launch, which can move
+    # a running statistic by one fp32 ulp
+    assert torch.allclose(states[0][0], states[1][0], rtol=2.5e-7, atol=1e-9), float((states[0][0] - states[1][0]).abs().max())
+    with torch.no_grad():                                # eval mode / autograd on: the flag is ignored
+        net.eval()
+        assert net(x, 2, heatmap_only=True)[0] is not None

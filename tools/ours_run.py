@@ -14,6 +14,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--clients", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--profile", action="store_true")
 a = ap.parse_args()
 from fedicra_amd.flower_common import MyModel
 from fedicra_amd.flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours import MyClient
@@ -42,3 +43,25 @@ for r in range(4):
     print(f"round {r}: loss {loss:.4f}  {dt * 1e3 / a.iters:.2f} ms/iter  {12 * a.iters / dt:.1f} images/s  "
           f"losses {[round(v, 4) for v in client.last_losses]}")
 print("peak GB", torch.cuda.max_memory_allocated() / 1e9)
+if "--profile" in sys.argv or True:
+    from fedicra_amd import _lib as L
+    client.use_graph = False
+    cfg = {"iter_global": 70, "iters": 3, "eval_iters": 99, "batch_size": 12, "stage": "fit"}
+    args.iters = 3
+    client._train(cfg)
+    L.profile_begin()
+    client._train(cfg)
+    kp = L.profile_end()
+    prof = kp.summary()
+    fam = {}
+    for k, v in prof.items():
+        f = fam.setdefault(k[0], [0, 0.0])
+        f[0] += v["calls"]
+        f[1] += v["ms"]
+    tot = sum(v[1] for v in fam.values())
+    print(f"C-ABI launches, eager, per iteration (sum {tot / 3:.2f} ms; torch glue kernels not included):")
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {k:24s} {v[0] / 3:6.1f} launches  {v[1] / 3:7.3f} ms")
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]
+    for k, v in top:
+        print("   ", k, f"{v['calls'] / 3:.1f} x {v['ms'] / v['calls'] * 1e3:.1f} us")
