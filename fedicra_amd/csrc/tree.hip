@@ -407,8 +407,9 @@ __global__ __launch_bounds__(256) void tree_edge_weights_bwd_kernel(const float*
 //     first node is needed and committed to the ring when the pass reaches it, so neither the load latency nor the
 //     dependent gather hop is ever on the chain.  A level wider than a chunk takes the direct path (global loads).
 #define TREE_CAP 4096
-#define TREE_RT 256      // threads of a recursion workgroup (one wavefront without any barrier was measured: 26.9 vs
-                         // 19.3 ms for the 4-tree loss -- the chunk loader and the wide levels serialise)
+#define TREE_RT 512      // threads of a recursion workgroup.  Measured for the 4-tree loss: 64 (one wavefront, no barrier at
+                         // all) 26.9 ms, 128: 21.9, 256: 19.4, 512: 18.9 -- the chunk loader and the occasional wide level
+                         // want the threads more than the narrow levels mind the barrier; 1024-node chunks: no change
 #define TREE_CH 512      // nodes per streamed chunk
 #define TREE_RING (2 * TREE_CH)
 
