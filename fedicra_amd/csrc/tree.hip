@@ -236,6 +236,8 @@ __global__ __launch_bounds__(TREE_THREADS) void tree_bfs_kernel(const int* __res
 //     between levels wait for the LDS queue only.
 // A level wider than the frontier buffer is served from the global outputs already written (behind a full barrier).
 // Children are emitted in the same order (up, down, left, right, minus the parent): identical output.
+// Measured: the traversal is bound by the instruction stream of its single wave (~0.8 us per level with or without the
+// global stores), not by memory.
 #define BFS_T 256
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
