@@ -29,6 +29,7 @@ class MyClient(_PCEClient):
         self.gatecrf_loss = ModelLossSemsegGatedCRF()
         self.loss_gatedcrf_kernels_desc = [{"weight": 1, "xy": 6, "rgb": 0.1}]          # :68-69
         self.loss_gatedcrf_radius = 5
+        self._lc_stream = None
 
     def _iteration(self, x, y, rec):
         args, opt = self.args, self.optimizer
@@ -43,6 +44,20 @@ class MyClient(_PCEClient):
         loss_ce = ops.ce_loss(outputs.permute(0, 2, 3, 1), y, args.num_classes)          # :135
         unlabeled = (y == args.num_classes)                                              # :136
         three_channel = x.repeat(1, 3, 1, 1) if args.img_class == "faz" else x           # :138-141
+        # The LC loss's no-grad forwards (:153-163) need nothing from the losses above them, and the tree-energy loss is
+        # ~10 ms of dependent chains on a few dozen workgroups: the forwards run on a side stream beside it (no autograd
+        # node is created there; fork / join on the current stream, so a captured iteration keeps a parallel branch).
+        others = []
+        if args.strategy in ["FedICRA"]:
+            cur = torch.cuda.current_stream()
+            if self._lc_stream is None:
+                self._lc_stream = torch.cuda.Stream(device=x.device)
+            self._lc_stream.wait_stream(cur)
+            with torch.cuda.stream(self._lc_stream), torch.no_grad():
+                for other_client in range(args.min_num_clients):
+                    if other_client != args.cid:
+                        # logits and head outputs of these forwards are never read
+                        others.append(self.model(x, other_client, heatmap_only=True)[-4][-1].detach())
         out_tree_loss = self.tree_loss_multi(outputs, three_channel, aux[0], aux[1], aux[2], unlabeled,
                                              args.tree_loss_weight)[0]                   # :142
         outputs_soft = torch.softmax(outputs.float(), dim=1)
@@ -51,13 +66,10 @@ class MyClient(_PCEClient):
         loss = loss_ce + out_tree_loss + 0.1 * out_gatedcrf                              # :151
         loss_lc = None
         if args.strategy in ["FedICRA"]:                                                 # :153-163
+            cur.wait_stream(self._lc_stream)
             acc = 0
-            for other_client in range(args.min_num_clients):
-                if other_client == args.cid:
-                    continue
-                with torch.no_grad():
-                    _heatmaps = self.model(x, other_client, heatmap_only=True)[-4]   # logits and head outputs of it are never read
-                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], _heatmaps[-1].detach())
+            for hm in others:
+                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], hm)
             loss_lc = -acc / (args.min_num_clients - 1)
             loss = torch.add(loss, loss_lc, alpha=args.alpha)
         if self.amp:
