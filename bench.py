@@ -172,6 +172,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
 
+    if a.clients_per_gpu > 2:
+        # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with more than two client streams some
+        # would share a queue and serialise (3 clients: 8.1k images/s on 4 queues, 10.2k on 8).  Must be set before the
+        # runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from fedicra_amd.comm import WeightedAllReduce, init_process_group_from_env
     rank, local, world = init_process_group_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
