@@ -313,6 +313,7 @@ class MyModel(nn.Module):
                         st["warm"] = True
                     elif st["graph"] is None:
                         torch.cuda.synchronize()
+                        ops.reserve_graph_tables()
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, capture_error_mode="thread_local"):
                             st["loss"] = iteration(st["x"], st["y"])

@@ -177,6 +177,7 @@ class MyClient(BaseClient):
                         self._steps[pattern] = rec
                     elif rec.graph is None:
                         torch.cuda.synchronize()
+                        ops.reserve_graph_tables()               # pinned wgrad-reduce tables: not allocatable mid-capture
                         g = torch.cuda.CUDAGraph()
                         # thread_local: only this thread's calls are policed during the capture -- RCCL's watchdog
                         # thread polls events of its own and must not invalidate it (multi-GPU runs)

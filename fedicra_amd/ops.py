@@ -255,27 +255,36 @@ def flush_wgrad():
     _pending_wgrad.clear()
 
 
-_PIN_SLOTS, _PIN_ROWS = 64, 128
-_pin_pool = None
-_pin_next = [0, _PIN_SLOTS // 2]       # eager slots cycle in the first half; captured graphs take the second half for good
+_PIN_SLOTS, _PIN_ROWS = 32, 128
+_pin_pool = None                       # eager launches: a ring of pinned staging tables
+_pin_next = 0
+_graph_free = []                       # captured graphs: each takes a pinned table for good (the graph re-reads it on replay)
+
+
+def reserve_graph_tables(n=4):
+    """Make sure `n` pinned reduce tables are available to a stream capture that is about to start.  Pinned memory
+    cannot be allocated while a stream is capturing, and a captured graph keeps its table for as long as it lives, so
+    the pool grows here -- outside the capture -- instead of being a fixed number of slots (a long-running process
+    that builds new clients every round would run out).  Called by the trainers right before torch.cuda.graph()."""
+    while len(_graph_free) < n:
+        chunk = torch.empty((8, _PIN_ROWS, L.WGRAD_ROW), dtype=torch.int64).pin_memory()
+        _graph_free.extend(chunk[i] for i in range(chunk.shape[0]))
 
 
 def _pinned_slot(nrows, capturing):
-    """Pinned host staging for the reduce table, allocated once (no host allocation inside a stream capture)."""
-    global _pin_pool
-    if _pin_pool is None:
-        _pin_pool = torch.empty((_PIN_SLOTS, _PIN_ROWS, L.WGRAD_ROW), dtype=torch.int64).pin_memory()
+    """Pinned host staging for the reduce table (no host allocation inside a stream capture)."""
+    global _pin_pool, _pin_next
     if nrows > _PIN_ROWS:
         raise L.FiError("too many deferred wgrad reductions in one backward pass")
-    half = _PIN_SLOTS // 2
     if capturing:
-        s = _pin_next[1]
-        if s >= _PIN_SLOTS:
-            raise L.FiError("out of pinned table slots for captured graphs")
-        _pin_next[1] += 1
-    else:
-        s = _pin_next[0]
-        _pin_next[0] = (s + 1) % half
+        if not _graph_free:
+            raise L.FiError("no pinned reduce table left for this capture: call ops.reserve_graph_tables() before "
+                            "torch.cuda.graph()")
+        return _graph_free.pop()[:nrows]
+    if _pin_pool is None:
+        _pin_pool = torch.empty((_PIN_SLOTS, _PIN_ROWS, L.WGRAD_ROW), dtype=torch.int64).pin_memory()
+    s = _pin_next
+    _pin_next = (s + 1) % _PIN_SLOTS
     return _pin_pool[s, :nrows]
 
 

@@ -372,3 +372,26 @@ def test_mini_federation_dice_against_the_cpu_oracle():
     # steps), so the end point is held to "both learned the task"; parity proper is asserted on round 1 above
     assert ref_dice > 0.5 and met["val_mean_dice"] > 0.5, "the phantom task should be learnable in 24 steps per client"
     assert abs(met["val_mean_dice"] - ref_dice) < 0.25
+
+
+def test_many_captured_clients_in_one_process():
+    """A simulation that builds fresh clients every round captures a new training step each time: the pinned tables the
+    captured wgrad reductions read from are grown outside the captures (ops.reserve_graph_tables), not a fixed pool."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from helpers import loader
+    batches = loader(1, 2, 32, cid=0, device=DEV)
+    last = None
+    for k in range(36):                                        # the old fixed pool had 32 slots
+        args = argparse.Namespace(strategy="FedAvg", amp=0, model="unet", cid=0, min_num_clients=1, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=30000, iters=3, rep_iters=3, alpha=0.5,
+                                  snapshot_path=None, use_graph=True)
+        net = UNet(1, 2).cuda()
+        c = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+        loss, _ = c._train({"iter_global": 0, "iters": 3, "eval_iters": 9, "batch_size": 2, "stage": "fit"})
+        assert c._steps["all"].graph is not None and np.isfinite(loss)
+        last = c
+    assert last is not None
