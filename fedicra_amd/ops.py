@@ -93,6 +93,7 @@ class _Context:
         self.arena = _ZeroArena()
         self.seed_offset = None        # device int32[1] added to every RNG seed (training-iteration counter)
         self.call_idx = {}             # uid -> how many times this layer drew a mask in the current iteration
+        self.graph_tables = []         # pinned + device reduce tables of the steps captured under this context
 
 
 _ctx = _Context()
@@ -203,7 +204,6 @@ def _packed(wk, dtype, mode, cout, kk, cin, param=None):
 _pending_wgrad = []            # (workspace, stride, slices, dw, n_dw, dbias, cout) awaiting the multi-tensor reduce
 _wgrad_cb_queued = False
 _table_keepalive = []          # pinned host tables of eager launches: must outlive the async copy
-_graph_tables = []             # tables captured into a hipGraph
 
 
 _side_streams = {}             # device index -> stream the partial-wgrad kernels run on, beside the dgrad/BN chain
@@ -251,7 +251,8 @@ def flush_wgrad():
     table = host.to(dev, non_blocking=True)
     L.wgrad_reduce_multi(table, len(rows), nblocks)
     if capturing:
-        _graph_tables.append((table, [p[:7] for p in _pending_wgrad]))   # the graph re-reads host + partials on every replay
+        # the graph re-reads the host table and the partials on every replay: they live as long as the owning client
+        _ctx.graph_tables.append((host, table, [p[:7] for p in _pending_wgrad]))
     _pending_wgrad.clear()
 
 
