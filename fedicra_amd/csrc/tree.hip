@@ -97,37 +97,99 @@ __global__ __launch_bounds__(TREE_THREADS) void tree_mst_kernel(const float* __r
     }
     __syncthreads();
     // cheapest outgoing edge of every component under the total order (weight, edge index)
-    for (int e = tid; e < E; e += TREE_THREADS) {
-      int u, v;
-      edge_ends(e, H, W, u, v);
-      const int cu = comp[u], cv = comp[v];
-      if (cu != cv) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(wt[e]) << 32) | (unsigned)e;   // weights >= 1
-        atomicMin(&best[cu], key);
-        atomicMin(&best[cv], key);
+    // (four edges per thread in flight: one workgroup walks 2V edges per round, and a loop of dependent
+    // load -> load -> atomic round trips is pure latency)
+    for (int e0 = tid; e0 < E; e0 += 4 * TREE_THREADS) {
+      int cu[4], cv[4];
+      float w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * TREE_THREADS;
+        cu[j] = cv[j] = 0;
+        w4[j] = 0.f;
+        if (e < E) {
+          int u, v;
+          edge_ends(e, H, W, u, v);
+          cu[j] = comp[u], cv[j] = comp[v], w4[j] = wt[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * TREE_THREADS;
+        if (e < E && cu[j] != cv[j]) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint(w4[j]) << 32) | (unsigned)e;   // weights >= 1
+          atomicMin(&best[cu[j]], key);
+          atomicMin(&best[cv[j]], key);
+        }
       }
     }
     __syncthreads();
     // hook every component onto the other end of its edge; of two components that chose the same edge the smaller id stays
-    for (int c = tid; c < V; c += TREE_THREADS) {
-      if (comp[c] != c) continue;
-      const unsigned long long k = best[c];
-      if (k == ~0ull) continue;
-      const int e = (int)(k & 0xffffffffu);
-      int u, v;
-      edge_ends(e, H, W, u, v);
-      const int cu = comp[u], cv = comp[v];
-      const int other = cu == c ? cv : cu;
-      flag[e] = 1;
-      par[c] = (best[other] == k && c < other) ? c : other;
+    for (int c0 = tid; c0 < V; c0 += 4 * TREE_THREADS) {
+      int cc[4];
+      unsigned long long k[4];
+      bool live[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j * TREE_THREADS;
+        cc[j] = c < V ? comp[c] : -1;
+        k[j] = c < V ? best[c] : ~0ull;
+      }
+      int cu[4], cv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j * TREE_THREADS;
+        live[j] = cc[j] == c && k[j] != ~0ull;
+        cu[j] = cv[j] = 0;
+        if (live[j]) {
+          int u, v;
+          edge_ends((int)(k[j] & 0xffffffffu), H, W, u, v);
+          cu[j] = comp[u], cv[j] = comp[v];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!live[j]) continue;
+        const int c = c0 + j * TREE_THREADS;
+        const int other = cu[j] == c ? cv[j] : cu[j];
+        flag[(int)(k[j] & 0xffffffffu)] = 1;
+        par[c] = (best[other] == k[j] && c < other) ? c : other;
+      }
     }
     __syncthreads();
     int mine = 0;
-    for (int v = tid; v < V; v += TREE_THREADS) {
-      int r = comp[v];
-      while (par[r] != r) r = par[r];
-      comp[v] = r;              // par[] is only read here; comp[v] belongs to this thread
-      mine += r == v;
+    for (int v0 = tid; v0 < V; v0 += 4 * TREE_THREADS) {       // four pointer chases per thread side by side
+      int r[4], p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = v0 + j * TREE_THREADS;
+        r[j] = v < V ? comp[v] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = par[r[j]];
+      bool again = true;
+      while (again) {
+        again = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p[j] != r[j]) {
+            r[j] = p[j];
+            again = true;
+          }
+        }
+        if (again) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) p[j] = par[r[j]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = v0 + j * TREE_THREADS;
+        if (v < V) {
+          comp[v] = r[j];         // par[] is only read here; comp[v] belongs to this thread
+          mine += r[j] == v;
+        }
+      }
     }
     __syncthreads();
     if (tid == 0) nroots = 0;
