@@ -542,20 +542,78 @@ struct NodeRing {
   __device__ __forceinline__ float getf(int q, int i) const { return __uint_as_float(get(q, i)); }
 };
 
+// The level walk shared by the three recursions.  UP: levels L-1 .. 0, a node's neighbours are its children in level l+1;
+// down: levels 0 .. L-1, the neighbour is the parent in level l-1.  `fast(i, lo, nlo, mine, other)` handles node i with
+// nothing but LDS (ring record of i, neighbour-level values in `other`, own result into `mine`); `slow(i, lo, nlo, mine,
+// other, cached)` is the global-memory body for levels wider than the streamed chunk or than the LDS level cache.
+//
+// Most levels are narrower than a wavefront.  A run of such levels is walked by wave 0 ALONE, with no workgroup barrier at
+// all (the DS queue of one wave is ordered), while the other waves skip ahead over the level table and wait at the one
+// barrier that ends the run; the whole workgroup only gets involved for a wide level or when the next chunk of node
+// records has to be committed to the ring (its loads sit in the registers of all 512 threads).
+template <int NW, bool UP, class Load, class Fast, class Slow>
+__device__ __forceinline__ void tree_walk(const int* __restrict__ lv, int V, int L, float (*lvl)[TREE_CAP],
+                                          NodeRing<NW>& nr, int cap, int chl, Load&& load, Fast&& fast, Slow&& slow) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  nr.start(load);
+  __syncthreads();
+  // level l = [lv[1+l], lv[2+l])
+  int l = UP ? L - 1 : 0;
+  while (UP ? l >= 0 : l < L) {
+    int lo = lv[1 + l], hi = lv[2 + l];
+    // neighbour level: UP -> children [hi, lv[3+l]) (none for the deepest level); down -> parents [lv[l], lo) (none for l = 0)
+    int nlo = UP ? hi : (l > 0 ? lv[l] : 0);
+    int nw = UP ? (l + 1 < L ? lv[3 + l] - hi : 0) : (l > 0 ? lo - nlo : 0);
+    auto needs_commit = [&](int a, int b) { return UP ? a < V - nr.next * TREE_CH : b > nr.next * TREE_CH; };
+    const bool streamed = hi - lo <= chl, cached = nw <= cap;
+    if (streamed && cached && hi - lo <= 64 && !needs_commit(lo, hi)) {
+      // ---- a run of narrow levels: wave 0 walks, everybody tracks the bounds.  Levels are contiguous, so stepping to
+      // the next level needs ONE new boundary (UP: its first position lv[l], down: its end lv[3+l]); it is loaded a
+      // level ahead so that the scalar load's latency is off the chain.
+      auto edge = [&](int lev) { return UP ? (lev >= 0 ? lv[1 + lev] : 0) : (lev < L ? lv[2 + lev] : 0); };
+      int e1 = edge(UP ? l - 1 : l + 1);                       // the new boundary of the next level
+      for (;;) {
+        const int e2 = edge(UP ? l - 2 : l + 2);               // ... and of the one after it
+        if (wave == 0 && lo + tid < hi) fast(lo + tid, lo, nlo, lvl[l & 1], lvl[(l + 1) & 1]);
+        if (wave == 0) asm volatile("" ::: "memory");
+        l += UP ? -1 : 1;
+        if (UP ? l < 0 : l >= L) break;
+        nw = hi - lo;                                          // the level just finished is the new neighbour level
+        if (UP) {
+          nlo = lo, hi = lo, lo = e1;
+        } else {
+          nlo = lo, lo = hi, hi = e1;
+        }
+        e1 = e2;
+        if (!(hi - lo <= 64 && hi - lo <= chl && nw <= cap && !needs_commit(lo, hi))) break;
+      }
+      level_barrier(false);
+      continue;
+    }
+    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
+    if (streamed && cached) {
+      for (int i = lo + tid; i < hi; i += TREE_RT) fast(i, lo, nlo, lvl[l & 1], lvl[(l + 1) & 1]);
+    } else {
+      for (int i = lo + tid; i < hi; i += TREE_RT) slow(i, lo, nlo, lvl[l & 1], lvl[(l + 1) & 1], cached);
+    }
+    level_barrier(hi - lo > cap);
+    l += UP ? -1 : 1;
+  }
+}
+
 __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const int* __restrict__ sidx, const int* __restrict__ schild,
                                                                const int* __restrict__ levels, int C, int V,
                                                                float* __restrict__ out, int cap, int chl) {
   __shared__ float lvl[2][TREE_CAP];           // a node's CONTRIBUTION to its parent: value * own edge weight
   __shared__ uint32_t ringmem[6][TREE_RING];   // children (4), x[sorted_index[i]], w[i]
-  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.x, c = blockIdx.y;
   const int* si = sidx + (size_t)b * V;
   const int4* sc = reinterpret_cast<const int4*>(schild + (size_t)b * V * 4);
   const int* lv = levels + (size_t)b * (V + 2);
   const float* wb = w + (size_t)b * V;
   const float* xb = x ? x + ((size_t)b * C + c) * V : nullptr;
   float* ob = out + ((size_t)b * C + c) * V;
-  const int L = lv[0];
   auto load = [&](int i, uint32_t* r) {
     const int4 ch = sc[i];
     r[0] = ch.x, r[1] = ch.y, r[2] = ch.z, r[3] = ch.w;
@@ -563,52 +621,34 @@ __global__ __launch_bounds__(TREE_RT) void tree_aggr_up_kernel(const float* __re
     r[5] = __float_as_uint(wb[i]);
   };
   NodeRing<6> nr;
-  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = true;
-  nr.start(load);
-  __syncthreads();
-  int lo_next = lv[L], hi_next = lv[L + 1], chi_next = lv[L + 1];       // level L-1 = [lv[L], lv[L+1]), no children
-  int lo_ahead = L >= 2 ? lv[L - 1] : 0;
-  for (int l = L - 1; l >= 0; --l) {
-    const int lo = lo_next, hi = hi_next;
-    const int clo = hi, chi = chi_next;                          // the children live in level l+1 = [hi, lv[3+l])
-    chi_next = hi, hi_next = lo, lo_next = lo_ahead;             // level boundaries slide; the new one is loaded a level ahead
-    if (l >= 2) lo_ahead = lv[l - 1];
-    const float* below = lvl[(l + 1) & 1];
-    float* mine = lvl[l & 1];
-    const bool cached = chi - clo <= cap;
-    const bool streamed = hi - lo <= chl;
-    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
-    if (streamed && cached) {
-      // fast path: LDS in, LDS out (+ a fire-and-forget store).  Kept free of any global LOAD so that no s_waitcnt
-      // vmcnt lands on the chain (vmcnt also counts the stores and the chunk loads in flight).
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        const int c0 = (int)nr.get(0, i), c1 = (int)nr.get(1, i), c2 = (int)nr.get(2, i), c3 = (int)nr.get(3, i);
-        float s = nr.getf(4, i);
-        const float wi = nr.getf(5, i);
-        // four independent LDS reads in flight (slot 0 stands in for "no child"), one wait
-        const float v0 = below[c0 > 0 ? c0 - clo : 0], v1 = below[c1 > 0 ? c1 - clo : 0];
-        const float v2 = below[c2 > 0 ? c2 - clo : 0], v3 = below[c3 > 0 ? c3 - clo : 0];
-        if (c0 > 0) s = __fadd_rn(s, v0);
-        if (c1 > 0) s = __fadd_rn(s, v1);
-        if (c2 > 0) s = __fadd_rn(s, v2);
-        if (c3 > 0) s = __fadd_rn(s, v3);
-        ob[i] = s;
-        mine[i - lo] = __fmul_rn(s, wi);
-      }
-    } else {
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        const int4 c4 = sc[i];
-        const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        float s = xb ? xb[si[i]] : 1.0f;
+  nr.ring = ringmem, nr.V = V, nr.tid = threadIdx.x, nr.up = true;
+  // fast path: LDS in, LDS out (+ a fire-and-forget store).  Kept free of any global LOAD so that no s_waitcnt vmcnt lands
+  // on the chain (vmcnt also counts the stores and the chunk loads in flight).
+  auto fast = [&](int i, int lo, int clo, float* mine, const float* below) {
+    const int c0 = (int)nr.get(0, i), c1 = (int)nr.get(1, i), c2 = (int)nr.get(2, i), c3 = (int)nr.get(3, i);
+    float s = nr.getf(4, i);
+    const float wi = nr.getf(5, i);
+    // four independent LDS reads in flight (slot 0 stands in for "no child"), one wait
+    const float v0 = below[c0 > 0 ? c0 - clo : 0], v1 = below[c1 > 0 ? c1 - clo : 0];
+    const float v2 = below[c2 > 0 ? c2 - clo : 0], v3 = below[c3 > 0 ? c3 - clo : 0];
+    if (c0 > 0) s = __fadd_rn(s, v0);
+    if (c1 > 0) s = __fadd_rn(s, v1);
+    if (c2 > 0) s = __fadd_rn(s, v2);
+    if (c3 > 0) s = __fadd_rn(s, v3);
+    ob[i] = s;
+    mine[i - lo] = __fmul_rn(s, wi);
+  };
+  auto slow = [&](int i, int lo, int clo, float* mine, const float* below, bool cached) {
+    const int4 c4 = sc[i];
+    const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+    float s = xb ? xb[si[i]] : 1.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (cc[q] > 0) s = __fadd_rn(s, cached ? below[cc[q] - clo] : __fmul_rn(ld_coherent(ob + cc[q]), wb[cc[q]]));
-        ob[i] = s;
-        if (i - lo < cap) mine[i - lo] = __fmul_rn(s, wb[i]);
-      }
-    }
-    level_barrier(hi - lo > cap);
-  }
+    for (int q = 0; q < 4; ++q)
+      if (cc[q] > 0) s = __fadd_rn(s, cached ? below[cc[q] - clo] : __fmul_rn(ld_coherent(ob + cc[q]), wb[cc[q]]));
+    ob[i] = s;
+    if (i - lo < cap) mine[i - lo] = __fmul_rn(s, wb[i]);
+  };
+  tree_walk<6, true>(lv, V, lv[0], lvl, nr, cap, chl, load, fast, slow);
 }
 
 __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __restrict__ xs, const float* __restrict__ w,
@@ -617,14 +657,13 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
                                                                  float* __restrict__ out, int cap, int chl) {
   __shared__ float lvl[2][TREE_CAP];
   __shared__ uint32_t ringmem[4][TREE_RING];   // parent position, vertex, x_sorted[i], w[i]
-  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.x, c = blockIdx.y;
   const int* si = sidx + (size_t)b * V;
   const int* sp = spar + (size_t)b * V;
   const int* lv = levels + (size_t)b * (V + 2);
   const float* wb = w + (size_t)b * V;
   const float* xb = xs + ((size_t)b * C + c) * V;
   float* ob = out + ((size_t)b * C + c) * V;
-  const int L = lv[0];
   auto load = [&](int i, uint32_t* r) {
     r[0] = (uint32_t)sp[i];
     r[1] = (uint32_t)si[i];
@@ -632,42 +671,24 @@ __global__ __launch_bounds__(TREE_RT) void tree_prop_down_kernel(const float* __
     r[3] = __float_as_uint(i == 0 ? 0.f : wb[i]);      // the root's edge weight counts as 0 (refine.cu:43-46)
   };
   NodeRing<4> nr;
-  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = false;
-  nr.start(load);
-  __syncthreads();
-  int plo_next = 0, lo_next = lv[1], hi_next = lv[2];
-  int hi_ahead = L >= 2 ? lv[3] : 0;
-  for (int l = 0; l < L; ++l) {
-    const int lo = lo_next, hi = hi_next;
-    const int plo = plo_next;                                    // the parents live in level l-1 = [lv[l], lo)
-    plo_next = lo, lo_next = hi, hi_next = hi_ahead;
-    if (l + 2 < L) hi_ahead = lv[4 + l];
-    const float* above = lvl[(l + 1) & 1];
-    float* mine = lvl[l & 1];
-    const bool cached = lo - plo <= cap;
-    const bool streamed = hi - lo <= chl;
-    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
-    if (streamed && cached) {
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        const int p = (int)nr.get(0, i), vtx = (int)nr.get(1, i);
-        const float xi = nr.getf(2, i), wi = nr.getf(3, i);
-        const float pv = l == 0 ? 0.f : above[p - plo];
-        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
-        ob[vtx] = v;
-        mine[i - lo] = v;
-      }
-    } else {
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        const int p = sp[i];
-        const float xi = xb[i], wi = i == 0 ? 0.f : wb[i];
-        const float pv = l == 0 ? 0.f : (cached ? above[p - plo] : ld_coherent(ob + si[p]));
-        const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
-        ob[si[i]] = v;
-        if (i - lo < cap) mine[i - lo] = v;
-      }
-    }
-    level_barrier(hi - lo > cap);
-  }
+  nr.ring = ringmem, nr.V = V, nr.tid = threadIdx.x, nr.up = false;
+  auto fast = [&](int i, int lo, int plo, float* mine, const float* above) {
+    const int p = (int)nr.get(0, i), vtx = (int)nr.get(1, i);
+    const float xi = nr.getf(2, i), wi = nr.getf(3, i);
+    const float pv = i == 0 ? 0.f : above[p - plo];
+    const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
+    ob[vtx] = v;
+    mine[i - lo] = v;
+  };
+  auto slow = [&](int i, int lo, int plo, float* mine, const float* above, bool cached) {
+    const int p = sp[i];
+    const float xi = xb[i], wi = i == 0 ? 0.f : wb[i];
+    const float pv = i == 0 ? 0.f : (cached ? above[p - plo] : ld_coherent(ob + si[p]));
+    const float v = __fadd_rn(__fmul_rn(xi, __fsub_rn(1.0f, __fmul_rn(wi, wi))), __fmul_rn(pv, wi));
+    ob[si[i]] = v;
+    if (i - lo < cap) mine[i - lo] = v;
+  };
+  tree_walk<4, false>(lv, V, lv[0], lvl, nr, cap, chl, load, fast, slow);
 }
 
 // refine.cu:136-199: grad[cur] = in_grad[cur]*(out_data[par] - w*in_data[cur]) + in_data[cur]*(G[par] - w*in_grad[cur]),
@@ -676,10 +697,11 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
                                                                 const float* __restrict__ out_data,
                                                                 const float* __restrict__ w, const int* __restrict__ sidx,
                                                                 const int* __restrict__ spar, const int* __restrict__ levels,
-                                                                int Cd, int Cg, int V, float* __restrict__ grad, int cap, int chl) {
+                                                                int Cd, int Cg, int V, float* __restrict__ grad, int cap,
+                                                                int chl) {
   __shared__ float lvl[2][TREE_CAP];
   __shared__ uint32_t ringmem[5][TREE_RING];   // parent position, w[i], in_grad[i], in_data[i], out_data[sorted_index[parent]]
-  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.x, k = blockIdx.y;
   const int Cmax = Cd > Cg ? Cd : Cg;
   const int* si = sidx + (size_t)b * V;
   const int* sp = spar + (size_t)b * V;
@@ -689,7 +711,6 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
   const float* odb = out_data + ((size_t)b * Cd + k % Cd) * V;
   float* igb = in_grad + ((size_t)b * Cg + k % Cg) * V;
   float* gb = grad + ((size_t)b * Cmax + k) * V;
-  const int L = lv[0];
   // in_grad[i] is only rewritten (propagated) when node i itself is processed, and a chunk is always loaded before the
   // pass reaches it: the streamed copy is the not-yet-propagated value the formula wants (the entry point guarantees one
   // workgroup per gradient channel: Cd == Cg or Cd == 1).
@@ -702,56 +723,38 @@ __global__ __launch_bounds__(TREE_RT) void tree_grad_rec_kernel(const float* __r
     r[4] = __float_as_uint(i > 0 ? odb[si[p]] : 0.f);
   };
   NodeRing<5> nr;
-  nr.ring = ringmem, nr.V = V, nr.tid = tid, nr.up = false;
-  nr.start(load);
-  __syncthreads();
-  int plo_next = 0, lo_next = lv[1], hi_next = lv[2];
-  int hi_ahead = L >= 2 ? lv[3] : 0;
-  for (int l = 0; l < L; ++l) {
-    const int lo = lo_next, hi = hi_next;
-    const int plo = plo_next;
-    plo_next = lo, lo_next = hi, hi_next = hi_ahead;
-    if (l + 2 < L) hi_ahead = lv[4 + l];
-    const float* above = lvl[(l + 1) & 1];
-    float* mine = lvl[l & 1];
-    const bool cached = lo - plo <= cap;
-    const bool streamed = hi - lo <= chl;
-    if (streamed && nr.ensure(lo, hi, load)) __syncthreads();
-    if (streamed && cached) {
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        const float ig = nr.getf(2, i);
-        float G = ig;                                              // the root's gradient stays as aggregated
-        if (i == 0) {
-          gb[0] = 0.f;
-        } else {
-          const int p = (int)nr.get(0, i);
-          const float wi = nr.getf(1, i), id = nr.getf(3, i), od = nr.getf(4, i);
-          const float gp = above[p - plo];
-          gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
-          G = ig * (1.0f - wi * wi) + gp * wi;
-          igb[i] = G;
-        }
-        mine[i - lo] = G;
-      }
+  nr.ring = ringmem, nr.V = V, nr.tid = threadIdx.x, nr.up = false;
+  auto fast = [&](int i, int lo, int plo, float* mine, const float* above) {
+    const float ig = nr.getf(2, i);
+    float G = ig;                                              // the root's gradient stays as aggregated
+    if (i == 0) {
+      gb[0] = 0.f;
     } else {
-      for (int i = lo + tid; i < hi; i += TREE_RT) {
-        float G;
-        if (i == 0) {
-          gb[0] = 0.f;
-          G = igb[0];
-        } else {
-          const int p = sp[i];
-          const float wi = wb[i], ig = igb[i], id = idb[i], od = odb[si[p]];
-          const float gp = cached ? above[p - plo] : ld_coherent(igb + p);
-          gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
-          G = ig * (1.0f - wi * wi) + gp * wi;
-          igb[i] = G;
-        }
-        if (i - lo < cap) mine[i - lo] = G;
-      }
+      const int p = (int)nr.get(0, i);
+      const float wi = nr.getf(1, i), id = nr.getf(3, i), od = nr.getf(4, i);
+      const float gp = above[p - plo];
+      gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
+      G = ig * (1.0f - wi * wi) + gp * wi;
+      igb[i] = G;
     }
-    level_barrier(hi - lo > cap);
-  }
+    mine[i - lo] = G;
+  };
+  auto slow = [&](int i, int lo, int plo, float* mine, const float* above, bool cached) {
+    float G;
+    if (i == 0) {
+      gb[0] = 0.f;
+      G = igb[0];
+    } else {
+      const int p = sp[i];
+      const float wi = wb[i], ig = igb[i], id = idb[i], od = odb[si[p]];
+      const float gp = cached ? above[p - plo] : ld_coherent(igb + p);
+      gb[i] = ig * (od - wi * id) + id * (gp - wi * ig);
+      G = ig * (1.0f - wi * wi) + gp * wi;
+      igb[i] = G;
+    }
+    if (i - lo < cap) mine[i - lo] = G;
+  };
+  tree_walk<5, false>(lv, V, lv[0], lvl, nr, cap, chl, load, fast, slow);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
