@@ -359,24 +359,27 @@ __global__ __launch_bounds__(BFS_T) void tree_bfs_lds_kernel(const int* __restri
     // 64 positions; called from two separate branches so that the LDS-fed one contains no global load (a merged value
     // would put an s_waitcnt vmcnt -- i.e. a wait for the stores in flight -- on every level)
     auto chunk = [&](int i, int cur, int pv) {
-      int kids[4], nk = 0;
-      if (i < hi) {
-        const uint32_t m = (mask[cur >> 3] >> ((cur & 7) * 4)) & 15u;
-        if ((m & 1u) && cur - W != pv) kids[nk++] = cur - W;
-        if ((m & 2u) && cur + W != pv) kids[nk++] = cur + W;
-        if ((m & 4u) && cur - 1 != pv) kids[nk++] = cur - 1;
-        if ((m & 8u) && cur + 1 != pv) kids[nk++] = cur + 1;
-      }
+      // the (up to) four children straight-line, no per-lane arrays or loops: the traversal is one wave's instruction stream
+      uint32_t m = 0u;
+      if (i < hi) m = (mask[cur >> 3] >> ((cur & 7) * 4)) & 15u;
+      const int k0 = cur - W, k1 = cur + W, k2 = cur - 1, k3 = cur + 1;
+      const int f0 = (m & 1u) && k0 != pv, f1 = (m & 2u) && k1 != pv, f2 = (m & 4u) && k2 != pv, f3 = (m & 8u) && k3 != pv;
+      const int nk = f0 + f1 + f2 + f3;
       const unsigned long long b0 = __ballot(nk & 1), b1 = __ballot(nk & 2), b2 = __ballot(nk & 4);
       const int off = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
       const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-      for (int q = 0; q < nk; ++q) {
-        const int pos = next + off + q;
-        si[pos] = kids[q];
+      int pos = next + off;
+      auto emit = [&](int kid, int q) {
+        si[pos] = kid;
         sp[pos] = i;
         sc[i * 4 + q] = pos;
-        if (pos - hi < cap) nv[pos - hi] = kids[q], np_[pos - hi] = cur;
-      }
+        if (pos - hi < cap) nv[pos - hi] = kid, np_[pos - hi] = cur;
+      };
+      int q = 0;
+      if (f0) { emit(k0, q); ++pos; ++q; }
+      if (f1) { emit(k1, q); ++pos; ++q; }
+      if (f2) { emit(k2, q); ++pos; ++q; }
+      if (f3) { emit(k3, q); }
       next += total;
     };
     if (in_lds) {
