@@ -231,7 +231,10 @@ int fi_gatedcrf_fwd(const float* y, const float* feat, int N, int H, int W, int 
  * fi_tree_bfs: breadth-first order from vertex 0 (bfs/bfs.cu:19-98): sorted_index [B][V] (vertex at each position),
  *   sorted_parent [B][V] (position of the parent; 0 for the root), sorted_child [B][V][4] (positions, 0 = none);
  *   levels int32 [B][V+2]: levels[b][0] = number of levels L, levels[b][1+l] = first position of level l (.. [1+L] = V);
- *   adjacency_workspace int32 [B][V][4].  Deterministic (frontier order; neighbours up, down, left, right).
+ *   adjacency_workspace int32 [B][V][4] (only touched when the image is too large for the LDS-resident traversal,
+ *   ~512^2).  Deterministic (frontier order; neighbours up, down, left, right).  Test hooks (environment, read per
+ *   call): FI_TREE_BFS_GLOBAL=1 forces the global-memory traversal; FI_TREE_CAP / FI_TREE_CHUNK shrink the LDS level
+ *   cache / streamed chunk of the three recursions so that small images exercise their global-memory paths.
  * fi_tree_edge_weights: w[b][i] = exp(-|e[:,sorted_index[i]] - e[:,parent]|^2 * inv_sigma)   (tree_filter.py:92-110);
  *   fi_tree_edge_weights_bwd: grad_embed (original order) from grad_w (sorted).
  * fi_tree_aggr_up  : out[i] = x[sorted_index[i]] + sum_child out[child]*w[child]   (x == NULL: 1)   refine.cu:70-134
