@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -547,6 +547,14 @@ def scale(x, y, a, divide=False):
 
 def axpy(acc, x, a):
     _chk(lib().fi_axpy(ptr(_dev(acc)), ptr(x), C.c_long(x.numel()), C.c_float(a), stream()), "fi_axpy")
+
+
+def fedopt_step(mode, cur, agg, m, v, eta, beta1, beta2, tau):
+    """mode 0 FedAdagrad, 1 FedAdam, 2 FedYogi; the python-float constants are rounded to fp32 the way numpy does."""
+    import numpy as np
+    f = lambda x: C.c_float(float(np.float32(x)))
+    _chk(lib().fi_fedopt_step(int(mode), ptr(_dev(cur)), ptr(agg), ptr(m), ptr(v), C.c_long(cur.numel()), f(eta), f(beta1),
+                              f(1.0 - beta1), f(beta2), f(1.0 - beta2), f(tau), stream()), "fi_fedopt_step")
 
 
 def ala_update(w, temp, grad, local, glob, eta):

@@ -467,13 +467,53 @@ extern "C" int fi_scale(const float* x, float* y, long n, float a, int divide, v
 }
 
 __global__ void axpy_kernel(float* __restrict__ acc, const float* __restrict__ x, long n, float a) {
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    acc[i] = __fadd_rn(acc[i], __fmul_rn(x[i], a));
+    acc[i] = acc[i] + x[i] * a;     // plain operators: the pragma does not reach into the __f*_rn header inlines
 }
 extern "C" int fi_axpy(float* acc, const float* x, long n, float a, void* stream) {
   if (!acc || !x) return FI_ERR_NULL;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, acc, x, n, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// flwr 1.0.0 FedOpt server optimizers (flwr/server/strategy/{fedadagrad,fedadam,fedyogi}.py, restated from the published
+// source -- flwr is absent: parity unpinned) on the flat fp32 state, every product / sum rounded to fp32 like numpy does:
+//   delta = agg - cur;  m = b1*m + (1-b1)*delta;  v: adagrad v + delta^2 | adam b2*v + (1-b2)*delta^2 |
+//   yogi v - (1-b2)*delta^2*sign(v - delta^2);  cur = cur + eta*m / (sqrt(v) + tau)
+__global__ void fedopt_step_kernel(int mode, float* __restrict__ cur, const float* __restrict__ agg, float* __restrict__ m,
+                                   float* __restrict__ v, long n, float eta, float b1, float omb1, float b2, float omb2,
+                                   float tau) {
+#pragma clang fp contract(off)   // numpy rounds every product and sum: no fused multiply-add (plain operators below -- the
+                                 // pragma does not reach into the __f*_rn header inlines, which DO get contracted)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = agg[i] - cur[i];
+    const float mi = b1 * m[i] + omb1 * d;
+    const float d2 = d * d;
+    float vi = v[i];
+    if (mode == 0) {
+      vi = vi + d2;
+    } else if (mode == 1) {
+      vi = b2 * vi + omb2 * d2;
+    } else {
+      const float df = vi - d2;
+      const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : df);          // np.sign: 0 -> 0, nan -> nan
+      vi = vi - (omb2 * d2) * sg;
+    }
+    m[i] = mi;
+    v[i] = vi;
+    cur[i] = cur[i] + (eta * mi) / (sqrtf(vi) + tau);
+  }
+}
+extern "C" int fi_fedopt_step(int mode, float* cur, const float* agg, float* m, float* v, long n, float eta, float beta1,
+                              float one_minus_beta1, float beta2, float one_minus_beta2, float tau, void* stream) {
+  if (!cur || !agg || !m || !v) return FI_ERR_NULL;
+  if (mode < 0 || mode > 2) return FI_ERR_UNSUPPORTED;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fedopt_step_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, mode, cur, agg, m, v,
+                     n, eta, beta1, one_minus_beta1, beta2, one_minus_beta2, tau);
   FI_CHECK_LAUNCH();
   return 0;
 }

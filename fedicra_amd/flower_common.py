@@ -470,13 +470,106 @@ class FedICRA(FedAvg):
         return f"FedICRA(accept_failures={self.accept_failures})"
 
 
+class FedOpt(FedAvg):
+    """flwr 1.0.0 ``FedOpt`` family (Reddi et al., Adaptive Federated Optimization): FedAvg's weighted mean is treated as
+    a pseudo-gradient ``delta = mean - current`` for a server-side Adagrad / Adam / Yogi step.  flwr is third-party and
+    absent here: restated from its published source (strategy/fedopt.py, fedadagrad.py, fedadam.py, fedyogi.py) --
+    *parity unpinned*.  Like flwr, ``initial_parameters`` is mandatory (the reference passes it only inside a commented
+    block, flower_pCE_2D.py:353-363, so its own FedOpt runs fail at construction).  Host payloads (lists of numpy arrays)
+    follow numpy's dtype rules array by array; ``DeviceWeights`` payloads run ``fi_fedopt_step`` on the flat state."""
+
+    MODE = None
+    DEFAULTS = {}
+
+    def __init__(self, *, initial_parameters, eta=None, eta_l=None, beta_1=None, beta_2=None, tau=None, **kwargs):
+        super().__init__(**kwargs)
+        d = self.DEFAULTS
+        self.eta = d["eta"] if eta is None else eta
+        self.eta_l = d["eta_l"] if eta_l is None else eta_l
+        self.beta_1 = d["beta_1"] if beta_1 is None else beta_1
+        self.beta_2 = d["beta_2"] if beta_2 is None else beta_2
+        self.tau = d["tau"] if tau is None else tau
+        self.on_device = isinstance(initial_parameters, DeviceWeights)
+        if self.on_device:
+            self.current = DeviceWeights(initial_parameters.state.clone(), initial_parameters.counters.clone())
+            self.cnt = initial_parameters.counters.clone()            # int64 like flwr's first current_weights
+        else:
+            self.current_weights = [np.array(a) for a in fl.parameters_to_ndarrays(initial_parameters)]
+        self.m_t = self.v_t = None
+
+    def _second_moment(self, v, d):
+        raise NotImplementedError
+
+    def aggregate_fit(self, server_round, results, failures):
+        agg, metrics = super().aggregate_fit(server_round, results, failures)
+        if agg is None:
+            return None, {}
+        if self.on_device:
+            cur = self.current.state
+            if self.m_t is None:
+                self.m_t, self.v_t = torch.zeros_like(cur), torch.zeros_like(cur)
+                self.m_c = torch.zeros(self.cnt.shape, dtype=torch.float64, device=cur.device)
+                self.v_c = torch.zeros_like(self.m_c)
+            L.fedopt_step(self.MODE, cur, agg.state, self.m_t, self.v_t, self.eta, self.beta_1, self.beta_2, self.tau)
+            # the int64 counters: FedAvg hands back their float64 true-divide; the step runs in float64 (numpy's promotion)
+            # and the clients truncate on load (quirk 6).  18 scalars: plain tensor arithmetic.
+            total = sum(r.num_examples for _, r in results)
+            avg = sum(r.parameters.counters.double() * int(r.num_examples) for _, r in results) / total
+            d = avg - self.cnt.double()
+            self.m_c = self.beta_1 * self.m_c + (1 - self.beta_1) * d
+            self.v_c = self._second_moment(self.v_c, d)
+            self.cnt = self.cnt.double() + self.eta * self.m_c / (torch.sqrt(self.v_c) + self.tau)
+            self.current = DeviceWeights(cur, self.cnt.to(torch.int64))
+            return DeviceWeights(cur.clone(), self.cnt.to(torch.int64)), metrics
+        fedavg_weights = fl.parameters_to_ndarrays(agg)
+        delta_t = [x - y for x, y in zip(fedavg_weights, self.current_weights)]
+        if not self.m_t:
+            self.m_t = [np.zeros_like(x) for x in delta_t]
+        self.m_t = [self.beta_1 * x + (1 - self.beta_1) * y for x, y in zip(self.m_t, delta_t)]
+        if not self.v_t:
+            self.v_t = [np.zeros_like(x) for x in delta_t]
+        self.v_t = [self._second_moment(x, y) for x, y in zip(self.v_t, delta_t)]
+        new_weights = [x + self.eta * y / (np.sqrt(z) + self.tau) for x, y, z in zip(self.current_weights, self.m_t, self.v_t)]
+        self.current_weights = new_weights
+        return fl.ndarrays_to_parameters(self.current_weights), metrics
+
+    def __repr__(self):
+        return f"{type(self).__name__}(accept_failures={self.accept_failures})"
+
+
+def _mul(y):
+    return y * y if torch.is_tensor(y) else np.multiply(y, y)
+
+
+class FedAdagrad(FedOpt):
+    MODE, DEFAULTS = 0, {"eta": 1e-1, "eta_l": 1e-1, "beta_1": 0.0, "beta_2": 0.0, "tau": 1e-9}
+
+    def _second_moment(self, v, d):
+        return v + _mul(d)
+
+
+class FedAdam(FedOpt):
+    MODE, DEFAULTS = 1, {"eta": 1e-1, "eta_l": 1e-1, "beta_1": 0.9, "beta_2": 0.99, "tau": 1e-9}
+
+    def _second_moment(self, v, d):
+        return self.beta_2 * v + (1 - self.beta_2) * _mul(d)
+
+
+class FedYogi(FedOpt):
+    MODE, DEFAULTS = 2, {"eta": 1e-2, "eta_l": 0.0316, "beta_1": 0.9, "beta_2": 0.99, "tau": 1e-3}
+
+    def _second_moment(self, v, d):
+        d2 = _mul(d)
+        sign = torch.sign(v - d2) if torch.is_tensor(v) else np.sign(v - d2)
+        return v - (1.0 - self.beta_2) * d2 * sign
+
+
 def get_strategy(name, **kwargs):
     assert name in (CENTRALIZED_FL + PERSONALIZED_FL)
-    if name == "FedAvg":
-        return FedAvg(**kwargs)
-    if name == "FedICRA":
-        return FedICRA(**kwargs)
-    raise NotImplementedError(name + " (FedAdagrad/FedAdam/FedYogi server optimizers are outside the hot path)")
+    cls = {"FedAvg": FedAvg, "FedICRA": FedICRA, "FedAdagrad": FedAdagrad, "FedAdam": FedAdam, "FedYogi": FedYogi}.get(name)
+    if cls is None:
+        raise NotImplementedError(name)
+    return cls(**kwargs)
 
 
 def fit_metrics_aggregation_fn(fit_metrics):

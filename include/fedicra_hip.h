@@ -327,6 +327,13 @@ int fi_amp_update(float* scale, int* growth_tracker, float* found_inf, float gro
  *           i.e. numpy's  acc + (x * n_k)  bit for bit -- used by the single-process aggregator. */
 int fi_scale(const float* x, float* y, long n, float a, int divide, void* stream);
 int fi_axpy(float* acc, const float* x, long n, float a, void* stream);
+/* The FedOpt server optimizers the reference can select (flower_common.py:432-448 -> flwr 1.0.0 FedAdagrad / FedAdam /
+ * FedYogi; third-party and absent: restated from the published source, parity unpinned) on the flat fp32 state:
+ *   delta = agg - cur;  m = beta1*m + (1-beta1)*delta;
+ *   v = v + delta^2 (mode 0) | beta2*v + (1-beta2)*delta^2 (1) | v - (1-beta2)*delta^2*sign(v - delta^2) (2);
+ *   cur = cur + eta*m / (sqrt(v) + tau)          -- every product and sum rounded to fp32, numpy's evaluation order. */
+int fi_fedopt_step(int mode, float* cur, const float* agg, float* m, float* v, long n, float eta, float beta1,
+                   float one_minus_beta1, float beta2, float one_minus_beta2, float tau, void* stream);
 /* FedICRA ALA element-wise step (/root/reference/code/flower_common.py:590-602):
  *   w    = clamp(w - eta * grad * (local - global), 0, 1)
  *   temp = global + (local - global) * w                                                   */

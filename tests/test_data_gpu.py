@@ -395,3 +395,50 @@ def test_many_captured_clients_in_one_process():
         assert c._steps["all"].graph is not None and np.isfinite(loss)
         last = c
     assert last is not None
+
+
+@pytest.mark.parametrize("name", ["FedAdagrad", "FedAdam", "FedYogi"])
+def test_fedopt_device_path_equals_host_path(name):
+    """FedOpt on DeviceWeights (fi_fedopt_step over the flat state) against the same strategy on numpy payloads: three
+    rounds, fp32 state bit for bit (numpy's evaluation order and roundings), counters after the clients' truncation."""
+    from fedicra_amd import fl
+    from fedicra_amd.flower_common import DeviceWeights, get_strategy
+    n = 100003
+    g = torch.Generator().manual_seed(3)
+    init = torch.randn(n, generator=g)
+    cnt0 = torch.tensor([5, 9], dtype=torch.int64)
+
+    class Res:
+        def __init__(self, params, ne):
+            self.parameters, self.num_examples, self.metrics = params, ne, {}
+
+    host = get_strategy(name, initial_parameters=fl.ndarrays_to_parameters([init.numpy().copy(), np.array(5), np.array(9)]))
+    dev = get_strategy(name, initial_parameters=DeviceWeights(init.to(DEV), cnt0.to(DEV)))
+    for rnd in range(3):
+        ws = [torch.randn(n, generator=g) * (0.5 + rnd) for _ in range(2)]
+        cs = [torch.tensor([7 + rnd, 11], dtype=torch.int64), torch.tensor([8 + 2 * rnd, 3], dtype=torch.int64)]
+        hres = [(None, Res(fl.ndarrays_to_parameters([w.numpy(), np.array(int(c[0])), np.array(int(c[1]))]), ne))
+                for w, c, ne in zip(ws, cs, (3, 5))]
+        dres = [(None, Res(DeviceWeights(w.to(DEV), c.to(DEV)), ne)) for w, c, ne in zip(ws, cs, (3, 5))]
+        hp, _ = host.aggregate_fit(rnd, hres, [])
+        dp, _ = dev.aggregate_fit(rnd, dres, [])
+        hw = fl.parameters_to_ndarrays(hp)
+        assert torch.equal(dp.state.cpu(), torch.from_numpy(hw[0])), float((dp.state.cpu() - torch.from_numpy(hw[0])).abs().max())
+        assert dp.counters.tolist() == [int(np.float64(hw[1])), int(np.float64(hw[2]))]
+
+
+def test_device_fedavg_equals_numpy_aggregate_bit_for_bit():
+    """aggregate_device (fi_scale / fi_axpy over flat device states) against flwr's `aggregate` restated in numpy, on
+    random data, K = 2, 5, 8 with the FAZ-like n_k: bit-identical fp32 (products rounded before the sum -- an FMA in the
+    accumulate differs in ~25 % of the elements), counters after the float64 divide + truncation."""
+    from fedicra_amd.flower_common import DeviceWeights, aggregate, aggregate_device
+    g = torch.Generator().manual_seed(11)
+    n = 200001
+    n_k = [21, 13, 17, 59, 3, 21, 13, 17]
+    for K in (2, 5, 8):
+        ws = [torch.randn(n, generator=g) * (1 + 0.3 * k) for k in range(K)]
+        cs = [torch.tensor([10 * k + 3, 7 + k], dtype=torch.int64) for k in range(K)]
+        want = aggregate([([w.numpy(), np.array(int(c[0])), np.array(int(c[1]))], n_k[k]) for k, (w, c) in enumerate(zip(ws, cs))])
+        got = aggregate_device([(DeviceWeights(w.to(DEV), c.to(DEV)), n_k[k]) for k, (w, c) in enumerate(zip(ws, cs))])
+        assert torch.equal(got.state.cpu(), torch.from_numpy(want[0])), K
+        assert got.counters.tolist() == [int(want[1]), int(want[2])]
