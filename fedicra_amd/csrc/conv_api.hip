@@ -103,7 +103,8 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     const int big = f32 ? 32 : 64, vg = f32 ? 4 : 8, esz = f32 ? 4 : 2, kstep = f32 ? 4 : 32;
     const int halo = d->ksize / 2, kk = d->ksize * d->ksize;
     const long kcp = (long)((kk * big + kstep - 1) / kstep) * kstep;
-    const long lds = ((long)(th + 2 * halo) * (16 + 2 * halo) * (big + vg) + (long)nf * 16 * (kcp + vg)) * esz;
+    const int pad = f32 ? vg : 16;                     // FiLdsStride: 16-bit tiles are padded to 32 bytes mod 64
+    const long lds = ((long)(th + 2 * halo) * (16 + 2 * halo) * (big + pad) + (long)nf * 16 * (kcp + pad)) * esz;
     if (nf <= 2 && ck * 2 == big && cin >= 2 * big && d->c0 % big == 0 && d->c1 % big == 0 && lds <= lds_cap) ck = big;
   }
   ConvArgs a;
