@@ -119,15 +119,19 @@ class UpBlock(_FiModule):
     def __init__(self, in_channels1, in_channels2, out_channels, dropout_p, bilinear=True):
         super().__init__()
         self.bilinear = bilinear
-        if not bilinear:
-            raise NotImplementedError("ConvTranspose2d branch (unet.py:60-62) is dead code in the reference: "
-                                      "every decoder passes the default bilinear=True")
-        self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
-        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        if bilinear:
+            self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        else:       # unet.py:60-62 -- no decoder of the reference selects it (they all pass the default), built for the surface
+            self.up = nn.ConvTranspose2d(in_channels1, in_channels2, kernel_size=2, stride=2)
         self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
 
     def _run(self, x1, x2):
-        up = ops.upsample2x(ops.conv2d(x1, None, self.conv1x1))
+        if self.bilinear:
+            up = ops.upsample2x(ops.conv2d(x1, None, self.conv1x1))
+        else:
+            from .. import extra_ops
+            up = extra_ops.conv_transpose2x(x1, self.up)
         return self.conv._run(x2, up)            # == ConvBlock(cat([x2, up], dim=1))
 
     def forward(self, x1, x2):

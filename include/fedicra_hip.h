@@ -362,6 +362,24 @@ int fi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, vo
 int fi_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, void* stream);
 int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int C, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- defined-but-unused module surface -----------
+ * ConvTranspose{2,3}d(kernel 2, stride 2) -- UpBlock(bilinear=False) (/root/reference/code/networks/unet.py:60-62, never
+ * selected by the reference's decoders) and VNet's UpsamplingDeconvBlock (networks/vnet.py:94-118) -- has no overlapping
+ * taps: it is ONE 1x1 convolution to P*Cout channels ordered [tap][co] (P = 4: (a, b); 8: (c, a, b)), run by
+ * fi_conv2d_fwd / _wgrad, followed by this depth-to-space shuffle:
+ *   packed [N][D][H][W][P][C]  <->  spatial [N][(2)D][2H][2W][C]   (three_d = 0: D must be 1; inverse: spatial -> packed). */
+int fi_depth_to_space2x(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int three_d, int inverse,
+                        void* stream);
+/* GroupNorm(G, C) (+ optional ReLU) over dense channel-last samples [N][pixels][C] (networks/vnet.py:5-31 with
+ * normalization='groupnorm'; InstanceNorm is G = C without affine): statistics in fp64 per (sample, group), mean / invstd
+ * [N][G] saved for the backward.  bwd: dx, and dgamma / dbeta ATOMICALLY ADDED (either may be NULL); z is only read when
+ * relu != 0 (the ReLU mask).  C / G <= 256. */
+int fi_groupnorm_fwd(int dtype, const void* x, void* z, const float* gamma, const float* beta, float* mean, float* invstd,
+                     int N, long pixels, int C, int G, float eps, int relu, void* stream);
+int fi_groupnorm_bwd(int dtype, const void* dz, const void* x, const void* z, const float* gamma, const float* mean,
+                     const float* invstd, void* dx, float* dgamma, float* dbeta, int N, long pixels, int C, int G, int relu,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif
