@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -563,6 +563,10 @@ def groupnorm_bwd(dz, x, z, gamma, mean, invstd, dx, dgamma, dbeta, N, pixels, C
     _chk(lib().fi_groupnorm_bwd(dt(x.dtype), ptr(_dev(dz)), ptr(x), ptr(z), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                                 ptr(dgamma), ptr(dbeta), int(N), C.c_long(pixels), int(Cc), int(G), int(relu), stream()),
          "fi_groupnorm_bwd")
+
+
+def channel_stats(x, stats, pixels, Cc):
+    _chk(lib().fi_channel_stats(dt(x.dtype), ptr(_dev(x)), ptr(stats), C.c_long(pixels), int(Cc), stream()), "fi_channel_stats")
 
 
 def fedopt_step(mode, cur, agg, m, v, eta, beta1, beta2, tau):

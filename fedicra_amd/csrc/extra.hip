@@ -211,3 +211,50 @@ extern "C" int fi_groupnorm_bwd(int dtype, const void* dz, const void* x, const 
   FI_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ per-channel statistics
+// stats[slot][c][2] += (sum, sum of squares) of x[pix][c] -- the layout fi_bn_finalize / fi_bn_fused_fwd read.  The 2D path
+// gets these sums from the convolution epilogue; BatchNorm3d behind the depth-sliced 3D convolution (VNet with
+// normalization='batchnorm', networks/vnet.py:16-17) takes them from this pass over the finished volume.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, long pixels,
+                                                            int C) {
+  __shared__ double s1[256], s2[256];
+  const int R = 256 / C, c = threadIdx.x % C, pr = threadIdx.x / C;
+  double a = 0.0, b = 0.0;
+  if (pr < R) {
+    for (long p = (long)blockIdx.x * R + pr; p < pixels; p += (long)gridDim.x * R) {
+      const double v = (double)to_f32(x[p * C + c]);
+      a += v;
+      b += v * v;
+    }
+  }
+  s1[threadIdx.x] = a, s2[threadIdx.x] = b;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    for (int r = 1; r < R; ++r) a += s1[r * C + threadIdx.x], b += s2[r * C + threadIdx.x];
+    const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
+    atomicAdd(&stats[((size_t)slot * C + threadIdx.x) * 2 + 0], a);
+    atomicAdd(&stats[((size_t)slot * C + threadIdx.x) * 2 + 1], b);
+  }
+}
+
+extern "C" int fi_channel_stats(int dtype, const void* x, double* stats, long pixels, int C, void* stream) {
+  if (!x || !stats) return FI_ERR_NULL;
+  if (pixels < 1 || C < 1 || C > 256) return FI_ERR_SHAPE;
+  long blocks = (pixels * C + 256 * 64 - 1) / (256 * 64);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g((unsigned)blocks), b(256);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(channel_stats_kernel<float>, g, b, 0, st, (const float*)x, stats, pixels, C);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, stats, pixels, C);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(channel_stats_kernel<f16_t>, g, b, 0, st, (const f16_t*)x, stats, pixels, C);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}

@@ -112,9 +112,79 @@ class _GroupNorm(Function):
         L.groupnorm_bwd(dz, x, z, g32, mean, invstd, dx, dg, db, N, pixels, Cc, groups, relu)
         gg = _accumulate(gamma, dg) if dg is not None else None
         gb = _accumulate(beta, db) if db is not None else None
-        return dx, gg, gb, None, None, None
+        return dx, gg, gb, None, None, None        # (dg / db are None for tensors that do not require grad)
 
 
 def group_norm(x, mod, relu=False):
     """nn.GroupNorm(num_groups, C) on a dense channel-last tensor, optionally fused with the ReLU that follows it."""
     return _GroupNorm.apply(x, mod.weight, mod.bias, int(mod.num_groups), float(mod.eps), bool(relu))
+
+
+class _AffineAct(Function):
+    """BatchNorm (train or eval) or no normalisation at all, followed by ReLU, on a dense channel-last tensor of any rank:
+    the 2D path's BN kernels over the flattened pixels, with the batch statistics taken by fi_channel_stats."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn):
+        Cc = y.shape[-1]
+        dev = y.device
+        pix = y.numel() // Cc
+        y4 = y.reshape(1, 1, pix, Cc)
+        z = torch.empty_like(y4)
+        coef = torch.empty(4, Cc, dtype=torch.float32, device=dev)
+        if bn is None:                                      # identity affine: ReLU only
+            coef[0].fill_(1.0)
+            coef[1].zero_()
+            coef[2].zero_()
+            coef[3].fill_(1.0)
+            L.bn_act_fwd(y4, coef[0], coef[1], z, 0.0, None)
+            training = False
+        else:
+            training = bn.training
+            stats = None
+            if training:
+                stats = torch.zeros(L.STATS_SLOTS * Cc * 2, dtype=torch.float64, device=dev)
+                L.channel_stats(y4, stats, pix, Cc)
+            L.bn_fused_fwd(y4, z, stats, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                           bn.eps, training, coef, 0.0, None)
+        ctx.save_for_backward(y4, coef)
+        ctx.meta = (training, bn, gamma, beta, tuple(y.shape))
+        return z.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        y4, coef = ctx.saved_tensors
+        training, bn, gamma, beta, shape = ctx.meta
+        Cc = y4.shape[-1]
+        dz4 = dz.contiguous().reshape(y4.shape)
+        if dz4.dtype != y4.dtype:
+            dz4 = dz4.to(y4.dtype)
+        sums = torch.zeros(L.STATS_SLOTS * Cc * 2, dtype=torch.float64, device=y4.device)
+        if training:
+            L.bn_act_bwd_reduce(dz4, y4, coef[0], coef[1], coef[2], coef[3], sums, 0.0, None)
+        dy = torch.empty_like(y4)
+        dg = db = None
+        if bn is not None and training:
+            dg = torch.zeros(Cc, dtype=torch.float32, device=y4.device)
+            db = torch.zeros(Cc, dtype=torch.float32, device=y4.device)
+        L.bn_act_bwd_apply(dz4, y4, coef[0], coef[1], coef[2], coef[3], sums, training, dy, dg, db, 0.0, None)
+        gg = _accumulate(gamma, dg) if dg is not None and ctx.needs_input_grad[1] else None
+        gb = _accumulate(beta, db) if db is not None and ctx.needs_input_grad[2] else None
+        return dy.reshape(shape), gg, gb, None
+
+
+def norm_relu(y, norm):
+    """The `normalization` + ReLU tail of VNet's blocks (networks/vnet.py:15-24): `norm` is None ('none'), a BatchNorm3d,
+    a GroupNorm or an InstanceNorm3d module."""
+    import torch.nn as nn
+    if norm is None:
+        return _AffineAct.apply(y, None, None, None)
+    if isinstance(norm, nn.BatchNorm3d):
+        return _AffineAct.apply(y, norm.weight, norm.bias, norm)
+    if isinstance(norm, nn.GroupNorm):
+        return group_norm(y, norm, relu=True)
+    if isinstance(norm, nn.InstanceNorm3d):                 # affine=False, no running statistics (torch's defaults)
+        Cc = y.shape[-1]
+        one = torch.ones(Cc, dtype=torch.float32, device=y.device)
+        return _GroupNorm.apply(y, one, torch.zeros_like(one), Cc, float(norm.eps), True)
+    raise NotImplementedError(type(norm).__name__)

@@ -27,7 +27,8 @@ def _taps(ksize, D):
     """(kd, output slice range, input slice offset) for every depth tap; the centre tap last."""
     if ksize == 1:
         return [(0, 0, D, 0)]
-    return [(kd, max(0, 1 - kd), min(D, D + 1 - kd), kd - 1) for kd in (0, 2, 1)]
+    taps = [(kd, max(0, 1 - kd), min(D, D + 1 - kd), kd - 1) for kd in (0, 2, 1)]
+    return [t for t in taps if t[2] > t[1]]            # a depth-1 volume (VNet's 16^3 bottleneck) only has the centre tap
 
 
 def _w_taps(weight, dtype, mode):
@@ -157,24 +158,25 @@ class _Dropout(Function):
     (regenerated) mask to the gradient."""
 
     @staticmethod
-    def forward(ctx, x, p, owner):
+    def forward(ctx, x, p, owner, channel=False):
         C = x.shape[-1]
-        v = x.reshape(-1, 1, 1, C)
-        spec = ops._drop_spec(p, "elem", v.shape[0], 1, 1, C, x.device, owner=owner)
+        # channel = True: Dropout3d, one draw per (sample, channel) -- the per-sample view gives the kernel its sample index
+        v = x.reshape(x.shape[0], -1, 1, C) if channel else x.reshape(-1, 1, 1, C)
+        spec = ops._drop_spec(p, "chan" if channel else "elem", v.shape[0], v.shape[1], 1, C, x.device, owner=owner)
         one, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
         z = torch.empty_like(v)
         L.bn_act_fwd(v, one, zero, z, 1.0, spec)
-        ctx.spec, ctx.C = spec, C
+        ctx.spec, ctx.C, ctx.vshape = spec, C, tuple(v.shape)
         return z.reshape(x.shape)
 
     @staticmethod
     def backward(ctx, dz):
         C = ctx.C
-        v = dz.contiguous().reshape(-1, 1, 1, C)
+        v = dz.contiguous().reshape(ctx.vshape)
         one, zero = torch.ones(C, device=dz.device), torch.zeros(C, device=dz.device)
         out = torch.empty_like(v)
         L.bn_act_fwd(v, one, zero, out, 1.0, ctx.spec)
-        return out.reshape(dz.shape), None, None
+        return out.reshape(dz.shape), None, None, None
 
 
 def conv3d(x0, x1, conv, norm=False, y_f32=False):
@@ -193,7 +195,7 @@ def upsample3d2x(x):
     return _Upsample3d.apply(x)
 
 
-def dropout(x, p, training, owner=None):
+def dropout(x, p, training, owner=None, channel=False):
     if not training or p <= 0.0:
         return x
-    return _Dropout.apply(x, float(p), owner)
+    return _Dropout.apply(x, float(p), owner, bool(channel))

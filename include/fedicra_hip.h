@@ -374,6 +374,10 @@ int fi_depth_to_space2x(int dtype, const void* src, void* dst, int N, int D, int
  * normalization='groupnorm'; InstanceNorm is G = C without affine): statistics in fp64 per (sample, group), mean / invstd
  * [N][G] saved for the backward.  bwd: dx, and dgamma / dbeta ATOMICALLY ADDED (either may be NULL); z is only read when
  * relu != 0 (the ReLU mask).  C / G <= 256. */
+/* stats[slot][c][2] += per-channel (sum, sum of squares) of x [pixels][C] (C <= 256): the accumulator layout of
+ * fi_bn_finalize / fi_bn_fused_fwd, for a BatchNorm that does not sit behind a 2D convolution epilogue (BatchNorm3d of
+ * VNet, networks/vnet.py:16-17).  Caller zeroes stats. */
+int fi_channel_stats(int dtype, const void* x, double* stats, long pixels, int C, void* stream);
 int fi_groupnorm_fwd(int dtype, const void* x, void* z, const float* gamma, const float* beta, float* mean, float* invstd,
                      int N, long pixels, int C, int G, float eps, int relu, void* stream);
 int fi_groupnorm_bwd(int dtype, const void* dz, const void* x, const void* z, const float* gamma, const float* mean,

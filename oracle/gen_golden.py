@@ -361,12 +361,37 @@ def g11_augment():
     save("g11_augment.npz", **d)
 
 
+def g12_vnet():
+    """VNet (section 8-a18: Conv3d 3^3 / strided 2^3 / ConvTranspose3d 2^3, BatchNorm3d / GroupNorm(16) / InstanceNorm3d):
+    the reference's own module, train mode without dropout -- logits, loss, gradient checksums."""
+    from networks.vnet import VNet
+    rng = np.random.default_rng(12)
+    d = {}
+    # batchnorm: 6 samples -- with 2, the 1^3 bottleneck normalises over two values per channel (+-1, decided by round-off)
+    for nz, size, B in (("none", 16, 2), ("batchnorm", 16, 6), ("groupnorm", 16, 2), ("instancenorm", 32, 1)):
+        torch.manual_seed(21)
+        m = VNet(n_channels=1, n_classes=2, normalization=nz, has_dropout=False).train()
+        x = torch.from_numpy(rng.random((B, 1, size, size, size), dtype=np.float32))
+        y = torch.from_numpy(rng.integers(0, 2, (B, size, size, size))).long()
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        d[f"{nz}/x"], d[f"{nz}/y"] = x.numpy(), y.numpy().astype(np.uint8)
+        d[f"{nz}/logits"], d[f"{nz}/loss"] = out.detach().numpy(), np.array(loss.item())
+        for k, p_ in m.named_parameters():
+            d[f"{nz}/grad/{k}"] = checksum(p_.grad)
+        if nz == "batchnorm":
+            d[f"{nz}/running_mean0"] = m.block_one.conv[1].running_mean.numpy().copy()
+            d[f"{nz}/running_var0"] = m.block_one.conv[1].running_var.numpy().copy()
+    save("g12_vnet.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet"]
     for w in which:
         globals()[w]()

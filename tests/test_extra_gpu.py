@@ -122,3 +122,92 @@ def test_upblock_transposed_conv_branch():
     assert (got[0] - o2.detach().cpu()).abs().max().item() < 1e-4
     assert (got[1] - h1.grad).abs().max().item() < 1e-4 * max(1.0, h1.grad.abs().max().item())
     assert (got[2] - ref_t.weight.grad).abs().max().item() < 1e-4 * max(1.0, ref_t.weight.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("nz", ["none", "batchnorm", "groupnorm", "instancenorm"])
+def test_vnet_matches_reference_golden(golden, nz):
+    """VNet (a18) against the reference's own module (golden g12): same constructor + torch seed -> same initial state, then
+    train-mode logits, loss, every parameter gradient (checksums) and BatchNorm3d's running statistics."""
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from fedicra_amd.networks.vnet import VNet
+    from helpers import assert_ck
+    g = golden("g12_vnet.npz")
+    torch.manual_seed(21)
+    m = VNet(n_channels=1, n_classes=2, normalization=nz, has_dropout=False).cuda().train()
+    set_compute_dtype(m, "fp32")
+    x = torch.from_numpy(g[f"{nz}/x"]).to(DEV)
+    y = torch.from_numpy(g[f"{nz}/y"]).long().to(DEV)
+    out = m(x)
+    ref = torch.from_numpy(g[f"{nz}/logits"])
+    err = (out.detach().cpu() - ref).abs().max().item()
+    assert err < 3e-4 * max(1.0, ref.abs().max().item()), f"logits err {err:.3e}"
+    loss = F.cross_entropy(out.float(), y)
+    assert abs(loss.item() - float(g[f"{nz}/loss"])) < 2e-5
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        ck = g[f"{nz}/grad/{k}"]
+        if nz != "none" and k.endswith(".bias") and (".conv.0." in k or ".conv.3." in k or ".conv.6." in k) and "out_conv" not in k \
+                and nz in ("batchnorm", "groupnorm", "instancenorm") and p.dim() == 1 and k.split(".")[-2] in ("0", "3", "6"):
+            continue                    # conv bias in front of a normalisation: true gradient 0, round-off on both sides
+        # checksums of whole gradient tensors; ReLU'(0) round-off flips behind a normalisation move them by ~1e-3
+        # (DESIGN.md "parity bar"), logits and loss above are the tight checks
+        assert_ck(p.grad.double().cpu(), ck, rtol=1e-2, atol=2e-6, what=f"{nz} grad {k}")
+    if nz == "batchnorm":
+        bn = m.block_one.conv[1]
+        assert (bn.running_mean.cpu() - torch.from_numpy(g[f"{nz}/running_mean0"])).abs().max().item() < 1e-5
+        assert (bn.running_var.cpu() - torch.from_numpy(g[f"{nz}/running_var0"])).abs().max().item() < 1e-4
+        assert int(bn.num_batches_tracked) == 1
+
+
+def test_vnet_factory_dropout_and_bf16():
+    from fedicra_amd import ops
+    from fedicra_amd.networks.net_factory_3d import net_factory_3d
+    from fedicra_amd.networks.unet import set_compute_dtype
+    torch.manual_seed(1)
+    m = net_factory_3d("vnet", 1, 2).train()
+    assert m.has_dropout and isinstance(m.block_one.conv[1], torch.nn.BatchNorm3d)
+    set_compute_dtype(m, "bf16")
+    x = torch.rand(2, 1, 16, 16, 16, device=DEV)
+    ops.manual_seed(2)
+    a, b = m(x), m(x)
+    assert a.shape == (2, 2, 16, 16, 16) and a.dtype == torch.float32 and not torch.equal(a, b)     # Dropout3d(0.5) draws
+    assert torch.equal(m(x, turnoff_drop=True).isfinite().all(), torch.tensor(True, device=DEV))
+    a.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["batchnorm", "batchnorm_eval", "none", "instancenorm"])
+def test_norm_relu_tail_against_torch(kind, dtype):
+    """The `normalization` + ReLU tail of VNet's blocks on an NDHWC volume: BatchNorm3d (batch statistics from
+    fi_channel_stats, running statistics updated; eval mode), no normalisation, InstanceNorm3d."""
+    from fedicra_amd import extra_ops
+    N, C, sp = 2, 32, (3, 4, 5)
+    x = (rnd(N, C, *sp, seed=1, scale=2.0) + 0.3).to(dtype).float().requires_grad_(True)
+    mod = {"batchnorm": torch.nn.BatchNorm3d(C), "batchnorm_eval": torch.nn.BatchNorm3d(C), "none": None,
+           "instancenorm": torch.nn.InstanceNorm3d(C)}[kind]
+    if kind.startswith("batchnorm"):
+        with torch.no_grad():
+            mod.weight.copy_(rnd(C, seed=2) + 1.5)
+            mod.bias.copy_(rnd(C, seed=3))
+            mod.running_mean.copy_(rnd(C, seed=4))
+            mod.running_var.copy_(rnd(C, seed=5) + 1.5)
+        mod.train(kind == "batchnorm")
+    import copy
+    dmod = copy.deepcopy(mod).to(DEV) if mod is not None else None
+    z = F.relu(mod(x) if mod is not None else x)
+    g = rnd(*z.shape, seed=6).to(dtype).float()
+    z.backward(g)
+    xd = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV).requires_grad_(True)
+    zd = extra_ops.norm_relu(xd, dmod)
+    zd.backward(g.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV))
+    close(zd.detach().float().cpu().permute(0, 4, 1, 2, 3), z.detach(), dtype, "fwd")
+    close(xd.grad.float().cpu().permute(0, 4, 1, 2, 3), x.grad, dtype, "dx", 4.0)
+    if kind == "batchnorm":
+        close(dmod.weight.grad, mod.weight.grad, dtype, "dgamma", 4.0)
+        close(dmod.bias.grad, mod.bias.grad, dtype, "dbeta", 4.0)
+        assert torch.allclose(dmod.running_mean.cpu(), mod.running_mean, atol=1e-2 if dtype != torch.float32 else 1e-5)
+        assert torch.allclose(dmod.running_var.cpu(), mod.running_var, atol=2e-2 if dtype != torch.float32 else 1e-4)
+        assert int(dmod.num_batches_tracked) == 1

@@ -207,7 +207,7 @@ def test_unet3d_surface_keys_and_init_match_reference_golden(golden):
     for k, v in m.state_dict().items():
         assert_ck(v.double(), g["init_seed11/" + k], what=k)
     with pytest.raises(NotImplementedError):
-        net_factory_3d("vnet")
+        net_factory_3d("voxresnet")
 
 
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
