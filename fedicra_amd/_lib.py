@@ -24,7 +24,7 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_conv3d_fwd", "fi_conv3d_dgrad", "fi_conv3d_wgrad_workspace", "fi_conv3d_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -547,6 +547,42 @@ def scale(x, y, a, divide=False):
 
 def axpy(acc, x, a):
     _chk(lib().fi_axpy(ptr(_dev(acc)), ptr(x), C.c_long(x.numel()), C.c_float(a), stream()), "fi_axpy")
+
+
+def _taps_array(taps):
+    arr = (C.c_void_p * 3)()
+    for i, t in enumerate(taps):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def conv3d_fwd(x0, x1, w_taps, bias, y, stats, *, ksize, y_f32=False):
+    """x*: [N,D,H,W,C] dense; w_taps: packed 2D operands per depth tap; y zeroed by the caller; stats [N, slots*C*2] or None."""
+    N, D, H, W, c0 = _dev(x0).shape
+    c1 = 0 if x1 is None else x1.shape[4]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, y.shape[4], 0, 1, 0, int(y_f32))
+    stride = 0 if stats is None else stats.stride(0)
+    _chk(lib().fi_conv3d_fwd(C.byref(d), D, ptr(x0), ptr(x1), _taps_array(w_taps), ptr(bias), ptr(y), ptr(stats),
+                             C.c_long(stride), stream()), "fi_conv3d_fwd")
+
+
+def conv3d_dgrad(dy, wt_taps, d0, d1, *, ksize):
+    N, D, H, W, cout = _dev(dy).shape
+    d = FiConv(dt(dy.dtype), N, H, W, ksize, cout, 0, d0.shape[4], 0 if d1 is None else d1.shape[4], 1, 1, 0)
+    _chk(lib().fi_conv3d_dgrad(C.byref(d), D, ptr(dy), _taps_array(wt_taps), ptr(d0), ptr(d1), stream()), "fi_conv3d_dgrad")
+
+
+def conv3d_wgrad(x0, x1, dy, dw_taps, dbias, *, ksize):
+    N, D, H, W, c0 = _dev(x0).shape
+    c1 = 0 if x1 is None else x1.shape[4]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[4], 0, 0, 0, 0)
+    lib().fi_conv3d_wgrad_workspace.restype = C.c_long
+    nbytes = lib().fi_conv3d_wgrad_workspace(C.byref(d), D)
+    if nbytes < 0:
+        _chk(int(nbytes), "fi_conv3d_wgrad_workspace")
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x0.device)      # caller-owned workspace
+    _chk(lib().fi_conv3d_wgrad(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_taps), ptr(dbias), ptr(ws), C.c_long(nbytes),
+                               stream()), "fi_conv3d_wgrad")
 
 
 def depth_to_space2x(src, dst, N, D, H, W, Cc, three_d, inverse=False):

@@ -319,3 +319,106 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   FI_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// 3D convolution (3x3x3 pad 1, or 1x1x1) over dense NDHWC volumes: a volume is D consecutive NHWC slices, so depth tap kd
+// is ONE 2D implicit-GEMM launch over the slices it reaches, accumulating into the output volume.  The centre tap goes
+// last -- it covers every slice, so its epilogue sees the finished sums (bias, per-sample statistics).
+// d describes a slice batch: N = samples, H, W, ksize (in-plane = depth extent), channel split; D = depth.
+// ---------------------------------------------------------------------------------------------
+static inline size_t fi_esz(int dtype) { return dtype == FI_F32 ? 4 : 2; }
+struct FiTap { int t, lo, hi, off; };
+static int fi_taps(int ksize, int D, FiTap* taps) {
+  if (ksize == 1) {
+    taps[0] = FiTap{0, 0, D, 0};
+    return 1;
+  }
+  int n = 0;
+  const int order[3] = {0, 2, 1};
+  for (int i = 0; i < 3; ++i) {
+    const int kd = order[i], lo = kd == 0 ? 1 : 0, hi = D + 1 - kd < D ? D + 1 - kd : D;
+    if (hi > lo) taps[n++] = FiTap{kd, lo, hi, kd - 1};
+  }
+  return n;
+}
+
+extern "C" int fi_conv3d_fwd(const FiConv* d, int D, const void* x0, const void* x1, const void* const* w_taps,
+                             const float* bias, void* y, double* stats, long stats_stride, void* stream) {
+  if (!d || !x0 || !w_taps || !y) return FI_ERR_NULL;
+  if (D < 1 || d->co1 != 0 || (d->c1 > 0 && !x1)) return FI_ERR_SHAPE;
+  FiTap taps[3];
+  const int nt = fi_taps(d->ksize, D, taps);
+  const size_t es = fi_esz(d->dtype), ys = d->y_f32 ? 4 : es, plane = (size_t)d->H * d->W;
+  for (int n = 0; n < d->N; ++n)
+    for (int i = 0; i < nt; ++i) {
+      const FiTap& t = taps[i];
+      FiConv s = *d;
+      s.N = t.hi - t.lo;
+      s.accumulate0 = 1;
+      const size_t in0 = ((size_t)n * D + t.lo + t.off) * plane;
+      const char* p0 = (const char*)x0 + in0 * d->c0 * es;
+      const char* p1 = d->c1 ? (const char*)x1 + in0 * d->c1 * es : nullptr;
+      char* py = (char*)y + ((size_t)n * D + t.lo) * plane * d->co0 * ys;
+      const bool centre = t.off == 0;
+      const int rc = fi_conv2d_fwd(&s, p0, p1, w_taps[t.t], centre ? bias : nullptr, py, nullptr,
+                                   (stats && centre) ? stats + (size_t)n * stats_stride : nullptr, stream);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+// dgrad: d->c0 = channels of dy, d->co0 / co1 = channels of the (possibly concatenated) input; d0 / d1 accumulate
+extern "C" int fi_conv3d_dgrad(const FiConv* d, int D, const void* dy, const void* const* wt_taps, void* d0, void* d1,
+                               void* stream) {
+  if (!d || !dy || !wt_taps || !d0) return FI_ERR_NULL;
+  if (D < 1 || d->c1 != 0 || (d->co1 > 0 && !d1)) return FI_ERR_SHAPE;
+  FiTap taps[3];
+  const int nt = fi_taps(d->ksize, D, taps);
+  const size_t es = fi_esz(d->dtype), plane = (size_t)d->H * d->W;
+  for (int n = 0; n < d->N; ++n)
+    for (int i = 0; i < nt; ++i) {
+      const FiTap& t = taps[i];
+      FiConv s = *d;
+      s.N = t.hi - t.lo;
+      s.accumulate0 = s.accumulate1 = 1;
+      const char* pdy = (const char*)dy + ((size_t)n * D + t.lo) * plane * d->c0 * es;
+      const size_t out0 = ((size_t)n * D + t.lo + t.off) * plane;
+      char* p0 = (char*)d0 + out0 * d->co0 * es;
+      char* p1 = d->co1 ? (char*)d1 + out0 * d->co1 * es : nullptr;
+      const int rc = fi_conv2d_fwd(&s, pdy, nullptr, wt_taps[t.t], nullptr, p0, p1, nullptr, stream);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+extern "C" long fi_conv3d_wgrad_workspace(const FiConv* d, int D) {
+  if (!d || D < 1) return FI_ERR_SHAPE;
+  FiConv s = *d;
+  s.N = D;
+  return fi_conv2d_wgrad_workspace(&s);
+}
+
+// dw_taps: fp32 [kd][cout][k][k][cin] (one 2D filter gradient per depth tap), dbias fp32 [cout] or NULL; both ADDED to.
+extern "C" int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_taps,
+                               float* dbias, void* workspace, long workspace_bytes, void* stream) {
+  if (!d || !x0 || !dy || !dw_taps) return FI_ERR_NULL;
+  if (D < 1 || (d->c1 > 0 && !x1)) return FI_ERR_SHAPE;
+  FiTap taps[3];
+  const int nt = fi_taps(d->ksize, D, taps);
+  const size_t es = fi_esz(d->dtype), plane = (size_t)d->H * d->W;
+  const size_t n_dw = (size_t)d->co0 * d->ksize * d->ksize * (d->c0 + d->c1);
+  for (int n = 0; n < d->N; ++n)
+    for (int i = 0; i < nt; ++i) {
+      const FiTap& t = taps[i];
+      FiConv s = *d;
+      s.N = t.hi - t.lo;
+      const size_t in0 = ((size_t)n * D + t.lo + t.off) * plane;
+      const char* p0 = (const char*)x0 + in0 * d->c0 * es;
+      const char* p1 = d->c1 ? (const char*)x1 + in0 * d->c1 * es : nullptr;
+      const char* pdy = (const char*)dy + ((size_t)n * D + t.lo) * plane * d->co0 * es;
+      const int rc = fi_conv2d_wgrad(&s, p0, p1, pdy, dw_taps + (size_t)t.t * n_dw, t.off == 0 ? dbias : nullptr, workspace,
+                                     workspace_bytes, stream);
+      if (rc) return rc;
+    }
+  return 0;
+}

@@ -56,12 +56,9 @@ class _Conv3d(Function):
         ydt = torch.float32 if (y_f32 and not norm) else dt
         y = torch.zeros((N, D, H, W, cout), dtype=ydt, device=dev)
         stats = torch.zeros((N, L.STATS_SLOTS * cout * 2), dtype=torch.float64, device=dev) if norm else None
-        for n in range(N):
-            for t, lo, hi, off in _taps(kd, D):
-                centre = off == 0
-                L.conv2d_fwd(x0[n, lo + off:hi + off], None if x1 is None else x1[n, lo + off:hi + off], wp[t],
-                             bias if centre else None, y[n, lo:hi], None, stats[n] if (norm and centre) else None,
-                             ksize=ksize, acc0=True, y_f32=ydt == torch.float32 and dt != torch.float32)
+        # every (sample, depth tap) 2D launch is issued by ONE C-ABI call (fi_conv3d_fwd)
+        L.conv3d_fwd(x0.contiguous(), None if x1 is None else x1.contiguous(), wp, bias, y, stats, ksize=ksize,
+                     y_f32=ydt == torch.float32 and dt != torch.float32)
         if not norm:
             ctx.save_for_backward(x0, x1, weight)
             ctx.norm, ctx.has_bias = False, bias is not None
@@ -102,20 +99,13 @@ class _Conv3d(Function):
             wt = _w_taps(weight, dt, 1)
             d0 = torch.zeros_like(x0)
             d1 = None if x1 is None else torch.zeros_like(x1)
-            for n in range(N):
-                for t, lo, hi, off in taps:
-                    L.conv2d_fwd(dy[n, lo:hi], None, wt[t], None, d0[n, lo + off:hi + off],
-                                 None if d1 is None else d1[n, lo + off:hi + off], None, ksize=ksize, acc0=True,
-                                 acc1=True, tag="conv_dgrad")
+            L.conv3d_dgrad(dy.contiguous(), wt, d0, d1, ksize=ksize)
             dx0 = d0 if need_x0 else None
             dx1 = d1 if need_x1 else None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             gwk = torch.zeros((kd, cout, ksize, ksize, cin), dtype=torch.float32, device=dev)
             gb = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            for n in range(N):
-                for t, lo, hi, off in taps:
-                    L.conv2d_wgrad(x0[n, lo + off:hi + off], None if x1 is None else x1[n, lo + off:hi + off],
-                                   dy[n, lo:hi], gwk[t], gb if off == 0 else None, ksize=ksize)
+            L.conv3d_wgrad(x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous(), gwk, gb, ksize=ksize)
             gw = gwk.permute(1, 4, 0, 2, 3).contiguous()               # [Cout,Cin,kD,kH,kW]
         return dx0, dx1, gw, gb, None, None
 

@@ -85,6 +85,22 @@ long fi_conv2d_wgrad_workspace(const FiConv* d);
 int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
                     float* dbias, void* workspace, long workspace_bytes, void* stream);
 
+/* Conv3d (3x3x3 pad 1 or 1x1x1, stride 1; /root/reference/code/networks/utils.py:99-123, networks/vnet.py:15) over dense
+ * NDHWC volumes [N][D][H][W][C]: a volume is D consecutive NHWC slices, so depth tap kd is ONE 2D implicit-GEMM launch over
+ * the slices it reaches, accumulating into the output (the centre tap last: its epilogue adds the bias and yields the
+ * statistics).  `d` describes a slice batch (N = samples, H, W, ksize, channel split); w_taps[kd] are the packed 2D
+ * operands of the depth taps (fi_pack_weights of weight[:, :, kd]).
+ *   fwd  : y (caller ZEROES it) += conv; stats: per-SAMPLE accumulators, sample n at stats + n*stats_stride (InstanceNorm),
+ *          or stats_stride = 0 for batch statistics, or NULL.
+ *   dgrad: d->c0 = channels of dy, co0 / co1 = channels of the (concatenated) input; d0 / d1 (caller zeroes) += .
+ *   wgrad: dw_taps fp32 [kd][cout][k][k][cin] and dbias ADDED to; workspace >= fi_conv3d_wgrad_workspace(d, D) bytes. */
+int fi_conv3d_fwd(const FiConv* d, int D, const void* x0, const void* x1, const void* const* w_taps, const float* bias,
+                  void* y, double* stats, long stats_stride, void* stream);
+int fi_conv3d_dgrad(const FiConv* d, int D, const void* dy, const void* const* wt_taps, void* d0, void* d1, void* stream);
+long fi_conv3d_wgrad_workspace(const FiConv* d, int D);
+int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_taps, float* dbias,
+                    void* workspace, long workspace_bytes, void* stream);
+
 /* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
  * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of
  * fi_wgrad_reduce_multi over a device table (int64[n][FI_WGRAD_ROW]):
