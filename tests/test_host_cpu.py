@@ -254,3 +254,14 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
                              ctypes.c_float(1e-8), None, None) == 0                        # empty range: no-op
     assert lib.fi_wgrad_reduce_multi(None, 3, 10, None) == ERR_NULL
     assert lib.fi_wgrad_reduce_multi(p, 0, 0, None) == 0
+    # 3D entries: validated before the first depth-slice launch
+    taps = (ctypes.c_void_p * 3)(0x1000, 0x1000, 0x1000)
+    assert lib.fi_conv3d_fwd(ctypes.byref(ok), 4, None, None, taps, None, p, None, ctypes.c_long(0), None) == ERR_NULL
+    assert lib.fi_conv3d_fwd(ctypes.byref(ok), 0, p, None, taps, None, p, None, ctypes.c_long(0), None) == ERR_SHAPE
+    assert lib.fi_conv3d_fwd(ctypes.byref(FiConv(0, 1, 8, 8, 3, 16, 8, 16, 0, 0, 0, 0)), 4, p, None, taps, None, p, None,
+                             ctypes.c_long(0), None) == ERR_SHAPE                          # c1 > 0 without x1
+    assert lib.fi_conv3d_dgrad(ctypes.byref(FiConv(0, 1, 8, 8, 3, 16, 0, 8, 8, 1, 1, 0)), 4, p, taps, p, None, None) == ERR_SHAPE
+    lib.fi_conv3d_wgrad_workspace.restype = ctypes.c_long
+    assert lib.fi_conv3d_wgrad_workspace(ctypes.byref(ok), 4) >= lib.fi_conv2d_wgrad_workspace(ctypes.byref(ok))
+    assert lib.fi_conv3d_wgrad_workspace(ctypes.byref(ok), 0) == ERR_SHAPE
+    assert lib.fi_conv3d_wgrad(ctypes.byref(ok), 4, p, None, p, None, None, p, ctypes.c_long(1 << 20), None) == ERR_NULL
