@@ -24,7 +24,8 @@ EXPORTS = [
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
-    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_conv3d_fwd", "fi_conv3d_dgrad", "fi_conv3d_wgrad_workspace", "fi_conv3d_wgrad", "fi_adamw_hyper",
+    "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_conv3d_fwd", "fi_conv3d_dgrad", "fi_conv3d_wgrad_workspace", "fi_conv3d_wgrad", "fi_convtranspose2x_fwd", "fi_convtranspose2x_dgrad", "fi_convtranspose2x_wgrad_workspace",
+    "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
 ]
@@ -583,6 +584,27 @@ def conv3d_wgrad(x0, x1, dy, dw_taps, dbias, *, ksize):
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x0.device)      # caller-owned workspace
     _chk(lib().fi_conv3d_wgrad(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_taps), ptr(dbias), ptr(ws), C.c_long(nbytes),
                                stream()), "fi_conv3d_wgrad")
+
+
+def convtranspose2x_fwd(x, w_packed, bias_taps, packed, y, N, D, H, W, cin, cout, three_d):
+    _chk(lib().fi_convtranspose2x_fwd(dt(_dev(x).dtype), N, D, H, W, cin, cout, int(three_d), ptr(x), ptr(w_packed),
+                                      ptr(bias_taps), ptr(packed), ptr(y), stream()), "fi_convtranspose2x_fwd")
+
+
+def convtranspose2x_dgrad(dy, wt_packed, packed, dx, N, D, H, W, cin, cout, three_d):
+    _chk(lib().fi_convtranspose2x_dgrad(dt(_dev(dy).dtype), N, D, H, W, cin, cout, int(three_d), ptr(dy), ptr(wt_packed),
+                                        ptr(packed), ptr(dx), stream()), "fi_convtranspose2x_dgrad")
+
+
+def convtranspose2x_wgrad(x, dy_packed, dw, dbias_taps, N, D, H, W, cin, cout, three_d):
+    fn = lib().fi_convtranspose2x_wgrad_workspace
+    fn.restype = C.c_long
+    nbytes = fn(dt(_dev(x).dtype), N, D, H, W, cin, cout, int(three_d))
+    if nbytes < 0:
+        _chk(int(nbytes), "fi_convtranspose2x_wgrad_workspace")
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)      # caller-owned workspace
+    _chk(lib().fi_convtranspose2x_wgrad(dt(x.dtype), N, D, H, W, cin, cout, int(three_d), ptr(x), ptr(dy_packed), ptr(dw),
+                                        ptr(dbias_taps), ptr(ws), C.c_long(nbytes), stream()), "fi_convtranspose2x_wgrad")
 
 
 def depth_to_space2x(src, dst, N, D, H, W, Cc, three_d, inverse=False):

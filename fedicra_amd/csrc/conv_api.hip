@@ -422,3 +422,53 @@ extern "C" int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const voi
     }
   return 0;
 }
+
+// ---------------------------------------------------------------- ConvTranspose{2,3}d(kernel 2, stride 2) -----------
+// No overlapping taps: ONE 1x1 implicit GEMM to / from P*Cout packed channels ([tap][co]) + the depth-to-space shuffle.
+// `packed` is caller-owned scratch of N*D*H*W*P*Cout elements of `dtype`.
+static inline FiConv fi_ct_desc(int dtype, long slices, int H, int W, int cin, int cout) {
+  return FiConv{dtype, (int)slices, H, W, 1, cin, 0, cout, 0, 0, 0, 0};
+}
+static inline int fi_ct_check(int N, int D, int H, int W, int cin, int cout, int three_d) {
+  if (N < 1 || D < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || (!three_d && D != 1)) return FI_ERR_SHAPE;
+  if ((long)N * D > 0x7fffffffL) return FI_ERR_SHAPE;
+  return 0;
+}
+
+extern "C" int fi_convtranspose2x_fwd(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* x,
+                                      const void* w_packed, const float* bias_taps, void* packed, void* y, void* stream) {
+  if (!x || !w_packed || !packed || !y) return FI_ERR_NULL;
+  if (int rc = fi_ct_check(N, D, H, W, cin, cout, three_d)) return rc;
+  const int P = three_d ? 8 : 4;
+  const FiConv d = fi_ct_desc(dtype, (long)N * D, H, W, cin, P * cout);
+  if (int rc = fi_conv2d_fwd(&d, x, nullptr, w_packed, bias_taps, packed, nullptr, nullptr, stream)) return rc;
+  return fi_depth_to_space2x(dtype, packed, y, N, D, H, W, cout, three_d, 0, stream);
+}
+
+extern "C" int fi_convtranspose2x_dgrad(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* dy,
+                                        const void* wt_packed, void* packed, void* dx, void* stream) {
+  if (!dy || !packed) return FI_ERR_NULL;
+  if (int rc = fi_ct_check(N, D, H, W, cin, cout, three_d)) return rc;
+  const int P = three_d ? 8 : 4;
+  if (int rc = fi_depth_to_space2x(dtype, dy, packed, N, D, H, W, cout, three_d, 1, stream)) return rc;
+  if (!dx) return 0;                                   // only the packed gradient was wanted (input needs no gradient)
+  if (!wt_packed) return FI_ERR_NULL;
+  const FiConv d = fi_ct_desc(dtype, (long)N * D, H, W, P * cout, cin);
+  return fi_conv2d_fwd(&d, packed, nullptr, wt_packed, nullptr, dx, nullptr, nullptr, stream);
+}
+
+extern "C" long fi_convtranspose2x_wgrad_workspace(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d) {
+  if (int rc = fi_ct_check(N, D, H, W, cin, cout, three_d)) return rc;
+  const FiConv d = fi_ct_desc(dtype, (long)N * D, H, W, cin, (three_d ? 8 : 4) * cout);
+  return fi_conv2d_wgrad_workspace(&d);
+}
+
+// dy_packed: the packed gradient fi_convtranspose2x_dgrad left in `packed`; dw fp32 [P*Cout][Cin], dbias_taps fp32 [P*Cout]
+extern "C" int fi_convtranspose2x_wgrad(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* x,
+                                        const void* dy_packed, float* dw, float* dbias_taps, void* workspace,
+                                        long workspace_bytes, void* stream) {
+  if (!x || !dy_packed || !dw) return FI_ERR_NULL;
+  if (int rc = fi_ct_check(N, D, H, W, cin, cout, three_d)) return rc;
+  const FiConv d = fi_ct_desc(dtype, (long)N * D, H, W, cin, (three_d ? 8 : 4) * cout);
+  return fi_conv2d_wgrad(&d, x, nullptr, dy_packed, dw, dbias_taps, workspace, workspace_bytes, stream);
+}

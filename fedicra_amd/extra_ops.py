@@ -39,9 +39,8 @@ class _ConvTranspose2x(Function):
         b2 = None if bias is None else bias.detach().float().repeat(P).contiguous()
         x2 = x.reshape(N * D, H, W, cin)
         tmp = torch.empty((N * D, H, W, P * cout), dtype=dt, device=dev)
-        L.conv2d_fwd(x2, None, wp, b2, tmp, None, None, ksize=1)
         y = torch.empty((N, 2 * D, 2 * H, 2 * W, cout) if three_d else (N, 2 * H, 2 * W, cout), dtype=dt, device=dev)
-        L.depth_to_space2x(tmp, y, N, D, H, W, cout, three_d)
+        L.convtranspose2x_fwd(x2, wp, b2, tmp, y, N, D, H, W, cin, cout, three_d)
         ctx.save_for_backward(x2, w2)
         ctx.meta = (N, D, H, W, cin, cout, P, three_d, weight, bias, tuple(x.shape))
         return y
@@ -55,18 +54,19 @@ class _ConvTranspose2x(Function):
         if dy.dtype != dt:
             dy = dy.to(dt)
         dtmp = torch.empty((N * D, H, W, P * cout), dtype=dt, device=dev)
-        L.depth_to_space2x(dy, dtmp, N, D, H, W, cout, three_d, inverse=True)
         dx = gw = gb = None
+        wt = dx2 = None
         if ctx.needs_input_grad[0]:
             wt = torch.empty(P * cout * cin, dtype=dt, device=dev)
             L.pack_weights(w2.view(P * cout, 1, 1, cin), wt, P * cout, 1, cin, 1)       # dgrad operand of the 1x1 conv
             dx2 = torch.empty((N * D, H, W, cin), dtype=dt, device=dev)
-            L.conv2d_fwd(dtmp, None, wt, None, dx2, None, None, ksize=1)
+        L.convtranspose2x_dgrad(dy, wt, dtmp, dx2, N, D, H, W, cin, cout, three_d)     # un-shuffle (+ the dgrad GEMM)
+        if dx2 is not None:
             dx = dx2.reshape(xshape)
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
             dw = torch.zeros((P * cout, 1, 1, cin), dtype=torch.float32, device=dev)
             db = torch.zeros(P * cout, dtype=torch.float32, device=dev)
-            L.conv2d_wgrad(x2, None, dtmp, dw, db, ksize=1)
+            L.convtranspose2x_wgrad(x2, dtmp, dw, db, N, D, H, W, cin, cout, three_d)
             if ctx.needs_input_grad[1]:
                 g = dw.view((2, 2, 2, cout, cin) if three_d else (2, 2, cout, cin))
                 g = g.permute(4, 3, 0, 1, 2) if three_d else g.permute(3, 2, 0, 1)

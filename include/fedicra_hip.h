@@ -386,6 +386,21 @@ int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int C, int H,
  *   packed [N][D][H][W][P][C]  <->  spatial [N][(2)D][2H][2W][C]   (three_d = 0: D must be 1; inverse: spatial -> packed). */
 int fi_depth_to_space2x(int dtype, const void* src, void* dst, int N, int D, int H, int W, int C, int three_d, int inverse,
                         void* stream);
+/* The whole operator in one call each (replaces nn.ConvTranspose2d / ConvTranspose3d(k 2, s 2) forward and the two halves
+ * of its backward).  x [N][D][H][W][Cin], y / dy [N][(2)D][2H][2W][Cout]; `packed` = caller-owned scratch of
+ * N*D*H*W*P*Cout elements of `dtype`.  w_packed / wt_packed: fi_pack_weights (mode 0 / 1) of W'[(tap, co)][ci] =
+ * weight[ci][co][tap]; bias_taps fp32 [P*Cout] (the bias repeated per tap) or NULL.
+ *   dgrad: un-shuffles dy into `packed` (kept for the wgrad call) and, when dx != NULL, runs the 1x1 dgrad GEMM;
+ *   wgrad: dw fp32 [P*Cout][Cin] and dbias_taps fp32 [P*Cout] are ADDED to (caller zeroes; sum dbias over the taps);
+ *          workspace as for fi_conv2d_wgrad, size from fi_convtranspose2x_wgrad_workspace (< 0: FI_ERR_*). */
+int fi_convtranspose2x_fwd(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* x,
+                           const void* w_packed, const float* bias_taps, void* packed, void* y, void* stream);
+int fi_convtranspose2x_dgrad(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* dy,
+                             const void* wt_packed, void* packed, void* dx, void* stream);
+long fi_convtranspose2x_wgrad_workspace(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d);
+int fi_convtranspose2x_wgrad(int dtype, int N, int D, int H, int W, int cin, int cout, int three_d, const void* x,
+                             const void* dy_packed, float* dw, float* dbias_taps, void* workspace, long workspace_bytes,
+                             void* stream);
 /* GroupNorm(G, C) (+ optional ReLU) over dense channel-last samples [N][pixels][C] (networks/vnet.py:5-31 with
  * normalization='groupnorm'; InstanceNorm is G = C without affine): statistics in fp64 per (sample, group), mean / invstd
  * [N][G] saved for the backward.  bwd: dx, and dgamma / dbeta ATOMICALLY ADDED (either may be NULL); z is only read when

@@ -265,3 +265,11 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.fi_conv3d_wgrad_workspace(ctypes.byref(ok), 4) >= lib.fi_conv2d_wgrad_workspace(ctypes.byref(ok))
     assert lib.fi_conv3d_wgrad_workspace(ctypes.byref(ok), 0) == ERR_SHAPE
     assert lib.fi_conv3d_wgrad(ctypes.byref(ok), 4, p, None, p, None, None, p, ctypes.c_long(1 << 20), None) == ERR_NULL
+    # ConvTranspose(k 2, s 2) composites
+    assert lib.fi_convtranspose2x_fwd(0, 1, 1, 8, 8, 16, 16, 0, None, p, None, p, p, None) == ERR_NULL
+    assert lib.fi_convtranspose2x_fwd(0, 1, 2, 8, 8, 16, 16, 0, p, p, None, p, p, None) == ERR_SHAPE   # 2D with depth > 1
+    assert lib.fi_convtranspose2x_dgrad(0, 1, 1, 0, 8, 16, 16, 0, p, p, p, p, None) == ERR_SHAPE
+    lib.fi_convtranspose2x_wgrad_workspace.restype = ctypes.c_long
+    assert lib.fi_convtranspose2x_wgrad_workspace(0, 2, 4, 8, 8, 16, 8, 1) > 0
+    assert lib.fi_convtranspose2x_wgrad_workspace(0, 2, 4, 8, 8, 0, 8, 1) == ERR_SHAPE
+    assert lib.fi_convtranspose2x_wgrad(0, 1, 1, 8, 8, 16, 16, 0, p, p, None, None, p, ctypes.c_long(64), None) == ERR_NULL
