@@ -273,3 +273,33 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.fi_convtranspose2x_wgrad_workspace(0, 2, 4, 8, 8, 16, 8, 1) > 0
     assert lib.fi_convtranspose2x_wgrad_workspace(0, 2, 4, 8, 8, 0, 8, 1) == ERR_SHAPE
     assert lib.fi_convtranspose2x_wgrad(0, 1, 1, 8, 8, 16, 16, 0, p, p, None, None, p, ctypes.c_long(64), None) == ERR_NULL
+
+
+def test_header_is_plain_c_and_links_from_a_c_host(tmp_path):
+    """include/fedicra_hip.h compiles as C99 (-pedantic: no C++-isms cross the boundary) and a C
+    host links libfedicra_hip.so directly; the calls made here are host-side planning / validation only (no GPU)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "fedicra_hip.h"
+int main(void) {
+  FiConv d = { FI_BF16, 12, 256, 256, 3, 16, 0, 16, 0, 0, 0, 0 };
+  long ws = fi_conv2d_wgrad_workspace(&d);
+  long ws3 = fi_conv3d_wgrad_workspace(&d, 8);
+  int rc = fi_conv2d_fwd(&d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+  printf("%ld %ld %d\n", ws, ws3, rc);
+  return ws > 0 && ws3 >= ws && rc == FI_ERR_NULL ? 0 : 1;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.join(ROOT, "fedicra_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                         str(src), "-o", str(exe), "-L", libdir, "-lfedicra_hip", "-Wl,-rpath," + libdir,
+                         "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, (run.stdout, run.stderr)
