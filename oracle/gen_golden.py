@@ -386,12 +386,52 @@ def g12_vnet():
     save("g12_vnet.npz", **d)
 
 
+def g13_heads():
+    """The two head models without the LC encoder (section 8-a12: `unet_head`, `unet_multihead` -- the latter is what the
+    tree-energy procedure trains under FedAvg): the reference's own UNet_Head / UNet_MultiHead, eval forward (logits,
+    decoder features, auxiliary maps), a seeded train-mode forward (dropout RNG order) and the gradients of
+    CE(main) + sum CE(aux at its own scale) in eval mode (no dropout, running statistics: deterministic on every side)."""
+    from networks.unet import UNet_Head, UNet_MultiHead
+    img, weak, dense = phantom_batch(3, 64, 1, 2, cid=5)
+    x = torch.from_numpy(img).unsqueeze(1)
+    d = {"x": img, "dense": dense.astype(np.uint8)}
+    for tag, cls, seed, naux in (("head", UNet_Head, 2025, 1), ("multihead", UNet_MultiHead, 2026, 3)):
+        m = cls(1, 2)
+        seeded_state(m, seed)
+        d[f"{tag}/keys"] = np.array(list(m.state_dict().keys()))
+        m.eval()
+        o = m(x)
+        assert len(o) == 6 + naux
+        d[f"{tag}/eval_logits"] = o[0].detach().numpy()
+        for i in range(2, 6):
+            d[f"{tag}/eval_de{i-1}_ck"] = checksum(o[i])
+        for i in range(naux):
+            d[f"{tag}/eval_aux{i+1}"] = o[6 + i].detach().numpy()
+        y = torch.from_numpy(dense).long()
+        loss = torch.nn.functional.cross_entropy(o[0], y)
+        for i in range(naux):
+            a = o[6 + i]
+            step = y.shape[-1] // a.shape[-1]
+            loss = loss + torch.nn.functional.cross_entropy(a, y[:, ::step, ::step])
+        loss.backward()
+        d[f"{tag}/loss"] = np.array(loss.item())
+        for k, p_ in m.named_parameters():
+            d[f"{tag}/grad/{k}"] = checksum(p_.grad)
+        m.zero_grad()
+        m.train()
+        torch.manual_seed(13)
+        o = m(x)
+        d[f"{tag}/train_logits_seed13"] = o[0].detach().numpy()
+        d[f"{tag}/train_aux1_seed13"] = o[6].detach().numpy()
+    save("g13_heads.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads"]
     for w in which:
         globals()[w]()

@@ -611,3 +611,37 @@ def test_single_site_trainer_sgd_matches_torch_loop():
     w_ref = ref.state_dict()["decoder.out_conv.weight"]
     w_hip = net.state_dict()["decoder.out_conv.weight"].cpu()
     assert (w_hip - w_ref).abs().max().item() < 2e-3
+
+
+def test_head_models_match_reference_golden(golden):
+    """unet_head / unet_multihead against the reference's own UNet_Head / UNet_MultiHead (g13): state_dict
+    keys, eval logits / decoder features / auxiliary maps within 1e-4, and every parameter gradient of
+    CE(main) + sum CE(aux at its scale) in eval mode (running statistics, no dropout: deterministic on both sides)."""
+    from fedicra_amd.networks.unet import UNet_Head, UNet_MultiHead
+    from helpers import assert_ck
+    g = golden("g13_heads.npz")
+    x = torch.from_numpy(g["x"]).unsqueeze(1).to(DEV)
+    y = torch.from_numpy(g["dense"].astype(np.int64)).to(DEV)
+    for tag, cls, heads, seed in (("head", UNet_Head, 1, 2025), ("multihead", UNet_MultiHead, 3, 2026)):
+        m = _mk(cls, 1, 2, seed=seed).eval()
+        assert list(m.state_dict().keys()) == [str(k) for k in g[f"{tag}/keys"]]
+        o = m(x)
+        assert len(o) == 6 + heads
+        assert (o[0].detach().cpu() - torch.from_numpy(g[f"{tag}/eval_logits"])).abs().max().item() < 1e-4
+        for i in range(2, 6):
+            assert_ck(o[i].detach().float().cpu(), g[f"{tag}/eval_de{i-1}_ck"], rtol=2e-5, atol=1e-5, what=f"{tag} de{i-1}")
+        for i in range(heads):
+            ref = torch.from_numpy(g[f"{tag}/eval_aux{i+1}"])
+            assert o[6 + i].shape == ref.shape
+            assert (o[6 + i].detach().float().cpu() - ref).abs().max().item() < 1e-4
+        loss = torch.nn.functional.cross_entropy(o[0].float(), y)
+        for i in range(heads):
+            a = o[6 + i].float()
+            step = y.shape[-1] // a.shape[-1]
+            loss = loss + torch.nn.functional.cross_entropy(a, y[:, ::step, ::step])
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 2e-5
+        loss.backward()
+        from fedicra_amd import ops
+        ops.flush_wgrad()
+        for k, p in m.named_parameters():
+            assert_ck(p.grad.float().cpu(), g[f"{tag}/grad/{k}"], rtol=5e-3, atol=1e-6, what=f"{tag} grad {k}")
