@@ -426,12 +426,42 @@ def g13_heads():
     save("g13_heads.npz", **d)
 
 
+def g14_metric_aggregation():
+    """The strategy protocol's metric folds (section 8b-3): the reference's own get_evaluate_metrics_aggregation_fn /
+    fit_metrics_aggregation_fn on random per-client metric dicts (3 clients, 3 classes, unequal example counts)."""
+    import argparse
+    import flower_common as rfc
+    rng = np.random.default_rng(14)
+    names = ["dice", "hd95", "recall", "precision", "jc", "specificity", "ravd"]
+    args = argparse.Namespace(min_num_clients=3, num_classes=3)
+    counts = [7, 19, 4]
+    em, fm = [], []
+    for c, n in enumerate(counts):
+        m = {}
+        for nm in names:
+            for cls in (1, 2):
+                m[f"client_{c}_val_{cls}_{nm}"] = float(rng.random())
+            m[f"client_{c}_val_mean_{nm}"] = float(rng.random())
+        em.append((n, m))
+        fm.append((n, {f"client_{c}_total_loss": float(rng.random()), f"client_{c}_lr": float(rng.random())}))
+    out = rfc.get_evaluate_metrics_aggregation_fn(args, names)(em)
+    fout = rfc.fit_metrics_aggregation_fn(fm)
+    d = {"counts": np.array(counts), "names": np.array(names)}
+    for c, (n, m) in enumerate(em):
+        d[f"in{c}_keys"], d[f"in{c}_vals"] = np.array(list(m.keys())), np.array(list(m.values()))
+    for c, (n, m) in enumerate(fm):
+        d[f"fit{c}_keys"], d[f"fit{c}_vals"] = np.array(list(m.keys())), np.array(list(m.values()))
+    d["out_keys"], d["out_vals"] = np.array(list(out.keys())), np.array([float(v) for v in out.values()])
+    d["fit_out_keys"], d["fit_out_vals"] = np.array(list(fout.keys())), np.array([float(v) for v in fout.values()])
+    save("g14_metric_aggregation.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation"]
     for w in which:
         globals()[w]()

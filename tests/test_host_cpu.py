@@ -303,3 +303,21 @@ int main(void) {
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert run.returncode == 0, (run.stdout, run.stderr)
+
+
+def test_metric_aggregation_matches_reference_golden(golden):
+    """Strategy protocol: get_evaluate_metrics_aggregation_fn / fit_metrics_aggregation_fn give the same
+    keys, in the same order, with the same values as the reference's own functions (g14)."""
+    import argparse
+    from fedicra_amd.flower_common import fit_metrics_aggregation_fn, get_evaluate_metrics_aggregation_fn
+    g = golden("g14_metric_aggregation.npz")
+    counts = [int(n) for n in g["counts"]]
+    names = [str(n) for n in g["names"]]
+    em = [(counts[c], dict(zip(map(str, g[f"in{c}_keys"]), map(float, g[f"in{c}_vals"])))) for c in range(3)]
+    fm = [(counts[c], dict(zip(map(str, g[f"fit{c}_keys"]), map(float, g[f"fit{c}_vals"])))) for c in range(3)]
+    out = get_evaluate_metrics_aggregation_fn(argparse.Namespace(min_num_clients=3, num_classes=3), names)(em)
+    assert list(out.keys()) == [str(k) for k in g["out_keys"]]
+    np.testing.assert_allclose(np.array([float(v) for v in out.values()]), g["out_vals"], rtol=1e-15, atol=0)
+    fout = fit_metrics_aggregation_fn(fm)
+    assert list(fout.keys()) == [str(k) for k in g["fit_out_keys"]]
+    np.testing.assert_array_equal(np.array([float(v) for v in fout.values()]), g["fit_out_vals"])
