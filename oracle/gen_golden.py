@@ -456,12 +456,27 @@ def g14_metric_aggregation():
     save("g14_metric_aggregation.npz", **d)
 
 
+def g15_two_stream_sampler():
+    """dataloaders/dataset.py:254-300 TwoStreamBatchSampler under np.random.seed: two epochs of index batches."""
+    from dataloaders.dataset import TwoStreamBatchSampler
+    d = {}
+    for tag, (prim, sec, bs, sbs) in {"a": (list(range(23)), list(range(100, 107)), 6, 2),
+                                      "b": (list(range(8)), list(range(50, 53)), 4, 3)}.items():
+        np.random.seed(15)
+        smp = TwoStreamBatchSampler(prim, sec, bs, sbs)
+        ep = [np.array([list(map(int, b)) for b in smp]) for _ in range(2)]
+        d[f"{tag}/args"] = np.array([len(prim), sec[0], len(sec), bs, sbs])
+        d[f"{tag}/len"] = np.array(len(smp))
+        d[f"{tag}/epoch0"], d[f"{tag}/epoch1"] = ep
+    save("g15_two_stream_sampler.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler"]
     for w in which:
         globals()[w]()

@@ -169,3 +169,17 @@ def test_fedopt_strategies_follow_the_published_update_rules():
             assert float(out[1]) == float(cur[1])
     with pytest.raises(TypeError):
         get_strategy("FedAdam")
+
+
+def test_two_stream_batch_sampler_matches_reference_golden(golden):
+    """Same index batches as the reference's sampler under the same numpy seed, over two epochs (g15)."""
+    from fedicra_amd.dataloaders import TwoStreamBatchSampler
+    g = golden("g15_two_stream_sampler.npz")
+    for tag in ("a", "b"):
+        nprim, sec0, nsec, bs, sbs = (int(v) for v in g[f"{tag}/args"])
+        np.random.seed(15)
+        s = TwoStreamBatchSampler(list(range(nprim)), list(range(sec0, sec0 + nsec)), bs, sbs)
+        assert len(s) == int(g[f"{tag}/len"])
+        for e in range(2):
+            got = np.array([list(map(int, b)) for b in s])
+            np.testing.assert_array_equal(got, g[f"{tag}/epoch{e}"])
