@@ -471,12 +471,49 @@ def g15_two_stream_sampler():
     save("g15_two_stream_sampler.npz", **d)
 
 
+def g16_base_datasets():
+    """The reference's own BaseDataSets (dataset.py:63-183) over a dict-backed h5py on the release's directory layout:
+    per client the sample lists (as sets: os.listdir order is the file system's), and per sample name the arrays
+    __getitem__ returns for 'train' (label = sup_type) and 'val' (label = 'mask'), with and without the transform."""
+    import random
+    import tempfile
+    import h5py
+    from dataloaders.dataset import BaseDataSets, RandomGenerator
+    from oracle.dataset_tree import dataset_tree
+    store = {}
+
+    class File(dict):
+        def __init__(self, path, mode="r"):
+            super().__init__(store[os.path.normpath(path)])
+    h5py.File = File
+    d = {}
+    with tempfile.TemporaryDirectory() as root:
+        dataset_tree(root, store)
+        for client in ("client1", "client4", "client_all"):
+            for split in ("train", "val"):
+                ds = BaseDataSets(root, split, None, client, "scribble", "faz")
+                names = sorted(ds.sample_list)
+                d[f"{client}/{split}/names"] = np.array(names)
+                by = {n: ds[i] for i, n in enumerate(ds.sample_list)}
+                d[f"{client}/{split}/images"] = np.stack([by[n]["image"] for n in names])
+                d[f"{client}/{split}/labels"] = np.stack([by[n]["label"] for n in names])
+        ds = BaseDataSets(root, "train", RandomGenerator([16, 16], "faz"), "client2", "scribble", "faz")
+        order = np.argsort(ds.sample_list)
+        random.seed(16)
+        np.random.seed(16)
+        outs = [ds[int(i)] for i in order]
+        d["aug/names"] = np.array([ds.sample_list[int(i)] for i in order])
+        d["aug/images"] = np.stack([o["image"].numpy() for o in outs])
+        d["aug/labels"] = np.stack([o["label"].numpy() for o in outs])
+    save("g16_base_datasets.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets"]
     for w in which:
         globals()[w]()

@@ -183,3 +183,34 @@ def test_two_stream_batch_sampler_matches_reference_golden(golden):
         for e in range(2):
             got = np.array([list(map(int, b)) for b in s])
             np.testing.assert_array_equal(got, g[f"{tag}/epoch{e}"])
+
+
+def test_base_datasets_match_reference_golden(golden, tmp_path, monkeypatch):
+    """fedicra_amd.dataloaders.BaseDataSets over the same dict-backed tree the reference's own class was run on (g16):
+    sample lists per client, train label = sup_type / val label = 'mask' (the transform applied by __getitem__ is a
+    device launch: tests/test_data_gpu.py)."""
+    from fedicra_amd.dataloaders import BaseDataSets
+    from oracle.dataset_tree import dataset_tree
+    g = golden("g16_base_datasets.npz")
+    store = {}
+    dataset_tree(str(tmp_path), store)
+
+    class File(dict):
+        def __init__(self, path, mode="r"):
+            super().__init__(store[os.path.normpath(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    for client in ("client1", "client4", "client_all"):
+        for split in ("train", "val"):
+            ds = BaseDataSets(str(tmp_path), split, None, client, "scribble", "faz")
+            names = sorted(ds.sample_list)
+            assert names == [str(n) for n in g[f"{client}/{split}/names"]]
+            by = {n: ds[i] for i, n in enumerate(ds.sample_list)}
+            np.testing.assert_array_equal(np.stack([np.asarray(by[n]["image"]) for n in names]), g[f"{client}/{split}/images"])
+            np.testing.assert_array_equal(np.stack([np.asarray(by[n]["label"]) for n in names]), g[f"{client}/{split}/labels"])

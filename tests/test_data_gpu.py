@@ -442,3 +442,36 @@ def test_device_fedavg_equals_numpy_aggregate_bit_for_bit():
         got = aggregate_device([(DeviceWeights(w.to(DEV), c.to(DEV)), n_k[k]) for k, (w, c) in enumerate(zip(ws, cs))])
         assert torch.equal(got.state.cpu(), torch.from_numpy(want[0])), K
         assert got.counters.tolist() == [int(want[1]), int(want[2])]
+
+
+def test_base_datasets_getitem_with_transform_matches_reference_golden(golden, tmp_path, monkeypatch):
+    """BaseDataSets.__getitem__ with the RandomGenerator transform over the dict-backed release tree (g16: the reference's
+    own classes on the same tree under the same python / numpy seeds)."""
+    import os
+    import sys
+    import types
+    from fedicra_amd.dataloaders import BaseDataSets, RandomGenerator
+    from oracle.dataset_tree import dataset_tree
+    g = golden("g16_base_datasets.npz")
+    store = {}
+    dataset_tree(str(tmp_path), store)
+
+    class File(dict):
+        def __init__(self, path, mode="r"):
+            super().__init__(store[os.path.normpath(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    ds = BaseDataSets(str(tmp_path), "train", RandomGenerator([16, 16], "faz"), "client2", "scribble", "faz")
+    order = np.argsort(ds.sample_list)
+    assert [ds.sample_list[int(i)] for i in order] == [str(n) for n in g["aug/names"]]
+    random.seed(16)
+    np.random.seed(16)
+    outs = [ds[int(i)] for i in order]
+    np.testing.assert_array_equal(np.stack([o["image"].cpu().numpy() for o in outs]), g["aug/images"])
+    np.testing.assert_array_equal(np.stack([o["label"].cpu().numpy() for o in outs]), g["aug/labels"])
