@@ -508,12 +508,97 @@ def g16_base_datasets():
     save("g16_base_datasets.npz", **d)
 
 
+def _install_tree_kernels():
+    """The reference's Python glue (lib_tree_filter/modules/tree_filter.py, functions/*.py, the loss classes of
+    flower_common.py:646-818) calls five entry points of its CUDA extension `tree_filter_cuda`, which cannot be built
+    here.  For g17 ONLY, those five are served by the restated kernels of oracle/tree_ref.py (the MST by the reference's
+    own boruvka.cpp compiled into oracle/_ref), so that g17 pins everything ABOVE the extension boundary -- edge index /
+    weight construction, sorted gathers, exp(-d/sigma), the filter composition, ROI normalisation, autograd wiring --
+    against the reference's own code.  The kernels below that boundary stay 'restated, parity unpinned' (DESIGN 5)."""
+    import tree_filter_cuda as C
+    from oracle import tree_ref as T
+    assert T.have_reference_boruvka(), "build oracle/_ref first (python -c 'import __graft_entry__ as g; g.build()')"
+
+    def mst_forward(edge_index, edge_weight, vertex_count):
+        out = [T.mst_reference(edge_index[b].numpy(), edge_weight[b].numpy(), int(vertex_count))
+               for b in range(edge_index.shape[0])]
+        return torch.from_numpy(np.stack(out))
+
+    def bfs_forward(edge_index, max_adj):
+        si, sp, sc = [], [], []
+        for b in range(edge_index.shape[0]):
+            e = edge_index[b].numpy()
+            width = int(np.abs(e[:, 1] - e[:, 0]).max())          # vertical grid edges join v and v + W
+            a, p_, c, _ = T.bfs(e, e.shape[0] + 1, width)
+            si.append(a), sp.append(p_), sc.append(c)
+        return tuple(torch.from_numpy(np.stack(v)) for v in (si, sp, sc))
+
+    def _orders(sidx, spar, schild, b):
+        return sidx[b].numpy(), spar[b].numpy(), schild[b].numpy()
+
+    def refine_forward(feat, w, sidx, spar, schild):
+        r = [T.refine_forward(feat[b].numpy(), w[b].detach().numpy(), *_orders(sidx, spar, schild, b))
+             for b in range(feat.shape[0])]
+        return tuple(torch.from_numpy(np.stack([x[i] for x in r])) for i in range(5))
+
+    def refine_backward_feature(feat, w, sidx, spar, schild, out, aggr, aggr_up, wsum, wsum_up, gout):
+        return torch.from_numpy(np.stack([
+            T.refine_backward_feature(gout[b].contiguous().numpy(), w[b].numpy(), *_orders(sidx, spar, schild, b),
+                                      wsum[b].numpy()) for b in range(feat.shape[0])]))
+
+    def refine_backward_weight(feat, w, sidx, spar, schild, out, aggr, aggr_up, wsum, wsum_up, gout):
+        return torch.from_numpy(np.stack([
+            T.refine_backward_weight(gout[b].contiguous().numpy(), w[b].numpy(), *_orders(sidx, spar, schild, b),
+                                     out[b].numpy(), aggr[b].numpy(), aggr_up[b].numpy(), wsum[b].numpy(),
+                                     wsum_up[b].numpy()) for b in range(feat.shape[0])]))
+    C.mst_forward, C.bfs_forward, C.refine_forward = mst_forward, bfs_forward, refine_forward
+    C.refine_backward_feature, C.refine_backward_weight = refine_backward_feature, refine_backward_weight
+
+
+def g17_tree_glue():
+    """TreeEnergyLoss (low-level tree only, and low + one high-level tree) and MScaleRecurveTreeEnergyLoss of the reference
+    (flower_common.py:646-689, 756-818) over its own MinimumSpanningTree / TreeFilter2D modules, with the extension's
+    five kernels served as _install_tree_kernels says: losses, filtered maps and the gradients w.r.t. the logits and the
+    three head maps."""
+    _install_tree_kernels()
+    import flower_common as rfc
+    rng = np.random.default_rng(17)
+    B, S = 2, 16
+    img = rng.random((B, 1, S, S), dtype=np.float32)
+    roi = rng.random((B, S, S)) > 0.2
+    mk = lambda *shape: (rng.standard_normal(shape) * 0.7).astype(np.float32)
+    arrs = {"preds": mk(B, 2, S, S), "h1": mk(B, 2, S // 4, S // 4), "h2": mk(B, 2, S // 2, S // 2), "h3": mk(B, 2, S, S)}
+    d = {"image": img, "roi": roi, **arrs}
+
+    def leaves():
+        return {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in arrs.items()}
+    low = torch.from_numpy(img).repeat(1, 3, 1, 1)
+    unl = torch.from_numpy(roi)
+    t = leaves()
+    loss, AS = rfc.TreeEnergyLoss()(t["preds"], low, None, unl, 0.6)
+    loss.backward()
+    d["low/loss"], d["low/AS"], d["low/g_preds"] = np.array(loss.item()), AS.detach().numpy(), t["preds"].grad.numpy()
+    t = leaves()
+    loss, AS = rfc.TreeEnergyLoss()(t["preds"], low, t["h2"], unl, 0.6)
+    loss.backward()
+    d["high/loss"], d["high/AS"] = np.array(loss.item()), AS.detach().numpy()
+    d["high/g_preds"], d["high/g_h2"] = t["preds"].grad.numpy(), t["h2"].grad.numpy()
+    t = leaves()
+    loss, a1, a2, a3 = rfc.MScaleRecurveTreeEnergyLoss()(t["preds"], low, t["h1"], t["h2"], t["h3"], unl, 0.6)
+    loss.backward()
+    d["ms/loss"] = np.array(loss.item())
+    d["ms/AS1"], d["ms/AS2"], d["ms/AS3"] = a1.detach().numpy(), a2.detach().numpy(), a3.detach().numpy()
+    for k in arrs:
+        d[f"ms/g_{k}"] = t[k].grad.numpy()
+    save("g17_tree_glue.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue"]
     for w in which:
         globals()[w]()
