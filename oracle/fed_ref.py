@@ -185,3 +185,64 @@ def local_train(model: nn.Module, state: TrainState, batches: Sequence[dict], *,
             g["lr"] = lr_
         state.current_lr = lr_
     return hist[-1], {"loss": hist, "loss_ce": hist_ce, "loss_lc": hist_lc, "lr": state.current_lr}
+
+
+def local_train_ours(model: nn.Module, state: TrainState, batches: Sequence[dict], *, iters: int, num_classes: int,
+                     base_lr: float, max_iterations: int, tree_loss_weight: float, img_class: str = "faz",
+                     strategy: str = "FedAvg", rep_iters: int = 3, alpha: float = 0.5, cid: int = 0, num_clients: int = 1,
+                     lc_model: bool = False):
+    """MyClient._train of the README procedure (flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours.py:52-198):
+    loss = CE(ignore = num_classes) + MScaleRecurveTreeEnergyLoss(logits, image x3, aux1..3, label == num_classes, w)
+           + 0.1 * GatedCRF(softmax(logits), [{weight 1, xy 6, rgb 0.1}], radius 5, image)   [+ alpha * loss_lc]
+    with the pCE client's batch selection, freeze schedule, per-round AdamW and poly learning rate."""
+    from .gatedcrf_ref import gated_crf_loss
+    from .tree_ref import mscale_recurve_tree_energy_loss
+    model.train()                                                             # :53
+    opt = torch.optim.AdamW(model.parameters(), lr=state.current_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                            amsgrad=False)                                    # :56
+    hist = {"loss": [], "loss_ce": [], "loss_tree": [], "loss_crf": [], "loss_lc": []}
+    n_b = len(batches)
+    for i_iter in range(iters):
+        if state.current_iter % n_b == 0:                                     # :72-76
+            state.sampled_batches = list(batches)
+        b = state.sampled_batches[state.current_iter % n_b]
+        x, y = b["image"], b["label"]
+        if img_class == "faz":
+            x = x.unsqueeze(1)
+        if strategy == "FedICRA":                                             # :89-107
+            head_phase = i_iter < iters - rep_iters
+            for n, p in model.named_parameters():
+                p.requires_grad = (n in OUT_CONV) == head_phase
+        out = model(x)                                                        # :112-128
+        logits = out[0]
+        heatmaps, aux = (out[6], out[7:10]) if lc_model else (None, out[6:9])
+        soft = torch.softmax(logits, dim=1)
+        loss_ce = pce_loss(logits, y, num_classes)                            # :135
+        unlabeled = (y == num_classes)                                        # :136
+        three = x.repeat(1, 3, 1, 1) if img_class == "faz" else x             # :138-141
+        loss_tree = mscale_recurve_tree_energy_loss(logits, three, aux[0], aux[1], aux[2], unlabeled, tree_loss_weight)[0]
+        loss_crf = gated_crf_loss(soft, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, x)[0]       # :143-150
+        loss = loss_ce + loss_tree + 0.1 * loss_crf                           # :151
+        if strategy == "FedICRA":                                             # :153-163
+            acc = 0
+            for other in range(num_clients):
+                if other == cid:
+                    continue
+                with torch.no_grad():
+                    hm_o = model(x, other)[-4]
+                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], hm_o[-1].detach())
+            loss_lc = -acc / (num_clients - 1)
+            loss = torch.add(loss, loss_lc, alpha=alpha)
+            hist["loss_lc"].append(float(loss_lc.item()))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        state.current_iter += 1
+        for k, v in (("loss", loss), ("loss_ce", loss_ce), ("loss_tree", loss_tree), ("loss_crf", loss_crf)):
+            hist[k].append(float(v.item()))
+        lr_ = base_lr * (1.0 - state.current_iter / max_iterations) ** 0.9    # :180
+        for g in opt.param_groups:
+            g["lr"] = lr_
+        state.current_lr = lr_
+    hist["lr"] = state.current_lr
+    return hist["loss"][-1], hist

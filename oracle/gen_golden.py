@@ -593,12 +593,38 @@ def g17_tree_glue():
     save("g17_tree_glue.npz", **d)
 
 
+def g18_ours_train():
+    """The reference's own MyClient._train of the README procedure (flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours.py:
+    52-198: pCE + multi-scale tree energy + 0.1 x gated CRF), FedAvg, 'unet_multihead', 3 iterations at 32^2; the tree
+    extension's kernels served as in g17.  Per-iteration loss / loss_ce / loss_tree from its log lines, final state."""
+    _install_tree_kernels()
+    import flower_pCE_2D_GateCRFMsacleTreeEnergyLoss_Ours as ref
+    import flower_common as fc
+    logs = []
+    ref.log = lambda lvl, msg, *a: logs.append(msg)
+    args = _args(model="unet_multihead", iters=3, tree_loss_weight=0.1, img_size=32)
+    loader = _loader(2, 4, 32, cid=2)
+    net = ref.net_factory(args, net_type="unet_multihead", in_chns=1, class_num=2)
+    seeded_state(net, 2027)
+    client = ref.MyClient(args, fc.MyModel(args, net, loader, loader), loader, loader)
+    torch.manual_seed(2027)
+    last, metrics = client._train({"iter_global": 3, "iters": 3, "eval_iters": 6, "batch_size": 4, "stage": "fit"})
+    rows = [m for m in logs if "loss :" in m]
+    d = {"losses_6dp": np.array([float(m.split("loss : ")[1].split(",")[0]) for m in rows]),
+         "loss_ce_6dp": np.array([float(m.split("loss_ce: ")[1].split(",")[0]) for m in rows]),
+         "loss_tree_6dp": np.array([float(m.split("loss_tree: ")[1].split(",")[0]) for m in rows]),
+         "last_loss": np.float64(last), "lr_after": np.float64(client.current_lr)}
+    d.update(state_checksums(net, "state/"))
+    d["out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+    save("g18_ours_train.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue", "g18_ours_train"]
     for w in which:
         globals()[w]()
