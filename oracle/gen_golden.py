@@ -616,6 +616,28 @@ def g18_ours_train():
          "last_loss": np.float64(last), "lr_after": np.float64(client.current_lr)}
     d.update(state_checksums(net, "state/"))
     d["out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+    # the README's configuration: --model unet_lc_multihead --strategy FedICRA (freeze schedule + LC loss on top)
+    logs.clear()
+    K, cid = 3, 1
+    args = _args(strategy="FedICRA", model="unet_lc_multihead", cid=cid, min_num_clients=K, iters=3, rep_iters=1, alpha=1.0,
+                 tree_loss_weight=0.1, img_size=32)
+    loader = _loader(2, 4, 32, cid=cid)
+    net = ref.net_factory(args, net_type="unet_lc_multihead", in_chns=1, class_num=2)
+    seeded_state(net, 2028, extra=ref_pcs_extra(net))
+    class PassThrough(fc.MyModel):                  # MyModel.forward as shipped drops emb_idx (cf. g5); a wrapper OUTSIDE
+        def forward(self, x, emb_idx=None):         # the reference hands it through so that :153-163 run unchanged
+            return self.model(x, emb_idx)
+    client = ref.MyClient(args, PassThrough(args, net, loader, loader), loader, loader)
+    torch.manual_seed(2028)
+    last, metrics = client._train({"iter_global": 60, "iters": 3, "eval_iters": 6, "batch_size": 4, "stage": "fit"})
+    rows = [m for m in logs if "loss :" in m]
+    d.update({"icra/losses_6dp": np.array([float(m.split("loss : ")[1].split(",")[0]) for m in rows]),
+              "icra/loss_ce_6dp": np.array([float(m.split("loss_ce: ")[1].split(",")[0]) for m in rows]),
+              "icra/loss_tree_6dp": np.array([float(m.split("loss_tree: ")[1].split(",")[0]) for m in rows]),
+              "icra/last_loss": np.float64(last),
+              "icra/loss_lc_last": np.float64(metrics.get(f"client_{cid}_loss_lc", np.nan))})
+    d["icra/out_conv_weight"] = net.state_dict()["decoder.out_conv.weight"].numpy().copy()
+    d["icra/running_mean0"] = net.state_dict()["encoder.in_conv.conv_conv.1.running_mean"].numpy().copy()
     save("g18_ours_train.npz", **d)
 
 
