@@ -4,7 +4,7 @@
 Volumes are dense NDHWC tensors ``[N, D, H, W, C]`` in the compute dtype, i.e. D consecutive NHWC slices, so the 2D
 kernels of libfedicra_hip.so do the heavy lifting:
 
-* ``Conv3d(3x3x3, pad 1)`` = for each depth tap kd one 3x3 implicit-GEMM launch over the slices that tap reaches,
+* ``Conv3d(3x3x3, pad 1)`` (fi_conv3d_fwd / dgrad / wgrad) = for each depth tap kd one 3x3 implicit-GEMM launch over the slices that tap reaches,
   accumulating into the output volume (the centre tap goes last: it covers every slice, so its epilogue sees the
   finished sums and produces the per-channel statistics);
 * ``InstanceNorm3d(affine=False) + ReLU`` = the fused BN-finalize/apply kernel run per sample (batch statistics of
@@ -21,14 +21,6 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import ops
-
-
-def _taps(ksize, D):
-    """(kd, output slice range, input slice offset) for every depth tap; the centre tap last."""
-    if ksize == 1:
-        return [(0, 0, D, 0)]
-    taps = [(kd, max(0, 1 - kd), min(D, D + 1 - kd), kd - 1) for kd in (0, 2, 1)]
-    return [t for t in taps if t[2] > t[1]]            # a depth-1 volume (VNet's 16^3 bottleneck) only has the centre tap
 
 
 def _w_taps(weight, dtype, mode):
@@ -94,7 +86,6 @@ class _Conv3d(Function):
             dy = dz if dz.dtype == dt else dz.to(dt)
         need_x0, need_x1 = ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1]
         dx0 = dx1 = gw = gb = None
-        taps = _taps(kd, D)
         if need_x0 or need_x1:
             wt = _w_taps(weight, dt, 1)
             d0 = torch.zeros_like(x0)
