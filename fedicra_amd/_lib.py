@@ -157,10 +157,13 @@ class KernelProfile:
 _prof = None
 
 
-def profile_begin():
+def profile_begin(subtract_overhead=True):
+    """subtract_overhead=False: raw event intervals (what bench.py's roofline object reports, so that it can be checked
+    against a rocprofv3 kernel trace without any correction)."""
     global _prof
     p = KernelProfile()
-    p.calibrate()
+    if subtract_overhead:
+        p.calibrate()
     _prof = p
     return _prof
 

@@ -27,7 +27,9 @@ from .flower_common import DeviceWeights
 
 
 class WeightedAllReduce:
-    def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None):
+    def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None, constant_term=None):
+        """`constant_term` = (DeviceWeights, n): a fixed contribution n * state to the weighted sum, added by rank 0 --
+        clients of the federation that no rank hosts (bench.py with fewer GPUs than clients)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -44,6 +46,12 @@ class WeightedAllReduce:
         else:
             self.all_n = [self.n_k]
         self.total = sum(self.all_n)
+        self.constant = None
+        if constant_term is not None:
+            cw, cn = constant_term
+            self.total += int(cn)
+            if self.rank == 0:
+                self.constant = (cw, int(cn))
         self.side = torch.cuda.Stream(device=device) if self.on_gpu else None
         self._send = None
         self._cnt = None
@@ -68,6 +76,9 @@ class WeightedAllReduce:
                 for w, n in zip(many[1:], self.n_local[1:]):          # acc + w_k * n_k, left to right (numpy's order)
                     L.axpy(self._send, w.state, float(n))
                     self._cnt.add_(w.counters, alpha=n)
+                if self.constant is not None:
+                    L.axpy(self._send, self.constant[0].state, float(self.constant[1]))
+                    self._cnt.add_(self.constant[0].counters, alpha=self.constant[1])
                 if self.world > 1:
                     dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                     dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
@@ -80,6 +91,9 @@ class WeightedAllReduce:
             for w, n in zip(many[1:], self.n_local[1:]):
                 self._send.add_(w.state * float(n))
                 self._cnt.add_(w.counters, alpha=n)
+            if self.constant is not None:
+                self._send.add_(self.constant[0].state * float(self.constant[1]))
+                self._cnt.add_(self.constant[0].counters, alpha=self.constant[1])
             if self.world > 1:
                 dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)

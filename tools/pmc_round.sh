@@ -1,13 +1,13 @@
 #!/bin/bash
 # HBM traffic per kernel family for the round (two PMC passes; counters only, no other trace domains).
-# Run on the GPU box from the repo root: bash tools/pmc_round.sh r01_e
-TAG=${1:-r01_e}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+# Run on the GPU box from the repo root: bash tools/pmc_round.sh r02_a
+TAG=${1:-r02_a}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+ARGS="--gpus 1 --steps 4 --warmup 4 --round-iters 4 --loader-batches 2 --no-graph --no-cpu-baseline --no-roofline --no-fp32"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- python $ROOT/bench.py --steps 4 --warmup 2 --no-graph \
-      --no-cpu-baseline --no-roofline --clients-per-gpu 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- python $ROOT/bench.py $ARGS > /tmp/pmc_$c.log 2>&1
 done
 python $ROOT/tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1) \
-    > $OUT/${TAG}_pmc_traffic.json
-head -c 900 $OUT/${TAG}_pmc_traffic.json
+    "$ARGS" > $OUT/${TAG}_pmc_traffic.json
+head -c 1500 $OUT/${TAG}_pmc_traffic.json

@@ -2,7 +2,7 @@
 """HBM bytes per launch and kernel family from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as
 MI355X_MICROARCH.md prescribes).  Both counters are in KB; FETCH_SIZE is doubled on gfx950 (tools/pmc_cal.py: a 512 MiB
 coalesced read reports 262200 KB), WRITE_SIZE is taken as reported.
-    pmc_traffic.py fetch_results.db write_results.db > profiles/<tag>_pmc_traffic.json"""
+    pmc_traffic.py fetch_results.db write_results.db ["bench args" [workload_key]] > profiles/<tag>_pmc_traffic.json"""
 import json
 import sqlite3
 import sys
@@ -38,11 +38,11 @@ def collect(path, counter):
     return acc
 
 
-def main(fetch_db, write_db):
+def main(fetch_db, write_db, bench_args="", key="c3-unet_lc-12x3x512-bf16"):
     rd, wr = collect(fetch_db, "FETCH_SIZE"), collect(write_db, "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
-                     "--steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --clients-per-gpu 1; 1x MI355X, bf16, "
-                     "12x1x256x256 (tools/pmc_round.sh)",
+                     + bench_args + "; 1x MI355X (tools/pmc_round.sh)",
+           "workload_key": key,
            "corrections": "FETCH_SIZE (KB) doubled on gfx950 (tools/pmc_cal.py calibration, MI355X_MICROARCH.md); "
                           "WRITE_SIZE (KB) as reported",
            "families": {}}
@@ -56,4 +56,4 @@ def main(fetch_db, write_db):
     json.dump(out, sys.stdout, indent=1)
 
 
-main(sys.argv[1], sys.argv[2])
+main(*sys.argv[1:])

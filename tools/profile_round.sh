@@ -1,16 +1,12 @@
 #!/bin/bash
-# Round profile: bench lines (co-located default, single client, fp32) + rocprofv3 kernel summaries.  Run on the GPU box
-# from the repo root: bash tools/profile_round.sh r01_e ; results land in gpurun_out/<tag>_*
-TAG=${1:-r01_e}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
-python bench.py > $OUT/${TAG}_bench_bf16.json 2> $OUT/${TAG}_bench_bf16.err
-python bench.py --clients-per-gpu 1 > $OUT/${TAG}_bench_bf16_1client.json 2>> $OUT/${TAG}_bench_bf16.err
-python bench.py --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench_bf16.err
+# Round profile: the driver's bench line + a rocprofv3 kernel summary of the same command.  Run on the GPU box from the
+# repo root: bash tools/profile_round.sh r02_a ; results land in gpurun_out/<tag>_*
+TAG=${1:-r02_a}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+FEDICRA_BENCH_VERBOSE=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
-for c in 2 1; do
-  rm -rf /tmp/prof_$c
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -- python $ROOT/bench.py --clients-per-gpu $c --no-cpu-baseline \
-      > /tmp/prof_$c.log 2>&1
-  DB=$(find /tmp/prof_$c -name "*.db" | head -1)
-  python $ROOT/tools/rocpd_summary.py $DB > $OUT/${TAG}_bench_bf16_${c}client_kernel_stats.csv
-done
-tail -c 600 $OUT/${TAG}_bench_bf16.json; echo; tail -c 300 $OUT/${TAG}_bench_bf16.err
+rm -rf /tmp/prof_k
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline \
+    --no-fp32 > /tmp/prof_k.log 2>&1
+DB=$(find /tmp/prof_k -name "*.db" | head -1)
+python $ROOT/tools/rocpd_summary.py $DB > $OUT/${TAG}_bench_kernel_stats.csv
+tail -c 1500 $OUT/${TAG}_bench.json; echo; tail -c 300 $OUT/${TAG}_bench.err; head -30 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-220
