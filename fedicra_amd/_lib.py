@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -35,6 +35,12 @@ class FiConv(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
                 ("c0", C.c_int), ("c1", C.c_int), ("co0", C.c_int), ("co1", C.c_int), ("accumulate0", C.c_int),
                 ("accumulate1", C.c_int), ("y_f32", C.c_int)]
+
+
+class FiInXform(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("pool", C.c_int),
+                ("drop_mode", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64), ("seed_group_stride", C.c_uint64),
+                ("seed_offset", C.c_void_p)]
 
 
 class FiBnAct(C.Structure):
@@ -232,6 +238,53 @@ def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False,
                 px * cin * _esz(x0) + (0 if y0 is None else px * cout * _esz(y0)) + cin * cout * ksize * ksize * _esz(x0)):
         _chk(lib().fi_conv2d_fwd(C.byref(d), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y0), ptr(y1), ptr(stats),
                                  stream()), "fi_conv2d_fwd")
+
+
+def in_xform(coef, slope, *, pool=False, drop=None, seed_group_stride=0):
+    """FiInXform for a source that holds a raw conv output: coef = fp32 [2][G][C] from bn_finalize_groups (None: the source
+    is used as it is); drop = (mode, p, seed, mask, seed_offset) as ops._drop_spec returns it (RNG element mode only)."""
+    if coef is None:
+        return None
+    G, Cc = coef.shape[1], coef.shape[2]
+    mode, p, seed, mask, soff = drop if drop is not None else (DROP_NONE, 0.0, 0, None, None)
+    if mode not in (DROP_NONE, DROP_RNG_ELEM) or mask is not None:
+        raise FiError("the fused forward draws its dropout masks on the device (RNG element mode only)")
+    t = FiInXform(coef.data_ptr(), coef[1].data_ptr(), float(slope), int(pool), mode, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                  seed_group_stride & 0xFFFFFFFFFFFFFFFF, None if soff is None else soff.data_ptr())
+    t._keep = (coef, soff)
+    return t
+
+
+def conv2d_fwd_fused(x0, t0, x1, t1, w, bias, y, stats, *, ksize, groups, cout=None, shared0=False, tag="conv_fwd"):
+    """fi_conv2d_fwd_fused: x* dense NHWC (source 0 at twice the resolution when t0.pool; holding ONE group's images when
+    shared0); stats fp64 [G][SLOTS][Cout][2] (or None); y None = statistics-only launch."""
+    _dev(x0)
+    N, H, W, c0 = x0.shape
+    if shared0:
+        N *= groups
+    if t0 is not None and t0.pool:
+        H, W = H // 2, W // 2
+    c1 = 0 if x1 is None else x1.shape[3]
+    co = int(cout) if y is None else y.shape[3]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, co, 0, 0, 0, 0)
+    cin, px = c0 + c1, N * H * W
+    gi = N // groups
+    with _timed(tag, (str(x0.dtype)[6:], N, H, W, cin, co, ksize, "fused"), 2.0 * px * cin * co * ksize * ksize,
+                x0.numel() * _esz(x0) + (0 if x1 is None else x1.numel() * _esz(x1)) + (0 if y is None else px * co * _esz(y))
+                + cin * co * ksize * ksize * _esz(x0)):
+        _chk(lib().fi_conv2d_fwd_fused(C.byref(d), None if t0 is None else C.byref(t0), None if t1 is None else C.byref(t1),
+                                       int(gi), int(bool(shared0)), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y), ptr(stats),
+                                       C.c_long(0 if stats is None else stats.numel() // groups), stream()),
+             "fi_conv2d_fwd_fused")
+
+
+def bn_finalize_groups(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, shared=False):
+    """stats fp64 [G][SLOTS][C][2] (shared: ONE accumulator set every group reads) -> coef fp32 [2][G][C]; running
+    statistics moved G times in group order."""
+    _chk(lib().fi_bn_finalize_groups(ptr(_dev(stats)), C.c_long(0 if shared else stats.numel() // groups), int(groups),
+                                     C.c_double(count),
+                                     ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(nbt), C.c_float(momentum),
+                                     C.c_float(eps), ptr(coef), gamma.numel(), stream()), "fi_bn_finalize_groups")
 
 
 def conv2d_wgrad(x0, x1, dy, dw, dbias, *, ksize, deterministic=True):

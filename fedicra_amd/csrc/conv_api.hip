@@ -23,6 +23,7 @@ int fi_conv_wgrad_quad_f16_k3(int th, const WgradArgs& a, hipStream_t st);
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
 #include <cstdlib>
+#include <cstring>
 // tuning knobs (read once): FI_MIN_BLOCKS = workgroups a launch should reach before the tile height stops
 // shrinking; FI_WGRAD_BLOCKS = total workgroups of a wgrad launch (each spatial slice costs |dw| of workspace).
 #ifdef FI_TRACE
@@ -54,8 +55,50 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
   return 4;
 }
 
+static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
+                         const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
+                         double* stats, long stats_group_stride, void* stream);
+
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
+  return conv_fwd_impl(d, nullptr, nullptr, 0, 0, x0, x1, w, bias, y0, y1, stats, 0, stream);
+}
+
+extern "C" int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
+                                   const void* x0, const void* x1, const void* w, const float* bias, void* y,
+                                   double* stats, long stats_group_stride, void* stream) {
+  if (!d) return FI_ERR_NULL;
+  if (d->co1 != 0 || d->accumulate0 || d->accumulate1 || d->y_f32) return FI_ERR_UNSUPPORTED;
+  if (group_images < 0 || (group_images > 0 && d->N % group_images)) return FI_ERR_SHAPE;
+  if (flags & ~FI_FUSED_SHARED_SOURCE0) return FI_ERR_UNSUPPORTED;
+  if ((flags & FI_FUSED_SHARED_SOURCE0) && (group_images < 1 || !t0)) return FI_ERR_SHAPE;
+  return conv_fwd_impl(d, t0, t1, group_images, flags, x0, x1, w, bias, y, nullptr, stats, stats_group_stride, stream);
+}
+
+static int fill_xform(const FiInXform* t, InXform* o, int is_second) {
+  memset(o, 0, sizeof(*o));
+  o->slope = 1.f;
+  if (!t) return 0;
+  if ((t->scale == nullptr) != (t->shift == nullptr)) return FI_ERR_NULL;
+  if (t->drop_p > 0.f && t->drop_mode != FI_DROP_NONE) {
+    if (t->drop_mode != FI_DROP_RNG_ELEM || is_second || t->pool || !t->scale) return FI_ERR_UNSUPPORTED;
+    o->drop_mode = FI_DROP_RNG_ELEM;
+    const double th = (double)t->drop_p * 4294967296.0;          // as fi_bn_act_fwd (ops.hip make_drop)
+    o->thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    o->keep_scale = t->drop_p < 1.f ? 1.0f / (float)(1.0 - (double)t->drop_p) : 0.f;
+    o->seed = t->seed;
+    o->seed_gstride = t->seed_group_stride;
+    o->seed_offset = t->seed_offset;
+  }
+  o->scale = t->scale;
+  o->shift = t->shift;
+  o->slope = t->slope;
+  return 0;
+}
+
+static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
+                         const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
+                         double* stats, long stats_group_stride, void* stream) {
   if (!d || !x0 || !w) return FI_ERR_NULL;
   if (!y0 && (!stats || y1)) return FI_ERR_NULL;          // y0 == NULL: statistics-only launch (nothing is stored)
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
@@ -108,6 +151,20 @@ extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, co
     if (nf <= 2 && ck * 2 == big && cin >= 2 * big && d->c0 % big == 0 && d->c1 % big == 0 && lds <= lds_cap) ck = big;
   }
   ConvArgs a;
+  if (int rc = fill_xform(t0, &a.t0, 0)) return rc;
+  if (int rc = fill_xform(t1, &a.t1, 1)) return rc;
+  a.xf = 0;
+  if (t0 || t1) {
+    const int vg = f32 ? 4 : 8;
+    if (ck <= vg) return FI_ERR_UNSUPPORTED;              // whole-vector channel counts only (host mirror checks)
+    const bool pool = t0 && t0->pool;
+    if (t1 && t1->pool) return FI_ERR_UNSUPPORTED;
+    if (pool && (d->c1 != 0 || d->ksize != 3)) return FI_ERR_UNSUPPORTED;
+    a.xf = pool ? 2 : 1;
+  }
+  a.bcast0 = (flags & FI_FUSED_SHARED_SOURCE0) ? 1 : 0;
+  a.gimages = group_images;
+  a.stats_gstride = stats_group_stride;
   a.x0 = x0;
   a.x1 = x1 ? x1 : x0;
   a.w = w;

@@ -19,7 +19,28 @@
 
 #include "common.h"
 
+// Input transform applied by the loader of the fused ("probe") forward: the source holds the RAW output y of the
+// producing convolution and the consumer evaluates z = dropout(act(scale[c] * y + shift[c])) -- BatchNorm apply,
+// LeakyReLU / ReLU and element-wise dropout -- while it stages the tile, optionally followed by the 2x2 max-pool of a
+// DownBlock (the source is then [N][2H][2W][C]).  z is rounded to the storage dtype exactly as fi_bn_act_fwd rounds it,
+// so the fused forward reproduces the unfused one bit for bit.  scale == NULL: the source is used as it is.
+struct InXform {
+  const float* scale;        // [groups][C] or NULL
+  const float* shift;        // [groups][C]
+  float slope;
+  int drop_mode;             // FI_DROP_NONE or FI_DROP_RNG_ELEM (source 0 only)
+  uint32_t thresh;
+  float keep_scale;
+  uint64_t seed, seed_gstride;   // group g draws with seed + g * seed_gstride
+  const int32_t* seed_offset;
+};
+
 struct ConvArgs {
+  InXform t0, t1;
+  int xf;                    // host side: which loader instantiation launch_conv_fwd picks (0 / 1 / 2 = + max-pool)
+  int bcast0;                // source 0 holds ONE group ([gimages] images) read by every group: source image = n % gimages
+  int gimages;               // images per group (0: one group): coefficient / seed / statistics group of image n = n / gimages
+  long stats_gstride;        // doubles between the statistics accumulators of consecutive groups
   const void* x0;
   const void* x1;
   const void* w;
@@ -128,7 +149,8 @@ template <typename T, int N> struct FiLdsStride {
       sizeof(T) == 2 ? N + ((32 - (N * 2) % 64 + 64) % 64) / 2 : N + DT<T>::VG;       // elements
 };
 
-template <typename T, int KS, int TH, int NF, int CK, bool PLAIN>
+// XF: 0 = plain loader, 1 = loader applies the InXform of each source, 2 = InXform + 2x2 max-pool of source 0 (c1 == 0)
+template <typename T, int KS, int TH, int NF, int CK, bool PLAIN, int XF = 0>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
@@ -171,6 +193,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const T* x1 = reinterpret_cast<const T*>(a.x1);
   const T* wg = reinterpret_cast<const T*>(a.w);
   constexpr bool VEC = CK > VG;   // chunks wider than one vector: channel counts are whole vectors (host check)
+  static_assert(XF == 0 || VEC, "the transforming loader exists for whole-vector channel counts only");
+  const int grp = a.gimages > 0 ? n / a.gimages : 0;
   FI_TR(0);
 #ifdef FI_TRACE
   if (a.trace && threadIdx.x == 0) {
@@ -211,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int wt = wcol / VPP, wv = wcol % VPP;
   const int wlds0 = wrow0 * WKP + wt * CK + wv * VG;
   auto stage = [&](int cb) {
-    {
+    if constexpr (XF == 0) {
       const int ci = cb + xv * VG;
       const bool chok = ci < cin;
       const int cc = chok ? ci : 0;
@@ -239,6 +263,121 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         if (xrow0 < XRPP && py < XH) {
           vec_t val = r[p];
           if (!ok[p]) memset(&val, 0, sizeof(val));
+          *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
+        }
+      }
+    } else {
+      // transforming loader: this thread's channel vector keeps ONE set of coefficients per chunk in registers
+      const int ci = cb + xv * VG;
+      const bool chok = ci < cin;
+      const int cc = chok ? ci : 0;
+      const bool first = cc < a.c0;
+      const int csrc = first ? cc : cc - a.c0;
+      const int cstride = first ? a.c0 : a.c1;
+      const T* colbase = (first ? x0 : x1) + csrc;
+      const float* scp = first ? a.t0.scale : a.t1.scale;
+      const float* shp = first ? a.t0.shift : a.t1.shift;
+      const float slope = first ? a.t0.slope : a.t1.slope;
+      const bool xf = scp != nullptr;
+      float sc[VG], sh[VG];
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        sc[j] = xf ? scp[(size_t)grp * cstride + csrc + j] : 1.f;
+        sh[j] = xf ? shp[(size_t)grp * cstride + csrc + j] : 0.f;
+      }
+      const bool drop = XF == 1 && first && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+      uint64_t seed = 0;
+      if (drop) {
+        seed = a.t0.seed + (uint64_t)grp * a.t0.seed_gstride;
+        if (a.t0.seed_offset) seed += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+      }
+      auto xform = [&](const vec_t& raw, size_t vecidx) -> vec_t {
+        union {
+          vec_t v;
+          T e[VG];
+        } u;
+        u.v = raw;
+        float f[VG];
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          float v = to_f32(u.e[j]) * sc[j] + sh[j];
+          f[j] = v > 0.f ? v : v * slope;
+        }
+        if (drop) {
+#pragma unroll
+          for (int g4 = 0; g4 < VG / 4; ++g4) {
+            uint32_t rr[4];
+            fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < VG; ++j) u.e[j] = from_f32<T>(f[j]);
+        return u.v;
+      };
+      // source image: every group reads the same [gimages] images when the source is shared (first conv of the probe batch)
+      const int nl = n - grp * a.gimages;
+      const int ns = (first && a.bcast0) ? nl : n;
+      constexpr int NS = XF == 2 ? 4 : 1;
+      vec_t r[XPASS][NS];
+      bool ok[XPASS];
+      unsigned vix[XPASS];
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        const int gy = ty * TH + py - HALO;
+        ok[p] = xcolok && chok && py < XH && gy >= 0 && gy < H;
+        const int cy = min(max(gy, 0), H - 1);
+        if constexpr (XF == 2) {
+          const int pix = (ns * 2 * H + 2 * cy) * (2 * W) + 2 * xcx;     // source is [N][2H][2W][C]
+          const T* src = colbase + (size_t)pix * cstride;
+          r[p][0] = *reinterpret_cast<const vec_t*>(src);
+          r[p][1] = *reinterpret_cast<const vec_t*>(src + cstride);
+          r[p][2] = *reinterpret_cast<const vec_t*>(src + (size_t)2 * W * cstride);
+          r[p][3] = *reinterpret_cast<const vec_t*>(src + (size_t)(2 * W + 1) * cstride);
+          vix[p] = 0;
+        } else {
+          const int pix = (ns * H + cy) * W + xcx;
+          r[p][0] = *reinterpret_cast<const vec_t*>(colbase + (size_t)pix * cstride);
+          // dropout index = vector index inside the group's dense [gimages][H][W][C] tensor (what fi_bn_act_fwd uses)
+          const int pixl = (nl * H + cy) * W + xcx;
+          vix[p] = (unsigned)pixl * (unsigned)(cstride / VG) + (unsigned)(csrc / VG);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        if (xrow0 < XRPP && py < XH) {
+          vec_t val;
+          if (!ok[p]) {
+            memset(&val, 0, sizeof(val));
+          } else if constexpr (XF == 2) {
+            union {
+              vec_t v;
+              T e[VG];
+            } q[4], m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k].v = xf ? xform(r[p][k], 0) : r[p][k];
+#pragma unroll
+            for (int j = 0; j < VG; ++j) {
+              // scan order, strict > : the element fi_maxpool2_fwd keeps
+              float best = to_f32(q[0].e[j]);
+              T bq = q[0].e[j];
+#pragma unroll
+              for (int k = 1; k < 4; ++k) {
+                const float v = to_f32(q[k].e[j]);
+                if (v > best) {
+                  best = v;
+                  bq = q[k].e[j];
+                }
+              }
+              m.e[j] = bq;
+            }
+            val = m.v;
+          } else {
+            val = xf ? xform(r[p][0], vix[p]) : r[p][0];
+          }
           *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
         }
       }
@@ -468,7 +607,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         // FI_STATS_SLOTS copies of the accumulator: thousands of workgroups adding to the same 2*C
         // addresses serialise at the fabric; spreading them over 32 slots (summed by the BN kernel) removes that.
         const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
-        atomicAdd(&a.stats[((size_t)slot * cout + co) * 2 + which], tot);
+        atomicAdd(&a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2 + which], tot);
       }
     }
   }
@@ -480,6 +619,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
 template <typename T, int KS, int TH, int NF, int CK>
 static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
+  const int xf = a.xf;
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP;
   constexpr int KC = KK * CK, KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
@@ -490,6 +630,24 @@ static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
   if (lds < red) lds = red;
   const long blocks = (long)a.N * a.tilesX * a.tilesY * a.nct;
   const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+  if constexpr (CK > DT<T>::VG) {
+    // fused-forward loaders: plain epilogue only (the probe forward stores one dtype, never accumulates)
+    if (xf) {
+      if (!plain) return FI_ERR_UNSUPPORTED;
+      if (xf == 2) {
+        if constexpr (KS == 3)
+          hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK, true, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+        else
+          return FI_ERR_UNSUPPORTED;
+      } else {
+        hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK, true, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+      }
+      FI_CHECK_LAUNCH();
+      return 0;
+    }
+  } else {
+    if (xf) return FI_ERR_UNSUPPORTED;
+  }
   if (plain)
     hipLaunchKernelGGL((conv_fwd_kernel<T, KS, TH, NF, CK, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   else

@@ -108,6 +108,45 @@ extern "C" int fi_bn_finalize(const double* stats, double count, const float* ga
   return 0;
 }
 
+// G groups of one fused launch: coefficients per group, running statistics moved G times in group order
+__global__ void bn_finalize_groups_kernel(const double* stats, long gstride, int G, double count, const float* gamma,
+                                          const float* beta, float* rmean, float* rvar, int64_t* nbt, float momentum,
+                                          float eps, float* coef, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += G;
+  if (c >= C) return;
+  const float ga = gamma[c], be = beta[c];
+  for (int g = 0; g < G; ++g) {
+    const double* st = stats + (size_t)g * gstride;
+    double s1 = 0.0, s2 = 0.0;
+    for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) {
+      s1 += st[((size_t)slot * C + c) * 2];
+      s2 += st[((size_t)slot * C + c) * 2 + 1];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    bn_running_update(rmean, rvar, c, momentum, mu, (float)unb);
+    const float sc = ga * istd;
+    coef[(size_t)g * C + c] = sc;
+    coef[(size_t)(G + g) * C + c] = be - mu * sc;
+  }
+}
+
+extern "C" int fi_bn_finalize_groups(const double* stats, long stats_group_stride, int groups, double count,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int64_t* nbt, float momentum, float eps, float* coef, int C, void* stream) {
+  if (!stats || !gamma || !beta || !running_mean || !running_var || !coef) return FI_ERR_NULL;
+  if (groups < 1 || C < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(fi_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats,
+                     stats_group_stride, groups, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, coef, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // BN apply + activation + dropout
 // ------------------------------------------------------------------------------------------------

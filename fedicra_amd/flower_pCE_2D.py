@@ -108,12 +108,16 @@ class MyClient(BaseClient):
         if args.strategy in ["FedICRA"]:                                             # :128-139
             heatmaps = out[6]
             acc = 0
-            for other_client in range(args.min_num_clients):
-                if other_client == args.cid:
-                    continue
-                with torch.no_grad():
-                    _heatmaps = self.model(x, other_client, heatmap_only=True)[6]   # nothing else of it is read
-                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], _heatmaps[-1].detach())
+            others = [c for c in range(args.min_num_clients) if c != args.cid]
+            with torch.no_grad():                                                    # all K-1 forwards as one batch
+                batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
+            for k, other_client in enumerate(others):
+                if batched is not None:
+                    other_map = batched[k]
+                else:
+                    with torch.no_grad():
+                        other_map = self.model(x, other_client, heatmap_only=True)[6][-1]   # nothing else of it is read
+                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], other_map.detach())
             loss_lc = -acc / (args.min_num_clients - 1)
             loss = torch.add(loss, loss_lc, alpha=args.alpha)
         if self.amp:                                         # :143-146

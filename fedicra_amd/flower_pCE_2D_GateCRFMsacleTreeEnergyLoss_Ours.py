@@ -54,8 +54,12 @@ class MyClient(_PCEClient):
                 self._lc_stream = torch.cuda.Stream(device=x.device)
             self._lc_stream.wait_stream(cur)
             with torch.cuda.stream(self._lc_stream), torch.no_grad():
-                for other_client in range(args.min_num_clients):
-                    if other_client != args.cid:
+                ids = [c for c in range(args.min_num_clients) if c != args.cid]
+                batched = self.model.model.probe_heatmaps(x, ids) if hasattr(self.model.model, "probe_heatmaps") else None
+                if batched is not None:                      # all K-1 forwards as one batch of statistics groups
+                    others = [h.detach() for h in batched]
+                else:
+                    for other_client in ids:
                         # logits and head outputs of these forwards are never read
                         others.append(self.model(x, other_client, heatmap_only=True)[-4][-1].detach())
         out_tree_loss = self.tree_loss_multi(outputs, three_channel, aux[0], aux[1], aux[2], unlabeled,

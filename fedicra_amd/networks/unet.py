@@ -90,6 +90,16 @@ class ConvBlock(_FiModule):
         z = ops.conv_bn_act(x0, x1, s[0], s[1], s[2].negative_slope, self.dropout_p, "elem")
         return ops.conv_bn_act(z, None, s[4], s[5], s[6].negative_slope, 0.0)
 
+    def _probe(self, s0, s1, groups, pool=False, first=False):
+        """This block inside the batched no-grad forward (ops.probe_*): sources and result are raw activations."""
+        s = self.conv_conv
+        if first:
+            r = ops.probe_first_conv_bn(s0, s[0], s[1], s[2].negative_slope, groups)
+        else:
+            r = ops.probe_conv_bn(s0, s1, s[0], s[1], s[2].negative_slope, groups, pool=pool)
+        drop = ops._probe_drop(self.dropout_p, s[1], groups)
+        return ops.probe_conv_bn(r, None, s[4], s[5], s[6].negative_slope, groups, in_drop=drop)
+
     def forward(self, x):
         return self._out(self._run(self._in(x)))
 
@@ -243,6 +253,23 @@ class LCEncoder(_FiModule):
             hmaps.append(h)
         return feats, hmaps
 
+    def _probe(self, x, emb_ids):
+        """The encoder for len(emb_ids) forwards of the SAME batch x under different embeddings, as one batch of groups
+        (group g = forward g): every ConvBlock half stays a raw activation, the pooling happens in the consumer's loader,
+        only the deepest level is materialised for the channel selection.  -> (4 raw skips, x4 tensor, heat-map [G*B,1,1,C])"""
+        G, B = len(emb_ids), x.shape[0]
+        r = self.in_conv._probe(x, None, G, first=True)
+        feats = [r]
+        for blk in (self.down1, self.down2, self.down3, self.down4):
+            r = blk.maxpool_conv[1]._probe(r, None, G, pool=True)
+            feats.append(r)
+        z = ops.probe_materialize(feats[4], G)
+        emb = torch.zeros((G * B, self.n_client), device=x.device)
+        for g, e in enumerate(emb_ids):
+            emb[g * B:(g + 1) * B, self.cid if not e else e] = 1   # unet.py:186 (quirk 2: 0 means "own")
+        x4, h = self.pcs_list[0]._run(z, emb)
+        return feats[:4], x4, h
+
     def forward(self, x, emb_idx=None):
         f, h = self._run(self._in(x), emb_idx)
         return [self._out(t) for t in f], [None if t is None else self._out(t) for t in h]
@@ -287,6 +314,23 @@ class _DecoderBase(_FiModule):
     def _run(self, f, probe=False):
         return self._trunk(f, probe)
 
+    def _heads(self):
+        """(head Sequential, index of the trunk output it reads) pairs."""
+        return []
+
+    def _probe(self, skips, x4, groups):
+        """Decoder of the batched no-grad forward: nothing is returned -- what it leaves behind are the BatchNorm running
+        statistics of every block and head, moved `groups` times as the separate forwards would."""
+        def up(blk, lo, skip):
+            u = ops.upsample2x(ops.probe_conv(lo, blk.conv1x1, groups))
+            return blk.conv._probe(skip, u, groups)
+        o = [None, up(self.up1, x4, skips[3])]
+        o.append(up(self.up2, o[1], skips[2]))
+        o.append(up(self.up3, o[2], skips[1]))
+        o.append(up(self.up4, o[3], skips[0]))
+        for head, idx in self._heads():
+            ops.probe_conv_bn(o[idx], None, head[0], head[1], 0.0, groups, store=False)
+
     def forward(self, feature):
         return tuple(self._out(t) for t in self._run([self._in(t) for t in feature]))
 
@@ -302,6 +346,9 @@ class Decoder_Head(_DecoderBase):
         super().__init__(params)
         self.dsn_head = _dsn_head(self.ft_chns[2], self.n_class)
 
+    def _heads(self):
+        return [(self.dsn_head, 2)]
+
     def _run(self, f, probe=False):
         o = self._trunk(f, probe)
         return o + [_run_head(self.dsn_head, o[2], probe)]
@@ -315,6 +362,9 @@ class Decoder_MultiHead(_DecoderBase):
         self.dsn_head1 = _dsn_head(self.ft_chns[2], self.n_class)
         self.dsn_head2 = _dsn_head(self.ft_chns[1], self.n_class)
         self.dsn_head3 = _dsn_head(self.ft_chns[0], self.n_class)
+
+    def _heads(self):
+        return [(self.dsn_head1, 2), (self.dsn_head2, 3), (self.dsn_head3, 4)]
 
     def _run(self, f, probe=False):
         o = self._trunk(f, probe)
@@ -385,6 +435,31 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         hm = [None if t is None else self._out(t) for t in h]
         out = lambda t: None if t is None else self._out(t)
         return [out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + [out(t) for t in o[5:]]
+
+
+    def probe_heatmaps(self, x, emb_ids):
+        """The heat-maps ``self(x, e)[6][-1]`` for every e in emb_ids -- FedICRA's LC loss asks for them once per OTHER client
+        in every iteration (flower_pCE_2D.py:128-139: no-grad, train mode) -- from ONE batched pass: the K-1 forwards run
+        as statistics groups of the same launches (fi_conv2d_fwd_fused / fi_bn_finalize_groups), the activations between
+        the convolutions are never materialised, and the first convolution, identical under every embedding, runs once.
+        State afterwards is what the K-1 separate forwards leave: every BatchNorm's running statistics moved K-1 times in
+        order, num_batches_tracked += K-1, the same dropout masks.  Returns None when the batched form does not apply
+        (eval mode, autograd on, host-fed masks, other architectures): the caller then makes the separate forwards."""
+        enc, dec = self.encoder, self.decoder
+        if not (self.training and not torch.is_grad_enabled() and ops.probe_ready() and len(emb_ids) > 0):
+            return None
+        if enc.n_pcs != 1 or not all(getattr(b, "bilinear", True) for b in (dec.up1, dec.up2, dec.up3, dec.up4)):
+            return None
+        dt = self.compute_dtype()
+        vg = 4 if dt == torch.float32 else 8
+        if any(c % vg for c in enc.ft_chns):
+            return None
+        self._fi_refresh_packs(dt)
+        xin = self._in(x)
+        G, B = len(emb_ids), xin.shape[0]
+        skips, x4, h = enc._probe(xin, list(emb_ids))
+        dec._probe(skips, x4, G)
+        return [self._out(h[g * B:(g + 1) * B]) for g in range(G)]
 
 
 class UNet_LC(_UNetLCBase):

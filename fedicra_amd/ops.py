@@ -581,6 +581,112 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
                   bn.momentum, bn.eps, True, coef[0], coef[1], coef[2], coef[3])
 
 
+# ----------------------------------------------------------------------------- fused probe forward
+class RawAct:
+    """A ConvBlock half whose activation z = dropout(act(BN(y))) is never materialised: the raw convolution output y, the
+    coefficient rows of its BatchNorm (fp32 [2][G][C], one row pair per statistics group) and the activation slope.  The
+    consuming convolution applies them in its loader (fi_conv2d_fwd_fused).  `shared`: y holds ONE group's images, which
+    every group reads."""
+    __slots__ = ("y", "coef", "slope", "shared")
+
+    def __init__(self, y, coef, slope, shared=False):
+        self.y, self.coef, self.slope, self.shared = y, coef, slope, shared
+
+
+def probe_ready():
+    """The batched probe forward draws its masks from the device RNG stream of the current context (a training client's
+    iteration counter); parity runs that feed host masks take the sequential path instead."""
+    return _mask_provider is None and _ctx.seed_offset is not None
+
+
+def _probe_drop(p, bn_owner, groups):
+    """Dropout of a ConvBlock's first half for `groups` consecutive calls of the layer: the spec of the FIRST call (ops._drop_spec
+    numbering: seed = base + uid<<24 + k*0x10001) -- group g draws with k + g -- and the call counter moved past all of them."""
+    if p <= 0.0:
+        return None
+    spec = _drop_spec(p, "elem", 1, 1, 1, 1, None, owner=bn_owner)
+    uid = bn_owner._fi_uid if getattr(bn_owner, "_fi_uid", None) is not None else _layer_uid[id(bn_owner)]
+    _ctx.call_idx[uid] += groups - 1
+    return spec
+
+
+def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, store=True):
+    """One ConvBlock half of the batched no-grad train-mode forward: convolution of (possibly raw) sources with the
+    statistics epilogue per group, then the grouped BatchNorm finalize (running statistics moved `groups` times, in
+    order).  Returns RawAct(y, coef) -- or None when store is False (statistics-only: the auxiliary heads)."""
+    r0 = s0 if isinstance(s0, RawAct) else None
+    r1 = s1 if isinstance(s1, RawAct) else None
+    x0 = r0.y if r0 is not None else s0
+    x1 = None if s1 is None else (r1.y if r1 is not None else s1)
+    wk = _krsc(conv.weight)
+    cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+    dev = x0.device
+    shared0 = bool(r0 is not None and r0.shared)
+    N = x0.shape[0] * (groups if shared0 else 1)
+    H, W = x0.shape[1], x0.shape[2]
+    if pool:
+        H, W = H // 2, W // 2
+    wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=conv.weight)
+    t0 = None if r0 is None else L.in_xform(r0.coef, r0.slope, pool=pool, drop=in_drop, seed_group_stride=0x10001)
+    t1 = None if r1 is None else L.in_xform(r1.coef, r1.slope)
+    if (pool or in_drop is not None) and t0 is None:
+        raise L.FiError("pooling / dropout in the loader need a raw source 0")
+    stats = _ctx.arena.take(groups * L.STATS_SLOTS * cout * 2, dev)
+    y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev) if store else None
+    L.conv2d_fwd_fused(x0, t0, x1, t1, wp, conv.bias, y, stats, ksize=ksize, groups=groups, cout=cout, shared0=shared0)
+    coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
+    L.bn_finalize_groups(stats, groups, float((N // groups) * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, bn.momentum, bn.eps, coef)
+    return RawAct(y, coef, slope) if store else None
+
+
+def probe_first_conv_bn(x, conv, bn, slope, groups):
+    """The first convolution of the batch: the same images under every embedding, so it runs ONCE; its batch statistics
+    are every group's, and the running statistics still move `groups` times."""
+    wk = _krsc(conv.weight)
+    cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+    N, H, W, _ = x.shape
+    dev = x.device
+    wp = _packed(wk, x.dtype, 0, cout, ksize * ksize, cin, param=conv.weight)
+    stats = _ctx.arena.take(L.STATS_SLOTS * cout * 2, dev)
+    y = torch.empty((N, H, W, cout), dtype=x.dtype, device=dev)
+    L.conv2d_fwd(x, None, wp, conv.bias, y, None, stats, ksize=ksize)
+    coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
+    L.bn_finalize_groups(stats, groups, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, bn.momentum, bn.eps, coef, shared=True)
+    return RawAct(y, coef, slope, shared=True)
+
+
+def probe_conv(s0, conv, groups):
+    """Plain convolution (UpBlock.conv1x1) of a possibly raw source."""
+    if not isinstance(s0, RawAct):
+        wk = _krsc(conv.weight)
+        cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+        N, H, W, _ = s0.shape
+        y = torch.empty((N, H, W, cout), dtype=s0.dtype, device=s0.device)
+        L.conv2d_fwd(s0, None, _packed(wk, s0.dtype, 0, cout, ksize * ksize, cin, param=conv.weight), conv.bias, y, None,
+                     None, ksize=ksize)
+        return y
+    wk = _krsc(conv.weight)
+    cout, ksize, cin = wk.shape[0], wk.shape[1], wk.shape[3]
+    N, H, W, _ = s0.y.shape
+    y = torch.empty((N, H, W, cout), dtype=s0.y.dtype, device=s0.y.device)
+    L.conv2d_fwd_fused(s0.y, L.in_xform(s0.coef, s0.slope), None, None,
+                       _packed(wk, s0.y.dtype, 0, cout, ksize * ksize, cin, param=conv.weight), conv.bias, y, None,
+                       ksize=ksize, groups=groups, cout=cout)
+    return y
+
+
+def probe_materialize(r, groups):
+    """z = act(BN(y)) of a raw activation as a tensor (the deepest encoder level, whose consumer is the channel
+    selection): one fi_bn_act_fwd per statistics group."""
+    z = torch.empty_like(r.y)
+    n = r.y.shape[0] // groups
+    for g in range(groups):
+        L.bn_act_fwd(r.y[g * n:(g + 1) * n], r.coef[0, g], r.coef[1, g], z[g * n:(g + 1) * n], r.slope, None)
+    return z
+
+
 def conv_bn_act(x0, x1, conv, bn, slope, drop_p=0.0, drop_kind="elem"):
     return _ConvBNAct.apply(x0, x1, conv.weight, conv.bias, bn.weight, bn.bias, conv, bn, float(slope),
                             float(drop_p), drop_kind)

@@ -76,6 +76,35 @@ typedef struct FiConv {
 int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                   void* y0, void* y1, double* stats, void* stream);
 
+/* Fused ("probe") forward: the same convolution, but every source may hold the RAW output y of its producing
+ * convolution, and the loader evaluates  z = dropout(act(scale[c]*y + shift[c]))  -- the BatchNorm apply, LeakyReLU / ReLU
+ * and element-wise Dropout of ConvBlock (unet.py:21-24) -- while it stages the tile, optionally followed by the 2x2
+ * max-pool of a DownBlock (unet.py:40; `pool`: source 0 is then [N][2H][2W][c0], c1 must be 0).  z is rounded to the
+ * storage dtype exactly as fi_bn_act_fwd rounds it, so a chain of fused launches reproduces the unfused forward bit for
+ * bit while the activations z are never written to or read from HBM.  Used for the no-grad forwards of FedICRA's LC
+ * loss (flower_pCE_2D.py:128-139): K-1 forwards per iteration whose only outputs are the heat-map and the BatchNorm
+ * running statistics.  Those K-1 forwards run as ONE batch of `group_images`-image groups: coefficient rows, dropout
+ * seeds (seed + g * seed_group_stride, element index inside the group) and the statistics accumulators
+ * (stats + g * stats_group_stride) belong to group g = n / group_images, i.e. each group sees exactly the batch
+ * statistics and masks its own forward would have seen.  scale == NULL: source used as it is (t == NULL likewise).
+ * Channel counts must be whole 16-byte vectors; single destination, storage dtype, no accumulation. */
+typedef struct FiInXform {
+  const float* scale;          /* fp32 [groups][C] (fi_bn_finalize_groups), or NULL                                  */
+  const float* shift;          /* fp32 [groups][C]                                                                   */
+  float slope;                 /* LeakyReLU negative slope; 0 = ReLU                                                 */
+  int pool;                    /* 1: 2x2 max-pool after the transform (source 0 only)                                */
+  int drop_mode;               /* FI_DROP_NONE or FI_DROP_RNG_ELEM (source 0 only, not with pool)                    */
+  float drop_p;
+  uint64_t seed;
+  uint64_t seed_group_stride;
+  const int32_t* seed_offset;  /* as FiBnAct.seed_offset                                                             */
+} FiInXform;
+#define FI_FUSED_SHARED_SOURCE0 1 /* source 0 holds ONE group (group_images images) that every group reads: the first
+                                    ConvBlock output of the batch, identical for all K-1 forwards up to its dropout   */
+int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
+                        const void* x0, const void* x1, const void* w, const float* bias, void* y, double* stats,
+                        long stats_group_stride, void* stream);
+
 /* dw[co][k*k][ci] += sum_pixels dy * x  (fp32);  dbias[co] += sum_pixels dy (fp32, may be NULL).
  * d->co0 = Cout, co1 ignored; dy is [N,H,W,Cout].  With a caller-owned `workspace` of at least
  * fi_conv2d_wgrad_workspace(d) bytes the reduction is two-stage and DETERMINISTIC (per-workgroup partial
@@ -133,6 +162,13 @@ int fi_pack_weights_multi(const long long* table, int ntensors, int dtype, void*
 int fi_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
                    float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+
+/* The same for G statistics groups of one launch of fi_conv2d_fwd_fused (group g at stats + g*stats_group_stride,
+ * `count` elements each): coef = fp32 [2][G][C] (scale rows, then shift rows), and the running statistics are moved G
+ * times IN GROUP ORDER -- what G consecutive train-mode forwards would do -- with num_batches_tracked += G. */
+int fi_bn_finalize_groups(const double* stats, long stats_group_stride, int groups, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float momentum, float eps, float* coef, int C, void* stream);
 
 typedef struct FiBnAct {
   int dtype;

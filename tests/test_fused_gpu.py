@@ -1,0 +1,181 @@
+"""The fused ("probe") forward against the unfused kernels it replaces: the transforming conv loader (BatchNorm apply +
+LeakyReLU + dropout [+ 2x2 max-pool] while staging) vs fi_bn_act_fwd [+ fi_maxpool2_fwd] + fi_conv2d_fwd, and the batched
+K-1 no-grad forwards of FedICRA's LC loss vs the K-1 separate forwards (flower_pCE_2D.py:128-139)."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _coef(G, C, gen):
+    sc = (0.5 + torch.rand(G, C, generator=gen)).float()
+    sh = (torch.randn(G, C, generator=gen) * 0.3).float()
+    return torch.stack([sc, sh]).to(DEV).contiguous()          # [2][G][C]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", ["plain", "drop", "pool", "cat", "k1", "shared", "wide", "ragged"])
+def test_transforming_loader_equals_bn_act_then_conv(dtype, case):
+    """Same bits out of the convolution whether its input z was materialised by fi_bn_act_fwd (and pooled by
+    fi_maxpool2_fwd) or evaluated by the loader from the raw y; the statistics epilogue lands in the group's accumulators."""
+    from fedicra_amd import _lib as L
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(len(case) * 31 + ord(case[0]))
+    G, B = (3, 2)
+    H = W = 24
+    c0, c1, cout, k = 16, 0, 32, 3
+    drop_p, pool, shared = 0.0, False, False
+    if case == "drop":
+        drop_p = 0.3
+    elif case == "pool":
+        pool = True
+    elif case == "cat":
+        c0, c1 = 16, 16
+    elif case == "k1":
+        k, c0, cout = 1, 32, 16
+    elif case == "shared":
+        shared, drop_p = True, 0.2
+    elif case == "wide":
+        c0, cout = 128, 64
+    elif case == "ragged":
+        H, W = 20, 27
+    N = G * B
+    hs, ws = (2 * H, 2 * W) if pool else (H, W)
+    y0 = torch.randn(B if shared else N, hs, ws, c0, generator=gen).to(DEV).to(td)
+    coef0 = _coef(G, c0, gen)
+    x1 = torch.randn(N, H, W, c1, generator=gen).to(DEV).to(td) if c1 else None
+    w = (torch.randn(cout, k, k, c0 + c1, generator=gen) * 0.1).to(DEV).to(td)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    soff = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+    seed, stride = 0x1234567, 0x10001
+    # --- unfused: per group bn_act (+pool) then one conv over the whole batch
+    z = torch.empty((N, hs, ws, c0), dtype=td, device=DEV)
+    for g in range(G):
+        src = y0 if shared else y0[g * B:(g + 1) * B]
+        drop = (L.DROP_RNG_ELEM, drop_p, seed + g * stride, None, soff) if drop_p > 0 else None
+        L.bn_act_fwd(src, coef0[0, g], coef0[1, g], z[g * B:(g + 1) * B], 0.01, drop)
+    if pool:
+        zp = torch.empty((N, H, W, c0), dtype=td, device=DEV)
+        L.maxpool2_fwd(z, zp)
+        z = zp
+    want = torch.empty((N, H, W, cout), dtype=td, device=DEV)
+    st_want = torch.zeros(G, L.STATS_SLOTS, cout, 2, dtype=torch.float64, device=DEV)
+    for g in range(G):
+        L.conv2d_fwd(z[g * B:(g + 1) * B], None if x1 is None else x1[g * B:(g + 1) * B], w, bias, want[g * B:(g + 1) * B],
+                     None, st_want[g], ksize=k)
+    # --- fused
+    drop = (L.DROP_RNG_ELEM, drop_p, seed, None, soff) if drop_p > 0 else None
+    t0 = L.in_xform(coef0, 0.01, pool=pool, drop=drop, seed_group_stride=stride)
+    got = torch.empty_like(want)
+    st_got = torch.zeros_like(st_want)
+    L.conv2d_fwd_fused(y0, t0, x1, None, w, bias, got, st_got, ksize=k, groups=G, shared0=shared)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    a, b = st_got.sum(1), st_want.sum(1)
+    assert torch.allclose(a, b, rtol=1e-9, atol=1e-9), float((a - b).abs().max())
+    # statistics-only launch: nothing stored, same accumulators
+    st_only = torch.zeros_like(st_want)
+    L.conv2d_fwd_fused(y0, t0, x1, None, w, bias, None, st_only, ksize=k, groups=G, cout=cout, shared0=shared)
+    assert torch.allclose(st_only.sum(1), b, rtol=1e-9, atol=1e-9)
+
+
+def test_bn_finalize_groups_moves_the_running_statistics_like_consecutive_forwards():
+    from fedicra_amd import _lib as L
+    gen = torch.Generator().manual_seed(5)
+    G, C, count = 4, 48, 1000.0
+    s1 = torch.randn(G, L.STATS_SLOTS, C, generator=gen).double() * 30
+    s2 = (torch.rand(G, L.STATS_SLOTS, C, generator=gen).double() + 1.0) * 400
+    stats = torch.stack([s1, s2], dim=-1).to(DEV).contiguous()
+    gamma, beta = torch.rand(C, generator=gen).to(DEV) + 0.5, torch.randn(C, generator=gen).to(DEV)
+    rm0, rv0 = torch.randn(C, generator=gen).to(DEV), torch.rand(C, generator=gen).to(DEV) + 0.5
+    rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    want = torch.empty(2, G, C, device=DEV)
+    tmp = torch.empty(2, C, device=DEV)
+    for g in range(G):
+        L.bn_finalize(stats[g], count, gamma, beta, rm, rv, nbt, 0.1, 1e-5, True, want[0, g], want[1, g], tmp[0], tmp[1])
+    rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    coef = torch.empty(2, G, C, device=DEV)
+    L.bn_finalize_groups(stats, G, count, gamma, beta, rm2, rv2, nbt2, 0.1, 1e-5, coef)
+    torch.cuda.synchronize()
+    assert torch.equal(coef, want) and torch.equal(rm, rm2) and torch.equal(rv, rv2) and int(nbt2) == G == int(nbt)
+    # shared accumulators: every group the same coefficients, running statistics still moved G times
+    rm3, rv3, nbt3 = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    L.bn_finalize_groups(stats[0].contiguous(), G, count, gamma, beta, rm3, rv3, nbt3, 0.1, 1e-5, coef, shared=True)
+    rm4, rv4 = rm0.clone(), rv0.clone()
+    for g in range(G):
+        L.bn_finalize(stats[0], count, gamma, beta, rm4, rv4, nbt, 0.1, 1e-5, True, tmp[0], tmp[1], want[0, 0], want[1, 0])
+    assert torch.equal(rm3, rm4) and torch.equal(rv3, rv4) and all(torch.equal(coef[:, g], coef[:, 0]) for g in range(G))
+
+
+@pytest.mark.parametrize("dtype,model", [("fp32", "unet_lc"), ("bf16", "unet_lc"), ("bf16", "unet_lc_multihead")])
+def test_batched_probe_forwards_equal_the_separate_forwards(dtype, model):
+    """`probe_heatmaps(x, others)` against `model(x, j, heatmap_only=True)` for every other client j from the same state and
+    dropout stream: the same heat-maps, the same BatchNorm running statistics and counters afterwards (statistics are
+    fp64 atomic sums whose order differs between launch shapes: an fp32 ulp or two), the same dropout call counters."""
+    from fedicra_amd import ops
+    from fedicra_amd.networks import net_factory
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from helpers import loader
+    in_chns = 3 if model == "unet_lc" else 1
+    b = loader(1, 4, 64, cid=1, in_chns=in_chns, ncls=in_chns, device=DEV)[0]["image"]
+    x = b if in_chns == 3 else b.unsqueeze(1)
+    K, cid = 5, 1
+    args = argparse.Namespace(min_num_clients=K, cid=cid)
+    others = [j for j in range(K) if j != cid]
+    res = []
+    for batched in (False, True):
+        torch.manual_seed(2022)
+        ops.manual_seed(3)
+        net = net_factory(args, net_type=model, in_chns=in_chns, class_num=in_chns).cuda().train()
+        set_compute_dtype(net, dtype)
+        ctx = ops.new_context()
+        ctx.seed_offset = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+        with ops.use_context(ctx), torch.no_grad():
+            ops.begin_iteration(x.device)
+            net(x)                                            # the iteration's own forward comes first (call counters at 1)
+            if batched:
+                hm = net.probe_heatmaps(x, others)
+                assert hm is not None
+            else:
+                hm = [net(x, j, heatmap_only=True)[6][-1] for j in others]
+        torch.cuda.synchronize()
+        res.append(([h.float().clone() for h in hm], net.flat_state.clone(), net.flat_counters.clone(), dict(ctx.call_idx)))
+    (h0, s0, c0, k0), (h1, s1, c1, k1) = res
+    assert k0 == k1 and torch.equal(c0, c1) and int(c1.min()) == K
+    tol = 1e-5 if dtype == "fp32" else 2e-2
+    for a, b_ in zip(h0, h1):
+        assert a.shape == b_.shape and torch.allclose(a, b_, rtol=0, atol=tol), float((a - b_).abs().max())
+    assert len({float(h.sum()) for h in h1}) == len(others)   # different embeddings / masks: different maps
+    assert torch.allclose(s0, s1, rtol=1e-5 if dtype == "fp32" else 5e-3, atol=1e-6 if dtype == "fp32" else 1e-3), \
+        float((s0 - s1).abs().max())
+
+
+def test_probe_heatmaps_declines_when_it_does_not_apply():
+    from fedicra_amd import ops
+    from fedicra_amd.networks import net_factory
+    from helpers import loader
+    x = loader(1, 2, 32, cid=0, device=DEV)[0]["image"].unsqueeze(1)
+    net = net_factory(argparse.Namespace(min_num_clients=3, cid=0), net_type="unet_lc", in_chns=1, class_num=2).cuda().train()
+    with torch.no_grad():
+        assert net.probe_heatmaps(x, [1, 2]) is None          # no device RNG stream in this context
+        ctx = ops.new_context()
+        ctx.seed_offset = torch.zeros(1, dtype=torch.int32, device=DEV)
+        with ops.use_context(ctx):
+            ops.begin_iteration(x.device)
+            assert net.probe_heatmaps(x, [1, 2]) is not None
+            ops.set_dropout_mask_provider(lambda shape, p: torch.ones(shape))
+            try:
+                assert net.probe_heatmaps(x, [1, 2]) is None  # host-fed masks: separate forwards
+            finally:
+                ops.set_dropout_mask_provider(None)
+            net.eval()
+            assert net.probe_heatmaps(x, [1, 2]) is None
+    net.train()
+    ctx2 = ops.new_context()
+    ctx2.seed_offset = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with ops.use_context(ctx2):
+        assert net.probe_heatmaps(x, [1, 2]) is None          # autograd on
