@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -238,6 +238,11 @@ def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False,
                 px * cin * _esz(x0) + (0 if y0 is None else px * cout * _esz(y0)) + cin * cout * ksize * ksize * _esz(x0)):
         _chk(lib().fi_conv2d_fwd(C.byref(d), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y0), ptr(y1), ptr(stats),
                                  stream()), "fi_conv2d_fwd")
+
+
+def conv_tuning(v2=-1, nf=0, ck=0, wgs_per_cu=0):
+    """fi_conv_tuning: measurement / test hook (which forward kernel is launched); results never depend on it."""
+    _chk(lib().fi_conv_tuning(int(v2), int(nf), int(ck), int(wgs_per_cu)), "fi_conv_tuning")
 
 
 def in_xform(coef, slope, *, pool=False, drop=None, seed_group_stride=0):

@@ -55,6 +55,69 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// ---- 16-byte vectors handled as four 32-bit words.  A vec_t that lives across a loop (the register set a persistent
+//      kernel keeps in flight) must never be touched through memset or a union with T[VG]: hipcc's SROA then carries it as
+//      16 separate BYTES (16 VGPRs instead of 4, reassembled with shifts at every use).  These helpers only ever use typed
+//      32-bit components.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint4 fi_vec_select(bool keep, const uint4& v) {
+  return make_uint4(keep ? v.x : 0u, keep ? v.y : 0u, keep ? v.z : 0u, keep ? v.w : 0u);
+}
+__device__ __forceinline__ float4 fi_vec_select(bool keep, const float4& v) {
+  return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+template <typename T> struct VecWords;
+template <> struct VecWords<float> {
+  static __device__ __forceinline__ void unpack(const float4& v, float (&f)[4]) {
+    f[0] = v.x, f[1] = v.y, f[2] = v.z, f[3] = v.w;
+  }
+  static __device__ __forceinline__ float4 pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct VecWords<bf16_t> {
+  static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[8]) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);             // bf16 -> fp32 is exact: the upper 16 bits
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x2_t p;
+      p[0] = (bf16_t)f[2 * i];                              // round to nearest even, as from_f32<bf16_t>
+      p[1] = (bf16_t)f[2 * i + 1];
+      w[i] = __builtin_bit_cast(unsigned, p);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <> struct VecWords<f16_t> {
+  static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[8]) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16x2_t p = __builtin_bit_cast(f16x2_t, w[i]);
+      f[2 * i] = (float)p[0];
+      f[2 * i + 1] = (float)p[1];
+    }
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2_t p;
+      p[0] = (f16_t)f[2 * i];
+      p[1] = (f16_t)f[2 * i + 1];
+      w[i] = __builtin_bit_cast(unsigned, p);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
 // wave-wide sum via xor shuffles (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

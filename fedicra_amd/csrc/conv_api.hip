@@ -19,6 +19,8 @@ int fi_conv_wgrad_f16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream
 int fi_conv_wgrad_f16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f16_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f16_k3(int th, const WgradArgs& a, hipStream_t st);
+int fi_conv_fwd_v2_bf16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_v2_f16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -42,6 +44,22 @@ static long min_blocks() {
 static long wgrad_blocks() {
   static long v = env_long("FI_WGRAD_BLOCKS", 512);
   return v;
+}
+
+// which forward kernel: [0] -1 = FI_V2 from the environment (default: per-layer choice), 0 = one-tile kernel, 1 = persistent
+// kernel wherever it applies; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
+static long g_tune[4] = {-1, 0, 0, 0};
+static long env_v2() {
+  static long v = env_long("FI_V2", 0);
+  return v;
+}
+extern "C" int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu) {
+  if ((nf && nf != 1 && nf != 2 && nf != 4) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 8) return FI_ERR_SHAPE;
+  g_tune[0] = v2;
+  g_tune[1] = nf;
+  g_tune[2] = ck;
+  g_tune[3] = wgs_per_cu;
+  return 0;
 }
 
 static int pick_th(int N, int H, int W, long per_tile_mult) {
@@ -189,6 +207,22 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
   a.trace = g_trace;
 #endif
   hipStream_t st = (hipStream_t)stream;
+  {
+    // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
+    const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
+    const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+    if (v2 && !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && plain && d->H >= 8) {
+      int n2 = cout > 32 ? 4 : (cout > 16 ? 2 : 1);
+      if (v2_nf) n2 = (int)v2_nf;
+      while (n2 > 1 && (n2 / 2) * 16 >= cout) n2 /= 2;
+      int c2 = (cin >= 32 && a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
+      if (v2_ck && a.xf != 2) c2 = (int)v2_ck;
+      a.tilesY = fi_cdiv(d->H, 16);
+      a.nct = fi_cdiv(cout, n2 * 16);
+      const int wgs = v2_wgs ? (int)v2_wgs : (n2 == 1 ? 4 : (n2 == 2 ? 3 : 2));   // what the register counts admit
+      return d->dtype == FI_F16 ? fi_conv_fwd_v2_f16_k3(n2, c2, wgs, a, st) : fi_conv_fwd_v2_bf16_k3(n2, c2, wgs, a, st);
+    }
+  }
   if (f32) return d->ksize == 3 ? fi_conv_fwd_f32_k3(th, nf, ck, a, st) : fi_conv_fwd_f32_k1(th, nf, ck, a, st);
   if (d->dtype == FI_F16) return d->ksize == 3 ? fi_conv_fwd_f16_k3(th, nf, ck, a, st) : fi_conv_fwd_f16_k1(th, nf, ck, a, st);
   return d->ksize == 3 ? fi_conv_fwd_bf16_k3(th, nf, ck, a, st) : fi_conv_fwd_bf16_k1(th, nf, ck, a, st);

@@ -1,0 +1,9 @@
+// Instantiations of the persistent forward kernel (conv_fwd_v2_kernel, conv_impl.h) for dtype=bf16, ksize=3.
+#include "conv_impl.h"
+
+#define V2_CASE(NF_, CK_) if (nf == NF_ && ck == CK_) return launch_conv_fwd_v2<bf16_t, 3, NF_, CK_>(a, wgs_per_cu, st);
+
+int fi_conv_fwd_v2_bf16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st) {
+  V2_CASE(1, 16) V2_CASE(2, 16) V2_CASE(4, 16) V2_CASE(1, 32) V2_CASE(2, 32) V2_CASE(4, 32)
+  return FI_ERR_UNSUPPORTED;
+}

@@ -657,6 +657,445 @@ static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel, second form: PERSISTENT workgroups with the next stage in flight
+// ---------------------------------------------------------------------------------------------
+// The one-tile kernel above hides a tile's staging round trip behind OTHER resident workgroups, which needs many of them:
+// small register tiles (most layers run one 16-channel output fragment per wave), the input tile re-staged once per
+// 16-channel slab, 3-5 us of every 6-10 us workgroup life spent waiting.  This form turns that around for the layers
+// where it pays (measured per layer, conv_api.hip picks): a workgroup walks MANY (tile, chunk) stages, and while the
+// MFMAs of stage s run from LDS the global loads of stage s+1 are already in flight into registers (one register set:
+// committed to LDS after the barrier that ends stage s, re-issued at once for stage s+2).  With the latency covered
+// inside the workgroup it can afford the big register tile -- 64 pixels x 16*NF channels per wave, 16*NF MFMAs per
+// 4 + NF LDS fragment reads -- and an unrolled tap loop, at 1-2 workgroups per CU.
+//   * a workgroup keeps ONE output-channel slab for all its tiles: single-chunk layers (Cin <= CK) stage their weights
+//     once per workgroup, not once per tile;
+//   * the epilogue of a finished tile is issued AFTER the next stage's LDS commit and the re-issue of the loads behind
+//     it: its global stores then sit behind those loads in the (in-order, shared) vmcnt queue and are a whole MFMA phase
+//     old by the time anything waits on that queue -- the wait for the next tile never waits for store acknowledgements;
+//   * XCD-aware: XCD x (= blockIdx % 8) owns the x-th eighth of the tiles and its workgroups stride through it together,
+//     so the halo overlap of neighbouring tiles and the slabs re-reading one tile meet in that XCD's L2.
+// Same LDS layouts, MFMA operand mapping, input transforms (XF) and plain epilogue (bias, one vector store per fragment,
+// BatchNorm statistics) as conv_fwd_kernel; 16-row tiles only.
+#ifndef FI_V2_UNROLL
+#define FI_V2_UNROLL 3
+#endif
+template <typename T, int KS, int NF, int CK, int XF>
+__global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
+  constexpr int TH = 16;
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
+  constexpr int CKP = FiLdsStride<T, CK>::value;
+  constexpr int KC = KK * CK;
+  constexpr int KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
+  constexpr int WKP = FiLdsStride<T, KCP>::value;
+  constexpr int BN = NF * 16;
+  constexpr int MF = TH / 4;
+  constexpr int VPP = CK / VG;
+  static_assert(CK > VG, "whole-vector channel counts only");
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);                           // [XH*XW][CKP]
+  T* ws = xs + XH * XW * CKP;                                   // [BN][WKP]
+  float* red = reinterpret_cast<float*>(ws + BN * WKP);         // [4 waves][BN][2]: statistics of a finished tile
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
+  const int H = a.H, W = a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0);
+  const T* x1 = reinterpret_cast<const T*>(a.x1);
+  const T* wg = reinterpret_cast<const T*>(a.w);
+
+  // ---- this workgroup's work: tiles t0 + k*tstep (k = 0, 1, ...) below t_end, output slab ct, nchunk chunks per tile
+  const int ntile = a.N * a.tilesY * a.tilesX;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, gx = gridDim.x >> 3;     // grid: a multiple of 8 * nct (host)
+  const int tpx = (ntile + 7) >> 3;
+  const int t_end = min(ntile, (xcd + 1) * tpx);
+  const int ct = q % a.nct, tstep = gx / a.nct;
+  const int t_first = xcd * tpx + q / a.nct;
+  if (t_first >= t_end) return;
+  const int nchunk = (cin + CK - 1) / CK;
+  const bool w_resident = nchunk == 1;
+
+  f32x4 acc[MF][NF];
+
+  // ---- staging geometry (as conv_fwd_kernel: a thread owns one vector column of the halo tile / the weight slab)
+  constexpr int XCOLS = XW * VPP, XRPP = 256 / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
+  constexpr int WCOLS = KK * VPP, WRPP = 256 / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
+  static_assert(XRPP >= 1 && WRPP >= 1, "tile too wide for 256 threads");
+  constexpr int NS = XF == 2 ? 4 : 1;
+  // Every phase below recomputes its thread geometry from an OPAQUE copy of the thread id: derived from `tid` directly,
+  // hipcc hoists a few dozen per-thread invariants (row offsets, LDS addresses, masks) of all phases out of the stage loop
+  // and keeps them live across it -- on top of the register set in flight and the accumulators that is hundreds of spills.
+#define FI_V2_GEOMETRY()                                                     \
+  int tid_ = tid;                                                            \
+  asm volatile("" : "+v"(tid_));                                             \
+  const int xcol = tid_ % XCOLS, xrow0 = tid_ / XCOLS;                       \
+  const int xpx = xcol / VPP, xv = xcol % VPP;                               \
+  const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;                      \
+  const int wcol = tid_ % WCOLS, wrow0 = tid_ / WCOLS;                       \
+  const int wt = wcol / VPP, wv = wcol % VPP;                                \
+  const int wlds0 = wrow0 * WKP + wt * CK + wv * VG;                         \
+  (void)xlds0; (void)wlds0; (void)xrow0; (void)wrow0; (void)xpx; (void)wt; (void)xv; (void)wv
+
+  vec_t xr[XPASS][NS];          // the ONE register set of the stage in flight
+  vec_t wr[WPASS];
+
+  auto issue = [&](int tile, int cb, bool with_w) __attribute__((always_inline)) {
+    FI_V2_GEOMETRY();
+    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
+    const int grp = a.gimages > 0 ? n / a.gimages : 0;
+    {
+      const int ci = cb + xv * VG;
+      const int cc = ci < cin ? ci : 0;
+      const bool first = cc < a.c0;
+      const int csrc = first ? cc : cc - a.c0;
+      const int cstride = first ? a.c0 : a.c1;
+      const T* colbase = (first ? x0 : x1) + csrc;
+      const int ns = (XF != 0 && first && a.bcast0) ? n - grp * a.gimages : n;
+      const int xcx = min(max(tx * 16 + xpx - HALO, 0), W - 1);
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int gy = ty * TH + xrow0 + p * XRPP - HALO;
+        const int cy = min(max(gy, 0), H - 1);
+        if constexpr (XF == 2) {
+          const T* src = colbase + (size_t)((ns * 2 * H + 2 * cy) * (2 * W) + 2 * xcx) * cstride;
+          xr[p][0] = *reinterpret_cast<const vec_t*>(src);
+          xr[p][1] = *reinterpret_cast<const vec_t*>(src + cstride);
+          xr[p][2] = *reinterpret_cast<const vec_t*>(src + (size_t)2 * W * cstride);
+          xr[p][3] = *reinterpret_cast<const vec_t*>(src + (size_t)(2 * W + 1) * cstride);
+        } else {
+          xr[p][0] = *reinterpret_cast<const vec_t*>(colbase + (size_t)((ns * H + cy) * W + xcx) * cstride);
+        }
+      }
+    }
+    if (with_w) {
+      const int ci = cb + wv * VG;
+      const T* colbase = wg + (size_t)wt * cin + (ci < cin ? ci : 0);
+#pragma unroll
+      for (int p = 0; p < WPASS; ++p) {
+        const int gco = ct * BN + wrow0 + p * WRPP;
+        wr[p] = *reinterpret_cast<const vec_t*>(colbase + (size_t)(gco < cout ? gco : 0) * (KK * cin));
+      }
+    }
+  };
+
+  auto commit = [&](int tile, int cb, bool with_w) __attribute__((always_inline)) {
+    FI_V2_GEOMETRY();
+    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
+    const int grp = a.gimages > 0 ? n / a.gimages : 0;
+    {
+      const int ci = cb + xv * VG;
+      const bool chok = ci < cin;
+      const int cc = chok ? ci : 0;
+      const bool first = cc < a.c0;
+      const int csrc = first ? cc : cc - a.c0;
+      const int cstride = first ? a.c0 : a.c1;
+      const int xgx = tx * 16 + xpx - HALO;
+      const bool xcolok = xrow0 < XRPP && xgx >= 0 && xgx < W && chok;
+      float sc[VG], sh[VG];
+      bool xf = false, drop = false;
+      float slope = 1.f;
+      uint64_t seed = 0;
+      if constexpr (XF != 0) {
+        const float* scp = first ? a.t0.scale : a.t1.scale;
+        const float* shp = first ? a.t0.shift : a.t1.shift;
+        slope = first ? a.t0.slope : a.t1.slope;
+        xf = scp != nullptr;
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          sc[j] = xf ? scp[(size_t)grp * cstride + csrc + j] : 1.f;
+          sh[j] = xf ? shp[(size_t)grp * cstride + csrc + j] : 0.f;
+        }
+        drop = XF == 1 && first && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+        if (drop) {
+          seed = a.t0.seed + (uint64_t)grp * a.t0.seed_gstride;
+          if (a.t0.seed_offset) seed += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+        }
+      }
+      auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
+        float f[VG];
+        VecWords<T>::unpack(raw, f);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          const float v = f[j] * sc[j] + sh[j];
+          f[j] = v > 0.f ? v : v * slope;
+        }
+        if (drop) {
+#pragma unroll
+          for (int g4 = 0; g4 < VG / 4; ++g4) {
+            uint32_t rr[4];
+            fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
+          }
+        }
+        return VecWords<T>::pack(f);
+      };
+      const int nl = n - grp * a.gimages;
+      const int xcx = min(max(xgx, 0), W - 1);
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        const int gy = ty * TH + py - HALO;
+        if (xrow0 < XRPP && py < XH) {
+          const bool ok = xcolok && gy >= 0 && gy < H;
+          vec_t val;
+          if constexpr (XF == 2) {
+            // z of the four source pixels, then the element-wise maximum (of the ROUNDED values, as fi_maxpool2_fwd sees them)
+            float best[VG], cand[VG];
+            VecWords<T>::unpack(xf ? xform(xr[p][0], 0) : xr[p][0], best);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              VecWords<T>::unpack(xf ? xform(xr[p][k], 0) : xr[p][k], cand);
+#pragma unroll
+              for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
+            }
+            val = fi_vec_select(ok, VecWords<T>::pack(best));      // values are exactly representable: pack does not round
+          } else if constexpr (XF == 1) {
+            const int cy = min(max(gy, 0), H - 1);
+            const unsigned vix = (unsigned)((nl * H + cy) * W + xcx) * (unsigned)(cstride / VG) + (unsigned)(csrc / VG);
+            val = fi_vec_select(ok, xf ? xform(xr[p][0], vix) : xr[p][0]);
+          } else {
+            val = fi_vec_select(ok, xr[p][0]);
+          }
+          *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
+        }
+      }
+    }
+    if (with_w) {
+      const int ci = cb + wv * VG;
+      const bool chok = ci < cin && wrow0 < WRPP;
+#pragma unroll
+      for (int p = 0; p < WPASS; ++p) {
+        const int co = wrow0 + p * WRPP;
+        if (wrow0 < WRPP && co < BN) {
+          *reinterpret_cast<vec_t*>(&ws[wlds0 + p * (WRPP * WKP)]) = fi_vec_select(chok && ct * BN + co < cout, wr[p]);
+        }
+      }
+    }
+  };
+
+  auto mma = [&]() __attribute__((always_inline)) {
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    const int li = lane_ & 15, kg = lane_ >> 4;
+    if constexpr (CK >= KSTEP) {
+#pragma unroll FI_V2_UNROLL
+      for (int t = 0; t < KK; ++t) {
+        const int r = t / KS, s = t % KS;
+#pragma unroll
+        for (int ks = 0; ks < CK / KSTEP; ++ks) {
+          frag_t b[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            b[f] = *reinterpret_cast<const frag_t*>(&ws[(f * 16 + li) * WKP + t * CK + ks * KSTEP + kg * KV]);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int row = wave * MF + m;
+            const frag_t av =
+                *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + ks * KSTEP + kg * KV]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(b[f], av, acc[m][f]);
+          }
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int ks = 0; ks < KCP / KSTEP; ++ks) {
+        const int k0 = ks * KSTEP + kg * KV;
+        int t = k0 / CK;
+        const int cil = k0 % CK;
+        if (t > KK - 1) t = KK - 1;
+        const int r = t / KS, s = t % KS;
+        frag_t b[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) b[f] = *reinterpret_cast<const frag_t*>(&ws[(f * 16 + li) * WKP + k0]);
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const int row = wave * MF + m;
+          const frag_t av = *reinterpret_cast<const frag_t*>(&xs[((row + r) * XW + li + s) * CKP + cil]);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(b[f], av, acc[m][f]);
+        }
+      }
+    }
+  };
+
+  auto epilogue = [&](int tile) __attribute__((always_inline)) {
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    const int li = lane_ & 15, kg = lane_ >> 4;
+    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
+    const int grp = a.gimages > 0 ? n / a.gimages : 0;
+    float ssum[NF][4], ssq[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[f][r] = ssq[f][r] = 0.f;
+    const int gx_ = tx * 16 + li;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int cg = ct * BN + f * 16 + kg * 4;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (a.bias && cg + r < cout) ? a.bias[cg + r] : 0.f;
+      const bool second = cg >= a.co0;
+      const int cdst = second ? a.co1 : a.co0;
+      const int cofs = second ? cg - a.co0 : cg;
+      void* ybase = second ? a.y1 : a.y0;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const int gy = ty * TH + wave * MF + m;
+        if (gy < H && gx_ < W && cg < cout) {
+          const size_t o = (((size_t)n * H + gy) * W + gx_) * cdst + cofs;
+          float v[4];
+          T e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = from_f32<T>(acc[m][f][r] + bv[r]);
+            v[r] = to_f32(e[r]);
+          }
+          if (ybase) {
+            typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type out_t;
+            out_t qv;
+            memcpy(&qv, e, sizeof(qv));
+            *reinterpret_cast<out_t*>(reinterpret_cast<T*>(ybase) + o) = qv;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ssum[f][r] += v[r];
+            ssq[f][r] += v[r] * v[r];
+          }
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = ssum[f][r], qq = ssq[f][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            qq += __shfl_xor(qq, o, 64);
+          }
+          if (li == 0) {
+            red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
+            red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = qq;
+          }
+        }
+      fi_lds_barrier();
+      if (tid < BN * 2) {
+        const int c = tid >> 1, which = tid & 1;
+        const int co = ct * BN + c;
+        if (co < cout) {
+          double tot = 0.0;
+#pragma unroll
+          for (int wv_ = 0; wv_ < 4; ++wv_) tot += (double)red[(wv_ * BN + c) * 2 + which];
+          const int slot = (blockIdx.x + tile) & (FI_STATS_SLOTS - 1);
+          atomicAdd(&a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2 + which], tot);
+        }
+      }
+      // `red` is rewritten only after the barrier that ends the next stage: every wave has passed this point by then
+    }
+  };
+
+  // ---- the stage loop.  `cur` = the stage whose operands are in LDS, `nxt` = the stage in flight / about to be committed.
+  //      The first trip has no current stage: it only commits stage 0 and issues stage 1 (one copy of every phase in the
+  //      code: the register allocator sees each of them once).
+  if (KCP > KC) {  // zero the K padding once: never overwritten by commit
+    constexpr int PV = (KCP - KC) / VG;
+    for (int i = tid; i < BN * PV; i += 256) {
+      vec_t z;
+      memset(&z, 0, sizeof(z));
+      *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
+    }
+  }
+  int ctile = -1, cchunk = 0;                    // current stage (none yet)
+  int ntile_ = t_first, nchunk_ = 0;             // next stage
+  bool first_w = true;
+  issue(ntile_, 0, true);
+  while (true) {
+    if (ctile >= 0) {
+      if (cchunk == 0) {
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      mma();
+      fi_lds_barrier();                          // every wave has read the current stage out of LDS (only LDS is ordered)
+    }
+    const int dtile = ctile;
+    const bool done = ctile >= 0 && cchunk == nchunk - 1;
+    const bool have_next = ntile_ < t_end;
+    if (have_next) {
+      commit(ntile_, nchunk_ * CK, first_w || !w_resident);     // waits for the loads issued a stage ago
+      first_w = false;
+      ctile = ntile_;
+      cchunk = nchunk_;
+      nchunk_ = cchunk + 1;
+      if (nchunk_ == nchunk) {
+        nchunk_ = 0;
+        ntile_ = ctile + tstep;
+      }
+      if (ntile_ < t_end) issue(ntile_, nchunk_ * CK, !w_resident);
+    }
+    // the finished tile's stores go out BEHIND the loads just issued (see the header comment)
+    if (done) epilogue(dtile);
+    if (!have_next) break;
+    fi_lds_barrier();                            // the next stage is in LDS (ds_write only; the loads just issued stay in flight)
+  }
+}
+
+#undef FI_V2_GEOMETRY
+// more than 64 KB of dynamic LDS per workgroup has to be allowed per kernel (once; gfx950 has 160 KB per CU)
+static inline bool fi_allow_big_lds(const void* kernel) {
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
+
+template <typename T, int KS, int NF, int CK>
+static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
+  constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = 16 + 2 * HALO, KK = KS * KS;
+  constexpr int KSTEP = DT<T>::KSTEP;
+  constexpr int KC = KK * CK, KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
+  constexpr int CKP = FiLdsStride<T, CK>::value, WKP = FiLdsStride<T, KCP>::value;
+  constexpr int BN = NF * 16;
+  const size_t lds = (size_t)(XH * XW * CKP + BN * WKP) * sizeof(T) + (size_t)4 * BN * 2 * sizeof(float);
+  const long ntile = (long)a.N * a.tilesX * a.tilesY;
+  // grid: a multiple of 8 (XCDs) x nct, at most wgs_per_cu per CU, no more than one workgroup per (tile, slab)
+  long per_xcd = 32L * wgs_per_cu / a.nct;
+  const long tpx = (ntile + 7) / 8;
+  if (per_xcd > tpx) per_xcd = tpx;
+  if (per_xcd < 1) per_xcd = 1;
+  const long blocks = 8 * per_xcd * a.nct;
+  const dim3 g((unsigned)blocks), b(256);
+  if (a.xf == 0) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_v2_kernel<T, KS, NF, CK, 0>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_v2_kernel<T, KS, NF, CK, 0>), g, b, lds, st, a);
+  } else if (a.xf == 1) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_v2_kernel<T, KS, NF, CK, 1>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_v2_kernel<T, KS, NF, CK, 1>), g, b, lds, st, a);
+  } else {
+    if constexpr (KS == 3 && CK * (int)sizeof(T) <= 32) {        // pooled sources: 4 raw vectors per staged one -> narrow chunks only
+      static const bool big = fi_allow_big_lds((const void*)conv_fwd_v2_kernel<T, KS, NF, CK, 2>);
+      (void)big;
+      hipLaunchKernelGGL((conv_fwd_v2_kernel<T, KS, NF, CK, 2>), g, b, lds, st, a);
+    } else {
+      return FI_ERR_UNSUPPORTED;
+    }
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad:  dw[co][t][ci] += sum_pix dy[pix][co] * x[pix + tap t][ci]
 //   GEMM view M = Cout, N = Cin (per tap), K = pixels.  A workgroup owns a (16*NFO) x (16*NFI)
 //   channel tile and walks spatial tiles (grid-stride), staging the x halo tile and the dy tile

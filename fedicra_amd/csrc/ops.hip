@@ -60,9 +60,15 @@ static inline int grid_for(long work_items, int per_block) {
 // running <- (1 - momentum) * running + momentum * batch, products rounded separately: the stand-alone finalize and the
 // fused finalize+apply kernel must move the running statistics identically (ops.conv_bn_stats_only relies on it)
 __device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int c, float momentum, float mu, float unb) {
+  // products rounded separately, in every inlined copy: the hip __fmul_rn / __fadd_rn helpers are themselves compiled with
+  // contraction on (hipcc fused one product into an fma in some kernels and not in others -- an ulp between kernels that
+  // must agree), so this is plain arithmetic under an explicit contract(off)
+#pragma clang fp contract(off)
   const float keep = 1.f - momentum;
-  rmean[c] = __fadd_rn(__fmul_rn(keep, rmean[c]), __fmul_rn(momentum, mu));
-  rvar[c] = __fadd_rn(__fmul_rn(keep, rvar[c]), __fmul_rn(momentum, unb));
+  const float a0 = keep * rmean[c], b0 = momentum * mu;
+  rmean[c] = a0 + b0;
+  const float a1 = keep * rvar[c], b1 = momentum * unb;
+  rvar[c] = a1 + b1;
 }
 
 __global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,

@@ -105,6 +105,13 @@ int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t
                         const void* x0, const void* x1, const void* w, const float* bias, void* y, double* stats,
                         long stats_group_stride, void* stream);
 
+/* Measurement hook (tools/kbench.py, tests): which forward kernel fi_conv2d_fwd[_fused] launches.  v2 = -1: the library's
+ * per-layer choice (default), 0: the one-tile kernel everywhere, 1: the persistent kernel wherever it applies (16-bit
+ * storage, 3x3, whole-vector channel counts, plain epilogue); nf / ck / wgs_per_cu = 0 keep the defaults, else force the
+ * persistent kernel's slab width (1, 2, 4 fragments of 16 channels), channel chunk (16, 32) and workgroups per CU.
+ * Process-wide, not thread-safe: results never depend on it (same arithmetic, same order). */
+int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu);
+
 /* dw[co][k*k][ci] += sum_pixels dy * x  (fp32);  dbias[co] += sum_pixels dy (fp32, may be NULL).
  * d->co0 = Cout, co1 ignored; dy is [N,H,W,Cout].  With a caller-owned `workspace` of at least
  * fi_conv2d_wgrad_workspace(d) bytes the reduction is two-stage and DETERMINISTIC (per-workgroup partial

@@ -179,3 +179,74 @@ def test_probe_heatmaps_declines_when_it_does_not_apply():
     ctx2.seed_offset = torch.zeros(1, dtype=torch.int32, device=DEV)
     with ops.use_context(ctx2):
         assert net.probe_heatmaps(x, [1, 2]) is None          # autograd on
+
+
+V2_CASES = [
+    # (N, H, W, c0, c1, cout, groups, xf-kind, stats, two_dst)
+    (4, 32, 32, 16, 0, 16, 1, "none", True, False),
+    (4, 40, 56, 32, 0, 32, 2, "xf", True, False),
+    (6, 33, 21, 16, 16, 16, 3, "xf", True, False),          # ragged tile edges, chunk spanning both sources
+    (4, 32, 48, 64, 0, 128, 2, "drop", True, False),
+    (4, 16, 16, 128, 128, 64, 1, "xf", False, False),
+    (6, 24, 24, 16, 0, 32, 3, "pool", True, False),
+    (2, 64, 64, 64, 0, 512, 1, "xf", "only", False),         # the auxiliary head: statistics-only
+    (3, 48, 32, 64, 0, 64, 1, "none", False, True),          # dgrad w.r.t. a concatenation: two destinations
+    (8, 16, 16, 256, 0, 256, 4, "shared", True, False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", range(len(V2_CASES)))
+def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
+    """conv_fwd_v2_kernel (persistent workgroups, next stage in flight) against conv_fwd_kernel on the same operands: the same
+    products accumulated in the same order -> the same bits, for every slab width / chunk / residency the host may pick."""
+    from fedicra_amd import _lib as L
+    N, H, W, c0, c1, cout, G, kind, stats, two = V2_CASES[case]
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(100 + case)
+    pool, shared = kind == "pool", kind == "shared"
+    B = N // G
+    hs, ws_ = (2 * H, 2 * W) if pool else (H, W)
+    x0 = torch.randn(B if shared else N, hs, ws_, c0, generator=gen).to(DEV).to(td)
+    x1 = torch.randn(N, H, W, c1, generator=gen).to(DEV).to(td) if c1 else None
+    w = (torch.randn(cout, 3, 3, c0 + c1, generator=gen) * 0.05).to(DEV).to(td)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    soff = torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    t0 = t1 = None
+    if kind != "none":
+        drop = (L.DROP_RNG_ELEM, 0.25, 0xABCDE, None, soff) if kind in ("drop", "shared") else None
+        t0 = L.in_xform(_coef(G, c0, gen), 0.01, pool=pool, drop=drop, seed_group_stride=0x10001)
+        if c1:
+            t1 = L.in_xform(_coef(G, c1, gen), 0.0)
+
+    def run():
+        st = torch.zeros(G, L.STATS_SLOTS, cout, 2, dtype=torch.float64, device=DEV) if stats else None
+        if two:
+            ya = torch.empty(N, H, W, cout // 2, dtype=td, device=DEV)
+            yb = torch.empty(N, H, W, cout // 2, dtype=td, device=DEV)
+            L.conv2d_fwd(x0, x1, w, None, ya, yb, None, ksize=3)
+            return (ya, yb), None
+        y = None if stats == "only" else torch.empty(N, H, W, cout, dtype=td, device=DEV)
+        if kind == "none":
+            L.conv2d_fwd(x0, x1, w, bias, y, None, None if st is None else st[0], ksize=3)
+        else:
+            L.conv2d_fwd_fused(x0, t0, x1, t1, w, bias, y, st, ksize=3, groups=G, cout=cout, shared0=shared)
+        return (y,), st
+
+    try:
+        L.conv_tuning(0)
+        want, st_want = run()
+        nfs = [n for n in (1, 2, 4) if n == 1 or (n // 2) * 16 < cout]
+        for nf in nfs:
+            for ck in (16, 32):
+                for wgs in (1, 3):
+                    L.conv_tuning(1, nf, ck, wgs)
+                    got, st_got = run()
+                    torch.cuda.synchronize()
+                    for a, b in zip(got, want):
+                        if a is not None:
+                            assert torch.equal(a, b), (nf, ck, wgs, float((a.float() - b.float()).abs().max()))
+                    if st_want is not None:
+                        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=1e-9, atol=1e-9), (nf, ck, wgs)
+    finally:
+        L.conv_tuning(-1)
