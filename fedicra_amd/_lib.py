@@ -241,7 +241,7 @@ def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False,
 
 
 def conv_tuning(v2=-1, nf=0, ck=0, wgs_per_cu=0):
-    """fi_conv_tuning: measurement / test hook (which forward kernel is launched); results never depend on it."""
+    """fi_conv_tuning: measurement / test hook (which forward kernel is launched; -1 = the library's per-layer choice)."""
     _chk(lib().fi_conv_tuning(int(v2), int(nf), int(ck), int(wgs_per_cu)), "fi_conv_tuning")
 
 

@@ -118,6 +118,17 @@ template <> struct VecWords<f16_t> {
   }
 };
 
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32_dpp (quad xor 1, quad
+// xor 2, half-row mirror, row mirror).  The same pairings as an xor butterfly -- fp addition commutes, so the same bits --
+// without its four ds_bpermute round trips through the LDS unit (what __shfl_xor compiles to).
+__device__ __forceinline__ float fi_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // wave-wide sum via xor shuffles (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -50,7 +50,7 @@ static long wgrad_blocks() {
 // kernel wherever it applies; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
 static long g_tune[4] = {-1, 0, 0, 0};
 static long env_v2() {
-  static long v = env_long("FI_V2", 0);
+  static long v = env_long("FI_V2", 2);      // 2 = the measured per-layer rule
   return v;
 }
 extern "C" int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu) {
@@ -108,6 +108,7 @@ static int fill_xform(const FiInXform* t, InXform* o, int is_second) {
     o->seed_gstride = t->seed_group_stride;
     o->seed_offset = t->seed_offset;
   }
+  if (!(t->slope >= 0.f && t->slope <= 1.f)) return FI_ERR_UNSUPPORTED;   // the loaders evaluate max(v, slope * v)
   o->scale = t->scale;
   o->shift = t->shift;
   o->slope = t->slope;
@@ -211,15 +212,19 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
     const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
     const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
-    if (v2 && !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && plain && d->H >= 8) {
-      int n2 = cout > 32 ? 4 : (cout > 16 ? 2 : 1);
+    // default (-1 / FI_V2 unset): where tools/kbench2.py measured it ahead -- the channel-rich plain launches (grad-path forward,
+    // dgrad, ALA: 64^2 128->128 32.7 -> 26.6 us, 256->128 58.6 -> 43.8 us at 12 images); the batched fused launches stay
+    // with the one-tile kernel (profiles/r02_c_kbench2.txt)
+    const bool v2_auto = v2 == 2 && a.xf == 0 && cin >= 128 && cout >= 128;
+    if ((v2 == 1 || v2_auto) && !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && plain && d->H >= 8) {
+      int n2 = v2_auto ? 2 : (cout > 32 ? 4 : (cout > 16 ? 2 : 1));
       if (v2_nf) n2 = (int)v2_nf;
       while (n2 > 1 && (n2 / 2) * 16 >= cout) n2 /= 2;
       int c2 = (cin >= 32 && a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
       if (v2_ck && a.xf != 2) c2 = (int)v2_ck;
       a.tilesY = fi_cdiv(d->H, 16);
       a.nct = fi_cdiv(cout, n2 * 16);
-      const int wgs = v2_wgs ? (int)v2_wgs : (n2 == 1 ? 4 : (n2 == 2 ? 3 : 2));   // what the register counts admit
+      const int wgs = v2_wgs ? (int)v2_wgs : (n2 == 1 || v2_auto ? 4 : (n2 == 2 ? 3 : 2));
       return d->dtype == FI_F16 ? fi_conv_fwd_v2_f16_k3(n2, c2, wgs, a, st) : fi_conv_fwd_v2_bf16_k3(n2, c2, wgs, a, st);
     }
   }

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         float f[VG];
 #pragma unroll
         for (int j = 0; j < VG; ++j) {
-          float v = to_f32(u.e[j]) * sc[j] + sh[j];
-          f[j] = v > 0.f ? v : v * slope;
+          const float v = to_f32(u.e[j]) * sc[j] + sh[j];
+          f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked), one select less
         }
         if (drop) {
 #pragma unroll
@@ -585,12 +585,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float s = ssum[f][r], q = ssq[f][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {  // over the 16 pixel lanes of this kg group
-          s += __shfl_xor(s, o, 64);
-          q += __shfl_xor(q, o, 64);
-        }
+        const float s = fi_row16_sum(ssum[f][r]), q = fi_row16_sum(ssq[f][r]);   // over the 16 pixel lanes of this kg group
         if (li == 0) {
           red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
           red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = q;
@@ -821,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < VG; ++j) {
           const float v = f[j] * sc[j] + sh[j];
-          f[j] = v > 0.f ? v : v * slope;
+          f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
         }
         if (drop) {
 #pragma unroll
@@ -977,12 +972,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s = ssum[f][r], qq = ssq[f][r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            s += __shfl_xor(s, o, 64);
-            qq += __shfl_xor(qq, o, 64);
-          }
+          const float s = fi_row16_sum(ssum[f][r]), qq = fi_row16_sum(ssq[f][r]);
           if (li == 0) {
             red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
             red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = qq;

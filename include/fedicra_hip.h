@@ -109,7 +109,9 @@ int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t
  * per-layer choice (default), 0: the one-tile kernel everywhere, 1: the persistent kernel wherever it applies (16-bit
  * storage, 3x3, whole-vector channel counts, plain epilogue); nf / ck / wgs_per_cu = 0 keep the defaults, else force the
  * persistent kernel's slab width (1, 2, 4 fragments of 16 channels), channel chunk (16, 32) and workgroups per CU.
- * Process-wide, not thread-safe: results never depend on it (same arithmetic, same order). */
+ * Process-wide, not thread-safe.  The kernels compute the same products in fp32; only the ORDER in which the channel chunks
+ * are accumulated follows the chunk width, so two configurations agree to fp32 round-off (a bf16 output may differ in its
+ * last bit for a few elements in 10^5), and bit for bit when their chunk widths agree. */
 int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu);
 
 /* dw[co][k*k][ci] += sum_pixels dy * x  (fp32);  dbias[co] += sum_pixels dy (fp32, may be NULL).

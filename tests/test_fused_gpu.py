@@ -198,8 +198,10 @@ V2_CASES = [
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", range(len(V2_CASES)))
 def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
-    """conv_fwd_v2_kernel (persistent workgroups, next stage in flight) against conv_fwd_kernel on the same operands: the same
-    products accumulated in the same order -> the same bits, for every slab width / chunk / residency the host may pick."""
+    """conv_fwd_v2_kernel (persistent workgroups, next stage in flight) against conv_fwd_kernel on the same operands, for every
+    slab width / chunk / residency the host may pick: the same fp32 products; the channel chunks are accumulated in the
+    order the chunk width gives, so outputs agree to the last bit or two of the storage type (and exactly wherever both
+    kernels chunk alike)."""
     from fedicra_amd import _lib as L
     N, H, W, c0, c1, cout, G, kind, stats, two = V2_CASES[case]
     td = TD[dtype]
@@ -243,10 +245,14 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
                     L.conv_tuning(1, nf, ck, wgs)
                     got, st_got = run()
                     torch.cuda.synchronize()
+                    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
                     for a, b in zip(got, want):
                         if a is not None:
-                            assert torch.equal(a, b), (nf, ck, wgs, float((a.float() - b.float()).abs().max()))
+                            d = (a.float() - b.float()).abs()
+                            assert bool((d <= 2 * ulp * b.float().abs() + 1e-3).all()), (nf, ck, wgs, float(d.max()))
+                            assert float((d > 0).float().mean()) < 2e-3, (nf, ck, wgs, float((d > 0).float().mean()))
                     if st_want is not None:
-                        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=1e-9, atol=1e-9), (nf, ck, wgs)
+                        # per-tile fp32 partial sums: the one-tile kernel may have picked another tile height, i.e. another grouping
+                        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=2e-6, atol=1e-6), (nf, ck, wgs)
     finally:
         L.conv_tuning(-1)

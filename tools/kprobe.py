@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""One conv layer, a few launches per forward-kernel configuration: the target of rocprofv3 --pmc runs (tools/kprobe.sh).
+    python tools/kprobe.py --H 128 --cin 64 --cout 512 [--groups 1] [--cfg v1 nf4ck32w2 ...] [--stats-only]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fedicra_amd import _lib as L  # noqa: E402
+
+
+def parse_cfg(s):
+    if s == "v1":
+        return (0, 0, 0, 0)
+    import re
+    m = re.fullmatch(r"nf(\d)ck(\d+)w(\d)", s)
+    return (1, int(m.group(1)), int(m.group(2)), int(m.group(3)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--H", type=int, default=128)
+    ap.add_argument("--cin", type=int, default=64)
+    ap.add_argument("--c1", type=int, default=0)
+    ap.add_argument("--cout", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--stats-only", action="store_true")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cfg", nargs="+", default=["v1", "nf4ck32w2"])
+    a = ap.parse_args()
+    td, dev = torch.bfloat16, "cuda"
+    G, N, H = a.groups, a.batch * a.groups, a.H
+    x0 = torch.randn(N, H, H, a.cin, device=dev).to(td)
+    x1 = torch.randn(N, H, H, a.c1, device=dev).to(td) if a.c1 else None
+    w = (torch.randn(a.cout, 3, 3, a.cin + a.c1, device=dev) * 0.05).to(td)
+    bias = torch.randn(a.cout, device=dev)
+    y = None if a.stats_only else torch.empty(N, H, H, a.cout, device=dev, dtype=td)
+    st = torch.zeros(G, L.STATS_SLOTS, a.cout, 2, dtype=torch.float64, device=dev)
+    t0 = L.in_xform(torch.rand(2, G, a.cin, device=dev) + 0.5, 0.01) if a.fused else None
+    for c in a.cfg:
+        L.conv_tuning(*parse_cfg(c))
+        for _ in range(a.reps):
+            if a.fused:
+                L.conv2d_fwd_fused(x0, t0, x1, None, w, bias, y, st, ksize=3, groups=G, cout=a.cout)
+            else:
+                L.conv2d_fwd(x0, x1, w, bias, y, None, st[0], ksize=3, cout=a.cout)
+        torch.cuda.synchronize()
+    L.conv_tuning(-1)
+
+
+main()
