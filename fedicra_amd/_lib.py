@@ -696,9 +696,9 @@ def fedopt_step(mode, cur, agg, m, v, eta, beta1, beta2, tau):
                               f(1.0 - beta1), f(beta2), f(1.0 - beta2), f(tau), stream()), "fi_fedopt_step")
 
 
-def ala_update(w, temp, grad, local, glob, eta):
+def ala_update(w, temp, grad, local, glob, eta, skip=None):
     _chk(lib().fi_ala_update(ptr(_dev(w)), ptr(temp), ptr(grad), ptr(local), ptr(glob), C.c_long(w.numel()),
-                             C.c_float(eta), stream()), "fi_ala_update")
+                             C.c_float(eta), ptr(skip), stream()), "fi_ala_update")
 
 
 def global_avgmax(x, avg, mx, amax):

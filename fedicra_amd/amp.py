@@ -51,6 +51,14 @@ class GradScaler:
         self._lazy(optimizer.model.flat_params.device)
         return optimizer.step_scaled(self._scale, self._found_inf)
 
+    def unscale_range(self, grads):
+        """scaler.unscale_ for one flat gradient range (an optimizer that does not step: the ALA loop's AdamW has lr = 0,
+        flower_common.py:560,576-584): grads /= scale in place, the found-inf flag raised on inf/NaN.  Returns the flag
+        (device fp32[1]) for kernels that must not consume an overflowed gradient."""
+        self._lazy(grads.device)
+        L.amp_unscale(grads, self._scale, self._found_inf)
+        return self._found_inf
+
     def update(self, new_scale=None):
         if not self._enabled or self._scale is None:
             return

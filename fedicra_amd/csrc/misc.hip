@@ -520,7 +520,8 @@ extern "C" int fi_fedopt_step(int mode, float* cur, const float* agg, float* m, 
 
 __global__ void ala_update_kernel(float* __restrict__ w, float* __restrict__ temp, const float* __restrict__ grad,
                                   const float* __restrict__ local, const float* __restrict__ global, long n,
-                                  float eta) {
+                                  float eta, const float* __restrict__ skip) {
+  if (skip && skip[0] != 0.f) return;            // the batch's gradients overflowed (amp): nothing moves
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float d = local[i] - global[i];
     float wi = w[i] - eta * (grad[i] * d);
@@ -530,11 +531,11 @@ __global__ void ala_update_kernel(float* __restrict__ w, float* __restrict__ tem
   }
 }
 extern "C" int fi_ala_update(float* w, float* temp, const float* grad, const float* local, const float* global,
-                             long n, float eta, void* stream) {
+                             long n, float eta, const float* skip, void* stream) {
   if (!w || !temp || !grad || !local || !global) return FI_ERR_NULL;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(ala_update_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, w, temp, grad,
-                     local, global, n, eta);
+                     local, global, n, eta, skip);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -50,16 +50,6 @@ class DeviceWeights:
 
 
 # ------------------------------------------------------------------------------ evaluation
-def _batch_images(dataloader, img_class, device):
-    xs, ys = [], []
-    for b in dataloader:
-        x, y = b["image"], b["label"]
-        x = x.reshape((-1,) + tuple(x.shape[-2:])) if img_class == "faz" else x.reshape((-1,) + tuple(x.shape[-3:]))
-        xs.append(x.unsqueeze(1) if img_class == "faz" else x)
-        ys.append(y.reshape((-1,) + tuple(y.shape[-2:])))
-    return torch.cat(xs).float().to(device), torch.cat(ys).to(torch.uint8).to(device)
-
-
 def dice_table(logits_nchw_view, labels_u8, classes):
     """Per-image integer counts {|P&G|, |P|, |G|} for classes 1..C-1 (val_2D.py:66-74) -> int64 [n, C-1, 3]."""
     lg = logits_nchw_view.permute(0, 2, 3, 1)
@@ -119,26 +109,51 @@ def metrics_from_counts(tp, npred, ngt, total, hd95=float("nan")):
     return [dice, float(hd95), recall, precision, jc, spec, ravd]
 
 
+EVAL_CHUNK = 16        # validation images per forward (the reference: one, val_2D.py:25-74)
+
+
 def evaluate(args, model, dataloader, amp=False):
-    """flower_common.py:122-136."""
+    """flower_common.py:122-136.  The validation forward runs in chunks of EVAL_CHUNK images: eval-mode BatchNorm makes the
+    images independent, so the metrics are those of the reference's one-image-at-a-time loop, while the activations of a
+    chunk (the full-resolution 512-channel head of unet_lc_multihead is ~0.6 GB per 384^2 image) stay bounded whatever
+    the size of the split."""
     dev = next(model.parameters()).device
-    x, y = _batch_images(dataloader, args.img_class, dev)
     was_training = model.training
     model.eval()                                          # val_2D.py:40
-    with torch.no_grad():
-        logits = model(x)[0]
+    ncls = args.num_classes
+    metric_list = np.zeros((ncls - 1, len(VAL_METRICS)))
+    seen = 0
+    xs, ys, held = [], [], 0
+
+    def flush():
+        nonlocal metric_list, seen, xs, ys, held
+        if not xs:
+            return
+        x, y = torch.cat(xs).float().to(dev), torch.cat(ys).to(torch.uint8).to(dev)
+        xs, ys, held = [], [], 0
+        with torch.no_grad():
+            logits = model(x)[0]
+        counts = dice_table(logits, y, ncls).cpu().numpy()
+        hd = hd95_table(logits, y, ncls)
+        total = int(y.shape[-1] * y.shape[-2])
+        for i in range(counts.shape[0]):
+            metric_list += np.array([metrics_from_counts(*map(int, counts[i, c]), total, hd[i, c]) for c in range(ncls - 1)])
+        seen += counts.shape[0]
+
+    for b in dataloader:
+        x, y = b["image"], b["label"]
+        x = x.reshape((-1,) + tuple(x.shape[-2:])) if args.img_class == "faz" else x.reshape((-1,) + tuple(x.shape[-3:]))
+        xs.append(x.unsqueeze(1) if args.img_class == "faz" else x)
+        ys.append(y.reshape((-1,) + tuple(y.shape[-2:])))
+        held += xs[-1].shape[0]
+        if held >= EVAL_CHUNK:
+            flush()
+    flush()
     model.train(was_training) if was_training else None
-    counts = dice_table(logits, y, args.num_classes).cpu().numpy()
-    hd = hd95_table(logits, y, args.num_classes)
-    total = int(y.shape[-1] * y.shape[-2])
-    metric_list = np.zeros((args.num_classes - 1, len(VAL_METRICS)))
-    for i in range(counts.shape[0]):
-        metric_list += np.array([metrics_from_counts(*map(int, counts[i, c]), total, hd[i, c])
-                                 for c in range(args.num_classes - 1)])
-    n_images = len(dataloader.dataset) if hasattr(dataloader, "dataset") else counts.shape[0]
+    n_images = len(dataloader.dataset) if hasattr(dataloader, "dataset") else seen
     metric_list = metric_list / n_images
     metrics_ = {}
-    for class_i in range(args.num_classes - 1):
+    for class_i in range(ncls - 1):
         for mi, name in enumerate(VAL_METRICS):
             metrics_["val_{}_{}".format(class_i + 1, name)] = metric_list[class_i, mi]
     for mi, name in enumerate(VAL_METRICS):
@@ -157,6 +172,9 @@ class MyModel(nn.Module):
         self.trainloader = trainloader
         self.valloader = valloader
         self.amp = (getattr(args, "amp", 0) == 1)
+        if self.amp:                                          # flower_common.py:466-468
+            from .amp import GradScaler
+            self.scaler = GradScaler()
         if self.args.strategy in ["FedICRA"]:
             self.start_phase = True
         self.fedaa_weights = None
@@ -287,10 +305,19 @@ class MyModel(nn.Module):
             temp.zero_grad()
             out = temp(x)[0]
             loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
-            loss.backward()
-            ops.flush_wgrad()
-            # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel)
-            L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta)
+            skip = None
+            if self.amp:                                      # :576-584: scaled backward, unscale (the lr = 0 step), update
+                self.scaler.scale(loss).backward()
+                ops.flush_wgrad()
+                skip = self.scaler.unscale_range(tg[s:e])
+            else:
+                loss.backward()
+                ops.flush_wgrad()
+            # w <- clamp(w - eta*grad*(local-global), 0, 1); temp <- global + (local-global)*w   (one kernel); an
+            # overflowed amp batch moves nothing (the reference would pour its inf/NaN gradients into w)
+            L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta, skip)
+            if self.amp:
+                self.scaler.update()
             st["iter"].add_(1)                                # fresh dropout masks for the next batch, replay included
             return loss
 

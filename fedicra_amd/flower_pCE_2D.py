@@ -161,7 +161,7 @@ class MyClient(BaseClient):
             opt.set_lr(self.current_lr, self.current_iter)
             iters = config["iters"]
             dev = self._net().flat_state.device
-            hist = torch.zeros((iters, 3), dtype=torch.float32, device=dev)
+            hist = torch.zeros((iters, 5), dtype=torch.float32, device=dev)   # loss, ce, lc, tree, crf
             n_b = len(self.trainloader)
         rec = None
         for i_iter in range(iters):
@@ -200,6 +200,9 @@ class MyClient(BaseClient):
                 hist[i_iter, 1] = rec.loss_ce
                 if rec.loss_lc is not None:
                     hist[i_iter, 2] = rec.loss_lc
+                if getattr(rec, "loss_tree", None) is not None:      # the tree-energy procedure's extra terms
+                    hist[i_iter, 3] = rec.loss_tree
+                    hist[i_iter, 4] = rec.loss_crf
                 self.current_iter += 1
                 lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
                 self.current_lr = lr_
@@ -211,6 +214,7 @@ class MyClient(BaseClient):
         args = self.args
         h = hist.cpu().numpy()                               # ONE sync per round
         self.last_losses = h[:, 0].tolist()
+        self.last_terms = [(float(r[0]), float(r[1]), float(r[3]), float(r[4]), float(r[2])) for r in h]   # loss, ce, tree, crf, lc
         # ---- pack general metrics (:160-175)
         image = x[1, :, :, :]
         image = (image - image.min()) / (image.max() - image.min())

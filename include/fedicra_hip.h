@@ -397,9 +397,11 @@ int fi_fedopt_step(int mode, float* cur, const float* agg, float* m, float* v, l
                    float one_minus_beta1, float beta2, float one_minus_beta2, float tau, void* stream);
 /* FedICRA ALA element-wise step (/root/reference/code/flower_common.py:590-602):
  *   w    = clamp(w - eta * grad * (local - global), 0, 1)
- *   temp = global + (local - global) * w                                                   */
+ *   temp = global + (local - global) * w
+ * skip (device fp32[1], may be NULL): when non-zero nothing is written -- the GradScaler's found-inf flag of an `--amp 1`
+ * batch whose scaled gradients overflowed (:576-584; the reference would feed the inf/NaN gradients into w).           */
 int fi_ala_update(float* w, float* temp, const float* grad, const float* local, const float* global, long n,
-                  float eta, void* stream);
+                  float eta, const float* skip, void* stream);
 
 /* ---------------------------------------------------------------- PCS helpers --------------
  * PersonalizedChannelSelection (unet.py:103-144): global avg / max pool over H*W per (n,c);

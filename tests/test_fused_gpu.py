@@ -252,7 +252,8 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
                             assert bool((d <= 2 * ulp * b.float().abs() + 1e-3).all()), (nf, ck, wgs, float(d.max()))
                             assert float((d > 0).float().mean()) < 2e-3, (nf, ck, wgs, float((d > 0).float().mean()))
                     if st_want is not None:
-                        # per-tile fp32 partial sums: the one-tile kernel may have picked another tile height, i.e. another grouping
-                        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=2e-6, atol=1e-6), (nf, ck, wgs)
+                        # statistics of the STORED outputs (a few of which differ in their last bit), per-tile fp32 partial sums grouped
+                        # by the tile height each kernel picked
+                        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=1e-4, atol=1e-3), (nf, ck, wgs)
     finally:
         L.conv_tuning(-1)

@@ -321,3 +321,37 @@ def test_metric_aggregation_matches_reference_golden(golden):
     fout = fit_metrics_aggregation_fn(fm)
     assert list(fout.keys()) == [str(k) for k in g["fit_out_keys"]]
     np.testing.assert_array_equal(np.array([float(v) for v in fout.values()]), g["fit_out_vals"])
+
+
+def test_run_federated_host_logic_follows_the_launcher_and_server_loop(tmp_path):
+    """fedicra_amd.run_federated without a GPU: the launcher's flags and defaults (flower_runner.py:18-55), the client
+    script's argument checks (flower_pCE_2D.py:262-276), the round schedule and config dicts of MyServer.fit / fit_config
+    (flower_common.py:256, flower_pCE_2D.py:320-338) and the checkpoint names (flower_common.py:343-365)."""
+    import pytest
+    from fedicra_amd import run_federated as rf
+    p = rf.build_parser()
+    a = p.parse_args(["--exp", "e1"])
+    assert (a.procedure, a.base_lr, a.model, a.img_class, a.max_iterations, a.iters, a.eval_iters, a.alpha, a.batch_size,
+            a.tree_loss_weight, a.strategy, a.img_size, a.amp, a.rep_iters) == \
+        ("flower_pCE_2D", 0.01, "unet", "faz", 30000, 10, 20, 0.5, 12, 0.1, "FedAvg", 256, 0, 3)
+    a.snapshot_dir = str(tmp_path)
+    sup = rf.check_args(a, 5)
+    assert sup == ["scribble_noisy", "keypoint", "block", "box", "scribble"] and (a.num_classes, a.in_chns) == (2, 1)
+    assert a.min_num_clients == 5 and a.root_path == "../data/FAZ_h5" and a.snapshot_path.endswith("e1")
+    assert list(rf.round_schedule(a))[:3] == [10, 20, 30] and list(rf.round_schedule(a))[-1] == 30000
+    assert rf.make_config(a, 20, "fit") == {"iter_global": 20, "iters": 10, "eval_iters": 20, "batch_size": 12, "stage": "fit"}
+    import os
+    b = os.path.basename
+    assert [b(n) for n in rf.checkpoint_names(a, 40, 0.87654321)] == ["iter_40_dice_0.8765.pth", "unet_best_model.pth"]
+    assert [b(n) for n in rf.checkpoint_names(a, 40, client_id=3, client_dice=0.5)] == \
+        ["client_3_iter_40_dice_0.5.pth", "client_3_unet_best_model.pth"]
+    assert [b(n) for n in rf.checkpoint_names(a, 3000)] == ["iter_3000.pth"]
+    assert [b(n) for n in rf.checkpoint_names(a, 3000, client_id=1)] == ["client_1_iter_3000.pth"]
+    bad = p.parse_args(["--exp", "e", "--eval_iters", "15"])
+    with pytest.raises(AssertionError):
+        rf.check_args(bad, 2)                                    # eval_iters must be a multiple of iters
+    icra = p.parse_args(["--exp", "e", "--strategy", "FedICRA", "--model", "unet"])
+    with pytest.raises(AssertionError):
+        rf.check_args(icra, 2)                                   # FedICRA needs the LC model
+    odoc = p.parse_args(["--exp", "e", "--img_class", "odoc"])
+    assert rf.check_args(odoc, 5)[3] == "keypoint" and (odoc.num_classes, odoc.in_chns) == (3, 3)
