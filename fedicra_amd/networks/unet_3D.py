@@ -14,8 +14,9 @@ import torch
 import torch.nn as nn
 from torch.nn import init
 
-from .. import ops3d
-from .unet import _DTYPES, default_compute_dtype
+from .. import ops, ops3d
+from ..flat import FlatStoreMixin
+from .unet import _DTYPES, PersonalizedChannelSelection, default_compute_dtype
 
 
 def _weights_init_kaiming(m):
@@ -71,11 +72,16 @@ class UnetUp3_CT(nn.Module):
     def _run(self, skip, low):
         up = ops3d.upsample3d2x(low)
         if up.shape[1:4] != skip.shape[1:4]:
-            raise NotImplementedError("odd volume sizes (the reference pads the skip tensor, utils.py:272-274)")
+            # utils.py:271-274 pads the skip by 2 * [offset // 2, offset // 2, 0] with offset = up - skip.  MaxPool3d floors,
+            # so the only offset besides 0 is -1 (an odd skip), for which that rule crops W by 2, H and D by 1: torch.cat then
+            # raises in the reference too ("Sizes of tensors must match except in dimension 1") -- same error class here.
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: skip {} vs up-sampled {} (odd volume "
+                               "size; the reference's padding rule does not reconcile them)".format(
+                                   tuple(skip.shape[1:4]), tuple(up.shape[1:4])))
         return self.conv._run(skip, up)
 
 
-class unet_3D(nn.Module):
+class unet_3D(FlatStoreMixin, nn.Module):
 
     def __init__(self, feature_scale=4, n_classes=21, is_deconv=True, in_channels=3, is_batchnorm=True):
         super().__init__()
@@ -105,6 +111,7 @@ class unet_3D(nn.Module):
             elif isinstance(m, nn.BatchNorm3d):
                 init_weights(m, init_type="kaiming")
         self._fi_dtype = None
+        self._fi_finish_init()                  # one flat fp32 state / gradient buffer: fused AdamW, aggregation, ALA
 
     def compute_dtype(self):
         return self._fi_dtype if self._fi_dtype is not None else default_compute_dtype()
@@ -113,7 +120,9 @@ class unet_3D(nn.Module):
         self._fi_dtype = _DTYPES[dtype] if isinstance(dtype, str) else dtype
         return self
 
-    def forward(self, inputs):
+    def _trunk(self, inputs, gate=None):
+        """-> (fp32 logits NDHWC, encoder features, decoder features); ``gate(center) -> center`` hooks the site-specific
+        channel selection of unet_3D_lc in after the deepest block."""
         dt = self.compute_dtype()
         x = inputs.permute(0, 2, 3, 4, 1).contiguous().to(dt)            # NCDHW -> dense NDHWC (plumbing)
         conv1 = self.conv1._run(x)
@@ -121,6 +130,8 @@ class unet_3D(nn.Module):
         conv3 = self.conv3._run(ops3d.maxpool3d(conv2))
         conv4 = self.conv4._run(ops3d.maxpool3d(conv3))
         center = self.center._run(ops3d.maxpool3d(conv4))
+        if gate is not None:
+            center = gate(center)
         center = ops3d.dropout(center, self.dropout1.p, self.training, owner=self.dropout1)
         up4 = self.up_concat4._run(conv4, center)
         up3 = self.up_concat3._run(conv3, up4)
@@ -128,8 +139,83 @@ class unet_3D(nn.Module):
         up1 = self.up_concat1._run(conv1, up2)
         up1 = ops3d.dropout(up1, self.dropout2.p, self.training, owner=self.dropout2)
         final = ops3d.conv3d(up1, None, self.final, norm=False, y_f32=True)
+        return final, [conv1, conv2, conv3, conv4, center], [up4, up3, up2, up1]
+
+    def forward(self, inputs):
+        final, _, _ = self._trunk(inputs)
         return final.permute(0, 4, 1, 2, 3)                              # NCDHW view of the fp32 logits
 
     @staticmethod
     def apply_argmax_softmax(pred):
         return torch.softmax(pred, dim=1)
+
+
+def _ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3)
+
+
+class unet_3D_lc(unet_3D):
+    """BASELINE.json configs[4]: "3D U-Net + per-client adapter heads".  The reference has no 3D federated model (nothing
+    calls net_factory_3d): this is ``unet_3D`` with the two personalisation devices of the reference's
+    2D ``UNet_LC`` lifted to volumes, keeping its conventions so that the FedICRA client code drives it unchanged --
+
+      * a ``PersonalizedChannelSelection`` (networks/unet.py:103-144; its fc layers are 1x1 convolutions on pooled vectors,
+        so the 2D module is used as it is) on the deepest block (``pcs_num = 1``): one-hot site embedding, global average /
+        maximum over the volume, shared MLP, sigmoid gate ``x * h + x``; held in a plain python list like
+        ``LCEncoder.pcs_list`` (unet.py:172-177: never optimised, never communicated) with the ``if not emb_idx`` rule
+        (unet.py:186: 0 means "own client");
+      * an auxiliary adapter head (``Decoder_Head.dsn_head``, unet.py:243-285, as Conv3d 3^3 -> InstanceNorm3d -> ReLU ->
+        Dropout3d(0.1) -> Conv3d 1^3 without bias) on the second decoder level;
+      * ``forward(x, emb_idx=None)`` returns UNet_LC's list: ``[logits, [conv1..center], up4, up3, up2, up1, heatmaps, aux]``
+        with the heat-map ``[B, C, 1, 1, 1]`` last in its list (flower_pCE_2D.py:134 reads ``[6][-1]``).
+
+    Parameters a federation keeps local under FedICRA's naming rule (names containing ``final`` / ``up_concat``, the 3D
+    counterparts of ``out_conv`` / ``up1..4``, flower_common.py:506) are listed in ``LOCAL_KEYS``."""
+
+    LOCAL_KEYS = ("final", "up_concat4", "up_concat3", "up_concat2", "up_concat1")
+
+    def __init__(self, feature_scale=4, n_classes=2, is_deconv=True, in_channels=1, is_batchnorm=True, client_num=8,
+                 client_id=0, head_width=4):
+        unet_3D.__init__(self, feature_scale, n_classes, is_deconv, in_channels, is_batchnorm)
+        self.n_client, self.cid = client_num, client_id
+        filters = [int(x / feature_scale) for x in [64, 128, 256, 512, 1024]]
+        hid = head_width * filters[1]
+        self.dsn_head = nn.Sequential(nn.Conv3d(filters[1], hid, 3, 1, 1), nn.InstanceNorm3d(hid), nn.ReLU(inplace=True),
+                                      nn.Dropout3d(0.10), nn.Conv3d(hid, n_classes, 1, bias=False))
+        init_weights(self.dsn_head[0], init_type="kaiming")
+        init_weights(self.dsn_head[4], init_type="kaiming")
+        self.pcs_list = [PersonalizedChannelSelection(filters[4], client_num)]      # plain list on purpose (quirk 1)
+        for pcs in self.pcs_list:
+            for q in pcs.parameters():
+                q.requires_grad_(False)
+        self._fi_finish_init()
+
+    def _apply(self, fn, *a, **k):
+        for pcs in getattr(self, "pcs_list", []):
+            pcs._apply(fn, *a, **k)
+        return super()._apply(fn, *a, **k)
+
+    def set_compute_dtype(self, dtype):
+        super().set_compute_dtype(dtype)
+        for pcs in self.pcs_list:
+            pcs._fi_dtype = self._fi_dtype
+        return self
+
+    def forward(self, inputs, emb_idx=None):
+        who = self.cid if not emb_idx else emb_idx                         # unet.py:186 (0 means "own")
+        hm = []
+
+        def gate(center):
+            B, d, h, w, C = center.shape
+            emb = torch.zeros((B, self.n_client), device=center.device)
+            emb[:, who] = 1
+            y, hmap = self.pcs_list[0]._run(center.reshape(B, d * h, w, C), emb)    # pooled over the whole volume
+            hm.append(hmap)
+            return y.reshape(B, d, h, w, C)
+        final, enc, dec = self._trunk(inputs, gate)
+        z = ops3d.conv3d(dec[2], None, self.dsn_head[0], norm=True)
+        z = ops3d.dropout(z, self.dsn_head[3].p, self.training, owner=self.dsn_head[3], channel=True)
+        aux = ops3d.conv3d(z, None, self.dsn_head[4], norm=False, y_f32=True)
+        heat = hm[0].reshape(hm[0].shape[0], 1, 1, 1, -1)
+        return [_ncdhw(final), [_ncdhw(t) for t in enc]] + [_ncdhw(t) for t in dec] + \
+               [[None, None, None, None, _ncdhw(heat)], _ncdhw(aux)]

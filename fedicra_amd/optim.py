@@ -24,6 +24,17 @@ import torch
 from . import _lib as L
 
 
+def _adopt_foreign_grads(params, active):
+    """Ops that hand autograd an ordinary gradient tensor (the 3D surface, plumbing glue) instead of accumulating into the
+    parameter's sink of the flat gradient buffer: move such gradients into the sink so that the fused step sees them."""
+    for n in active:
+        p = params[n]
+        sink = getattr(p, "_fi_gview", None)
+        if sink is not None and p.grad.data_ptr() != sink.data_ptr():
+            sink.copy_(p.grad.reshape(sink.shape) if p.grad.shape != sink.shape else p.grad)
+            p.grad = sink
+
+
 class FusedAdamW:
     MAX_GROUPS = 8
 
@@ -87,6 +98,7 @@ class FusedAdamW:
         active = [n for n in self._names if params[n].grad is not None]
         if not active:
             return
+        _adopt_foreign_grads(params, active)
         gi, ranges = self._group_for(active)
         P, G = self.model.flat_params, self.model.flat_grads
         if scale is not None:

@@ -129,7 +129,7 @@ class RefLCEncoder(nn.Module):
 
     def forward(self, x, emb_idx=None):
         who = self.cid if not emb_idx else emb_idx          # unet.py:186 (quirk 2)
-        emb = torch.zeros(x.size(0), self.n_client)
+        emb = torch.zeros(x.size(0), self.n_client, dtype=x.dtype)      # x's dtype: fp64 yardstick runs of the oracle
         emb[:, who] = 1
         stages = [self.in_conv, self.down1, self.down2, self.down3, self.down4]
         feats, hmaps = [], []
