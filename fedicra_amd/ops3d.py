@@ -102,9 +102,15 @@ class _Conv3d(Function):
 
 
 class _MaxPool3d(Function):
+    """nn.MaxPool3d(2): windows that do not fit are dropped (floor), i.e. an odd extent loses its last plane."""
+
     @staticmethod
     def forward(ctx, x):
         N, D, H, W, Cc = x.shape
+        ctx.full = None
+        if (D | H | W) & 1:
+            ctx.full = x.shape
+            x = x[:, :D // 2 * 2, :H // 2 * 2, :W // 2 * 2].contiguous()
         y = torch.empty((N, D // 2, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
         L.maxpool3d_fwd(x, y)
         ctx.save_for_backward(x)
@@ -115,6 +121,10 @@ class _MaxPool3d(Function):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x)
         L.maxpool3d_bwd(x, dy.contiguous(), dx)
+        if ctx.full is not None:                        # the dropped planes receive no gradient
+            out = torch.zeros(ctx.full, dtype=dx.dtype, device=dx.device)
+            out[:, :x.shape[1], :x.shape[2], :x.shape[3]] = dx
+            dx = out
         return dx
 
 
