@@ -78,7 +78,14 @@ def test_unet3d_lc_forward_and_backward_against_the_cpu_restatement(dtype):
         worst = max(worst, rel)
         # ReLU'(v) jumps at 0: an InstanceNorm output at round-off distance from 0 (some always are among 10^5..10^6) flips
         # a whole gradient path between two correct fp32 implementations -- the bound is that of the 2D full-size tests
-        assert rel < (3e-2 if dtype == "fp32" else 2.5e-1), (n, rel)
+        if dtype == "fp32":
+            assert rel < 3e-2, (n, rel)
+        else:
+            # 16-bit storage through five levels down to 2^3 voxels per instance (InstanceNorm over 8 values): element-wise
+            # bounds are meaningless there; direction and size of every gradient tensor must still agree
+            cos = float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))
+            ratio = float(a.norm() / b.norm().clamp_min(1e-12))
+            assert cos > 0.97 and 0.9 < ratio < 1.1, (n, cos, ratio)
     print(f"unet_3D_lc {dtype}: worst relative gradient error {worst:.2e}")
 
 
