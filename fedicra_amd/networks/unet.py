@@ -90,15 +90,17 @@ class ConvBlock(_FiModule):
         z = ops.conv_bn_act(x0, x1, s[0], s[1], s[2].negative_slope, self.dropout_p, "elem")
         return ops.conv_bn_act(z, None, s[4], s[5], s[6].negative_slope, 0.0)
 
-    def _probe(self, s0, s1, groups, pool=False, first=False):
-        """This block inside the batched no-grad forward (ops.probe_*): sources and result are raw activations."""
+    def _probe(self, s0, s1, groups, pool=False, first=False, store=True):
+        """This block inside the batched no-grad forward (ops.probe_*): sources and result are raw activations.  store =
+        False: nobody reads the block's output (the last decoder block when no head sits on it) -- its second convolution
+        runs for the BatchNorm statistics only and writes nothing."""
         s = self.conv_conv
         if first:
             r = ops.probe_first_conv_bn(s0, s[0], s[1], s[2].negative_slope, groups)
         else:
             r = ops.probe_conv_bn(s0, s1, s[0], s[1], s[2].negative_slope, groups, pool=pool)
         drop = ops._probe_drop(self.dropout_p, s[1], groups)
-        return ops.probe_conv_bn(r, None, s[4], s[5], s[6].negative_slope, groups, in_drop=drop)
+        return ops.probe_conv_bn(r, None, s[4], s[5], s[6].negative_slope, groups, in_drop=drop, store=store)
 
     def forward(self, x):
         return self._out(self._run(self._in(x)))
@@ -321,13 +323,15 @@ class _DecoderBase(_FiModule):
     def _probe(self, skips, x4, groups):
         """Decoder of the batched no-grad forward: nothing is returned -- what it leaves behind are the BatchNorm running
         statistics of every block and head, moved `groups` times as the separate forwards would."""
-        def up(blk, lo, skip):
+        def up(blk, lo, skip, store=True):
             u = ops.upsample2x(ops.probe_conv(lo, blk.conv1x1, groups))
-            return blk.conv._probe(skip, u, groups)
+            return blk.conv._probe(skip, u, groups, store=store)
+        read = {idx for _, idx in self._heads()}
         o = [None, up(self.up1, x4, skips[3])]
         o.append(up(self.up2, o[1], skips[2]))
         o.append(up(self.up3, o[2], skips[1]))
-        o.append(up(self.up4, o[3], skips[0]))
+        # the full-resolution output feeds the (skipped) logits convolution and, in the multi-head decoder, a head
+        o.append(up(self.up4, o[3], skips[0], store=4 in read))
         for head, idx in self._heads():
             ops.probe_conv_bn(o[idx], None, head[0], head[1], 0.0, groups, store=False)
 

@@ -1,10 +1,14 @@
-run() { echo -n "$1: "; env $1 timeout 30 python bench.py --no-cpu-baseline --no-roofline --steps 300 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
-run X=0
-run FI_WGRAD_BLOCKS=256
-run FI_WGRAD_BLOCKS=384
-run FI_WGRAD_BLOCKS=1024
+#!/bin/bash
+# Launch-geometry knobs of the one-tile conv kernels under the bench workload (configs[2]); bash tools/knob_sweep.sh <tag>
+TAG=${1:-r02}; OUT=gpurun_out/${TAG}_knob_sweep.txt; : > $OUT
+run() { echo "== $*" >> $OUT; env "$@" python bench.py --no-cpu-baseline --no-fp32 --no-roofline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['config']['ms_per_aggregation_round'])" >> $OUT; }
+run FI_NOP=1
 run FI_TARGET_BLOCKS=512
-run FI_TARGET_BLOCKS=2048
-run FI_MIN_BLOCKS=256
-run FI_MIN_BLOCKS=1024
-run X=1
+run FI_TARGET_BLOCKS=4096
+run FI_MIN_BLOCKS=2048
+run FI_FWD_LDS_CAP=65536
+run FI_V2=0
+run FI_WGRAD_BLOCKS=1024
+cat $OUT
