@@ -89,6 +89,7 @@ class Federation:
         # steady-state rounds: the one-off convergence loop of a client's FIRST personalised round (>= 11 ALA epochs,
         # flower_common.py:604-618) is not what "ms per aggregation round" means; every timed round runs exactly one epoch
         self.model.start_phase = False
+        self.model.verbose = False                       # stdout carries the one JSON line
         self.client = MyClient(args, self.model, self.loader, self.loader)
         all_n = client_num_batches(FEDERATION, a.batch)          # FedAvg weights n_k = len(trainloader_k) of the 8 sites
         absent = None

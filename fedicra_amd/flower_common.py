@@ -281,7 +281,8 @@ class MyModel(nn.Module):
         if torch.sum(old_local[n0:n0 + o0] - glob[n0:n0 + o0]) == 0:      # :520-522 (a sum test, as written)
             return
         if config["iter_global"] <= 50:                       # :524-526
-            print("skip", config)
+            if getattr(self, "verbose", True):
+                print("skip", config)
             return
         local_keys = [n for n, _ in net.named_parameters() if any(k in n for k in ALA_KEYS)]
         ranges = net.param_ranges(local_keys)
@@ -352,8 +353,9 @@ class MyModel(nn.Module):
                     loss = st["loss"]
                 losses.append(float(loss.item()))             # one host sync per ALA epoch (the reference: per batch)
                 count += 1
-                print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,
-                      self.start_phase)
+                if getattr(self, "verbose", True):             # the reference prints this line every epoch (:606-607)
+                    print("Client:", self.args.cid, "\tStd:", np.std(losses[-num_pre_loss:]), "\tALA epochs:", count,
+                          self.start_phase)
                 if not self.start_phase:                      # :611-612
                     break
                 if len(losses) > num_pre_loss and np.std(losses[-num_pre_loss:]) < threshold:      # :615

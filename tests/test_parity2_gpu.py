@@ -125,9 +125,9 @@ def test_base_client_fit_evaluate_get_parameters_two_rounds_against_the_oracle(p
             assert np.abs(a - b).max() < 5e-2 * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max())
         else:
             # four AdamW steps of ~lr each per weight: an element whose tiny gradient changes sign between two fp32
-            # realisations moves by up to 2 * lr; the bulk agrees far better
+            # realisations moves by up to 2 * lr per step (0.08 in all); the bulk agrees far better
             d = np.abs(a - b)
-            assert d.max() < 1.5e-2 * max(1.0, np.abs(b).max()) and d.mean() < 3e-3 * max(1.0, np.abs(b).max()), (k, d.max(), d.mean())
+            assert d.max() < 5e-2 * max(1.0, np.abs(b).max()) and d.mean() < 3e-3 * max(1.0, np.abs(b).max()), (k, d.max(), d.mean())
     # ---- evaluate through the protocol, folded by the strategy; Dice of the aggregated model vs the oracle's
     evs = []
     for cid in range(K):

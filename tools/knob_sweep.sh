@@ -3,7 +3,7 @@
 TAG=${1:-r02}; OUT=gpurun_out/${TAG}_knob_sweep.txt; : > $OUT
 run() { echo "== $*" >> $OUT; env "$@" python bench.py --no-cpu-baseline --no-fp32 --no-roofline 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['config']['ms_per_aggregation_round'])" >> $OUT; }
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['config']['ms_per_aggregation_round'])" >> $OUT; }
 run FI_NOP=1
 run FI_TARGET_BLOCKS=512
 run FI_TARGET_BLOCKS=4096
