@@ -355,3 +355,42 @@ def test_run_federated_host_logic_follows_the_launcher_and_server_loop(tmp_path)
         rf.check_args(icra, 2)                                   # FedICRA needs the LC model
     odoc = p.parse_args(["--exp", "e", "--img_class", "odoc"])
     assert rf.check_args(odoc, 5)[3] == "keypoint" and (odoc.num_classes, odoc.in_chns) == (3, 3)
+
+
+def _const_term_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fedicra_amd.comm import WeightedAllReduce
+    from fedicra_amd.flower_common import DeviceWeights
+    n_k = [3, 5][rank]
+    state = torch.arange(6, dtype=torch.float32) + 10 * rank
+    cnt = torch.tensor([rank + 1, 7], dtype=torch.int64)
+    absent = (DeviceWeights(torch.full((6,), 100.0), torch.tensor([4, 4], dtype=torch.int64)), 2)
+    agg = WeightedAllReduce(n_k, device=None, constant_term=absent)
+    out = agg.aggregate(DeviceWeights(state, cnt))
+    q.put((rank, out.state.clone(), out.counters.clone(), agg.total))
+    dist.destroy_process_group()
+
+
+def test_weighted_allreduce_constant_term_counts_the_clients_no_rank_hosts():
+    """bench.py with fewer GPUs than the federation has clients: the absent clients' n_k * state enters the weighted sum
+    once (rank 0 adds it), the total weight includes them, every rank gets the same mean (world_size 2, gloo)."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    ps = [ctx.Process(target=_const_term_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+    base = torch.arange(6, dtype=torch.float32)
+    want = (3 * base + 5 * (base + 10) + 2 * 100.0) / 10
+    want_c = ((torch.tensor([1, 7]) * 3 + torch.tensor([2, 7]) * 5 + torch.tensor([4, 4]) * 2).double() / 10).to(torch.int64)
+    for rank, st, cn, total in res:
+        assert total == 10 and torch.allclose(st, want) and torch.equal(cn, want_c), (rank, st, cn)
