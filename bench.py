@@ -205,6 +205,7 @@ def roofline_pass(client, a, dtype_name):
     conv_flops = sum(v["flops"] for k, v in prof.items() if k[0].startswith("conv"))
     roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": None, "kernel": f"{fname} (all shapes of the FedICRA iteration)/{dtype_name}",
+            "profile_command": "python bench.py --roofline-only  (profiles/*_roofline_kernel_stats.csv, *_pmc_traffic.json)",
             "launches_per_step": calls / float(iters), "avg_us": round(avg_ms * 1e3, 2),
             "arithmetic_intensity_flop_per_byte": round(ai, 1),
             "frac_of_mfma_peak": round(flops / (avg_ms * 1e-3) / 1e12 / mf_peak, 4),
@@ -271,6 +272,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode rate reported beside the headline")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the instrumented eager iterations of the roofline object (the command rocprofv3 is pointed at "
+                         "for profiles/*_roofline_kernel_stats.csv and the PMC traffic passes: same launch mix)")
     a = ap.parse_args()
     a.classes = 2 if a.in_chns == 1 else 3
 
@@ -289,6 +293,11 @@ def main():
     _lib.lib()
 
     fed = Federation(a, rank, world, dev, a.dtype)
+    if a.roofline_only:
+        roof = roofline_pass(fed.client, a, a.dtype)
+        if rank == 0:
+            print(json.dumps({"roofline": roof}), flush=True)
+        return
     elapsed, agg_ms = fed.timed(a.warmup, a.steps, dist)
     value = a.steps * a.batch * world / elapsed
 

@@ -21,6 +21,8 @@ int fi_conv_wgrad_quad_f16_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f16_k3(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_fwd_v2_bf16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_v2_f16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_thin_f16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -54,7 +56,7 @@ static long env_v2() {
   return v;
 }
 extern "C" int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu) {
-  if ((nf && nf != 1 && nf != 2 && nf != 4) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 8) return FI_ERR_SHAPE;
+  if ((nf && nf != 1 && nf != 2 && nf != 4) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 16) return FI_ERR_SHAPE;
   g_tune[0] = v2;
   g_tune[1] = nf;
   g_tune[2] = ck;
@@ -212,6 +214,25 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
     const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
     const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+    // thin-layer form (conv_thin_kernel): the whole filter in registers -- Cin <= 32, Cout <= 32, one destination.
+    // Chosen by default where tools/kbench2.py --thin measured it ahead of the one-tile kernel (profiles/r02_h_*): every
+    // 16-channel-output layer (1.3-1.55x), 32 outputs only with the plain transforming loader (1.1x; dropout / pooled
+    // sources: 0.97-1.03x, left with the one-tile kernel)
+    {
+      const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && cin <= 32 && cout <= 32 &&
+                        cout % 4 == 0 && d->co1 == 0 && plain && d->H >= 8 &&
+                        (long)d->N * d->H * d->W * (cin > cout ? cin : cout) * 2 * (a.xf == 2 ? 4 : 1) < (1L << 32);
+      const int n3 = cout > 16 ? 2 : 1;
+      const int c3 = (cin > 16 && a.xf != 2) ? 32 : 16;
+      const bool t0_drop = a.t0.drop_mode != FI_DROP_NONE;
+      const bool thin_auto = v2 == 2 && (n3 == 1 || (a.xf == 1 && !t0_drop));
+      if (fits && cin <= c3 && (v2 == 3 || thin_auto)) {
+        a.tilesY = fi_cdiv(d->H, 16);
+        a.nct = 1;
+        const int wgs = v2_wgs ? (int)v2_wgs : (n3 == 1 ? 8 : 2);
+        return d->dtype == FI_F16 ? fi_conv_thin_f16(n3, c3, wgs, a, st) : fi_conv_thin_bf16(n3, c3, wgs, a, st);
+      }
+    }
     // default (-1 / FI_V2 unset): where tools/kbench2.py measured it ahead -- the channel-rich plain launches (grad-path forward,
     // dgrad, ALA: 64^2 128->128 32.7 -> 26.6 us, 256->128 58.6 -> 43.8 us at 12 images); the batched fused launches stay
     // with the one-tile kernel (profiles/r02_c_kbench2.txt)

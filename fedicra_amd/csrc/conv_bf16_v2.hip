@@ -7,3 +7,10 @@ int fi_conv_fwd_v2_bf16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hi
   V2_CASE(1, 16) V2_CASE(2, 16) V2_CASE(4, 16) V2_CASE(1, 32) V2_CASE(2, 32) V2_CASE(4, 32)
   return FI_ERR_UNSUPPORTED;
 }
+
+#define THIN_CASE(NF_, CK_) if (nf == NF_ && ck == CK_) return launch_conv_thin<bf16_t, NF_, CK_>(a, wgs_per_cu, st);
+
+int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st) {
+  THIN_CASE(1, 16) THIN_CASE(2, 16) THIN_CASE(1, 32) THIN_CASE(2, 32)
+  return FI_ERR_UNSUPPORTED;
+}

@@ -1086,6 +1086,377 @@ static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward kernel, third form: the THIN layers (Cin <= 32, Cout <= 32: full and half resolution of the U-Net)
+// ---------------------------------------------------------------------------------------------
+// Measured (tools/kprobe.sh, ISA counts): at 16 or 32 channels the one-tile kernel is VALU-ISSUE bound, not memory bound --
+// ~600 vector instructions per thread and tile for 20 MFMAs (~1100 with the transforming loader): clamped 64-bit
+// addresses and zero-selects of the staging, the weight slab through LDS, AGPR copies, and a cross-lane statistics
+// reduction per tile; 48 tiles per CU x 4 waves x ~700 instructions x 4 cycles IS the 60 us the 512^2 16->16 layer takes.
+// This form strips the per-tile instruction stream down:
+//   * the whole filter (9 taps x <= 32 channels) lives in REGISTERS as MFMA operand fragments for the life of the
+//     workgroup: no weight staging, no weight fragment reads;
+//   * staging through raw buffer loads: a 32-bit byte offset per vector, out-of-image vectors take an out-of-range offset and
+//     the hardware returns zeros -- no clamps, no 64-bit address arithmetic, no zero-selects (plain loader);
+//   * stores through raw buffer stores the same way (tile overhang = out-of-range offset, dropped by the hardware);
+//   * BatchNorm statistics accumulate in registers over ALL tiles of the workgroup (a contiguous run of one statistics
+//     group) and are reduced across lanes / waves and added to the fp64 accumulators once;
+//   * persistent: the loads of tile t+1 are in flight during the MFMAs and the epilogue of tile t (conv_fwd_v2_kernel's
+//     ordering: the epilogue's stores are issued behind the next loads).
+// Same LDS tile layout, operand mapping, input transforms (XF) and rounding as the other two forms.
+// Register budget: a 168-register cap (3 waves per SIMD) made the one-fragment instantiations 10-15 % faster than letting
+// hipcc take 158-190 registers unasked (it schedules for the occupancy it is promised); the two-fragment ones spill under
+// any cap worth having and are left alone (profiles/r02_h_thin_variants.txt).
+template <typename T, int NF, int CK, int XF>
+__global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  constexpr int KS = 3, TH = 16, HALO = 1, XW = 18, XH = 18, KK = 9;
+  constexpr int VG = 8, KSTEP = 32, KV = 8;
+  constexpr int CKP = FiLdsStride<T, CK>::value;
+  constexpr int KC = KK * CK, NKS = (KC + KSTEP - 1) / KSTEP;
+  constexpr int BN = NF * 16, MF = 4, VPP = CK / VG;
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);                           // [XH*XW][CKP]
+  float* red = reinterpret_cast<float*>(xs + XH * XW * CKP);    // [4 waves][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int cin = a.c0 + a.c1, cout = a.co0;
+  const int H = a.H, W = a.W;
+
+  // ---- this workgroup's tiles: one contiguous run
+  const int ntile = a.N * a.tilesY * a.tilesX;
+  const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per, t_end = min(ntile, t_begin + per);
+  if (t_begin >= t_end) return;
+
+  // ---- the filter as MFMA "A" fragments: wf[f][ks] = w[co = f*16 + li][k = ks*32 + kg*8 .. +8), k = tap*CK + channel
+  frag_t wf[NF][NKS];
+  {
+    const T* wg = reinterpret_cast<const T*>(a.w);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int k0 = ks * KSTEP + kg * KV, t = k0 / CK, c = k0 % CK, co = f * 16 + li;
+        vec_t v = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 < KC && c < cin && co < cout) v = *reinterpret_cast<const vec_t*>(wg + ((size_t)co * KK + t) * cin + c);
+        wf[f][ks] = __builtin_bit_cast(frag_t, v);
+      }
+  }
+  float bv[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = f * 16 + kg * 4 + r;
+      bv[f][r] = (a.bias && co < cout) ? a.bias[co] : 0.f;
+    }
+
+  // ---- buffer resources (raw, range-checked: an offset beyond num_records reads zeros / drops the store)
+  const unsigned esz = sizeof(T);
+  const unsigned src_images = (XF != 0 && a.bcast0) ? (unsigned)a.gimages : (unsigned)a.N;
+  const unsigned hw_src = (XF == 2 ? 4u : 1u) * (unsigned)H * (unsigned)W;
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x0), 0,
+                                                                      src_images * hw_src * (unsigned)a.c0 * esz, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.x1), 0, a.c1 ? (unsigned)a.N * (unsigned)H * (unsigned)W * (unsigned)a.c1 * esz : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      a.y0, 0, a.y0 ? (unsigned)a.N * (unsigned)H * (unsigned)W * (unsigned)cout * esz : 0u, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  // ---- staging geometry: a thread owns one vector column (pixel column xpx, channel vector xv) of the halo tile
+  constexpr int XCOLS = XW * VPP, XRPP = 256 / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
+  constexpr int NS = XF == 2 ? 4 : 1;
+  const int xcol = tid % XCOLS, xrow0 = tid / XCOLS;
+  const int xpx = xcol / VPP, xv = xcol % VPP;
+  const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;
+  const int xc = xv * VG;                                       // first channel of this thread's vector
+  const bool xfirst = xc < a.c0;                                // which source it comes from
+  const bool xchan = xc < cin && xrow0 < XRPP;
+  const unsigned xcs = (unsigned)(xfirst ? a.c0 : a.c1), xco = (unsigned)(xfirst ? xc : xc - a.c0);
+
+  // tile coordinates are wave-uniform and advance by one tile at a time: no divisions in the loop
+  struct Tile {
+    int tx, ty, n;
+  };
+  auto tile_at = [&](int tile) {
+    Tile c;
+    c.tx = tile % a.tilesX;
+    c.ty = (tile / a.tilesX) % a.tilesY;
+    c.n = tile / (a.tilesX * a.tilesY);
+    return c;
+  };
+  auto tile_next = [&](Tile c) {
+    if (++c.tx == a.tilesX) {
+      c.tx = 0;
+      if (++c.ty == a.tilesY) {
+        c.ty = 0;
+        ++c.n;
+      }
+    }
+    return c;
+  };
+  vec_t xr[XPASS][NS];
+  auto issue = [&](const Tile& tc, int grp) __attribute__((always_inline)) {
+    const int tx = tc.tx, ty = tc.ty, n = tc.n;
+    const int ns = (XF != 0 && xfirst && a.bcast0) ? n - grp * a.gimages : n;
+    const int gx = tx * 16 + xpx - HALO;
+    const bool colok = xchan && gx >= 0 && gx < W;
+#pragma unroll
+    for (int p = 0; p < XPASS; ++p) {
+      const int gy = ty * TH + xrow0 + p * XRPP - HALO;
+      const bool ok = colok && gy >= 0 && gy < H;
+      if constexpr (XF == 2) {
+        const unsigned o = ((unsigned)((ns * 2 * H + 2 * gy) * (2 * W) + 2 * gx) * xcs + xco) * esz;
+        const unsigned rowb = (unsigned)(2 * W) * xcs * esz, pxb = xcs * esz;
+        xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
+        xr[p][1] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + pxb : OOB, 0, 0));
+        xr[p][2] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb : OOB, 0, 0));
+        xr[p][3] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb + pxb : OOB, 0, 0));
+      } else {
+        const unsigned o = ((unsigned)((ns * H + gy) * W + gx) * xcs + xco) * esz;
+        const v4u v = xfirst ? __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0)
+                             : __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? o : OOB, 0, 0);
+        xr[p][0] = __builtin_bit_cast(vec_t, v);
+      }
+    }
+  };
+
+  // transform state of the current statistics group (XF != 0): this thread's 8 scale / shift values, its dropout seed
+  float sc[VG], sh[VG];
+  float slope = 1.f;
+  bool xf = false, drop = false;
+  uint64_t seed = 0;
+  auto load_coefs = [&](int grp) __attribute__((always_inline)) {
+    if constexpr (XF != 0) {
+      const float* scp = xfirst ? a.t0.scale : a.t1.scale;
+      const float* shp = xfirst ? a.t0.shift : a.t1.shift;
+      slope = xfirst ? a.t0.slope : a.t1.slope;
+      xf = scp != nullptr && xc < cin;
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        sc[j] = xf ? scp[(unsigned)grp * xcs + xco + j] : 1.f;
+        sh[j] = xf ? shp[(unsigned)grp * xcs + xco + j] : 0.f;
+      }
+      drop = XF == 1 && xfirst && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+      if (drop) {
+        seed = a.t0.seed + (uint64_t)grp * a.t0.seed_gstride;
+        if (a.t0.seed_offset) seed += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+      }
+    }
+  };
+  auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
+    float f[VG];
+    VecWords<T>::unpack(raw, f);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      const float v = f[j] * sc[j] + sh[j];
+      f[j] = fmaxf(v, v * slope);
+    }
+    if (drop) {
+#pragma unroll
+      for (int g4 = 0; g4 < VG / 4; ++g4) {
+        uint32_t rr[4];
+        fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
+      }
+    }
+    return VecWords<T>::pack(f);
+  };
+
+  auto commit = [&](const Tile& tc, int grp) __attribute__((always_inline)) {
+    const int tx = tc.tx, ty = tc.ty, n = tc.n;
+    const int gx = tx * 16 + xpx - HALO;
+    const bool colok = xchan && gx >= 0 && gx < W;
+    const int nl = n - grp * a.gimages;
+#pragma unroll
+    for (int p = 0; p < XPASS; ++p) {
+      const int py = xrow0 + p * XRPP;
+      const int gy = ty * TH + py - HALO;
+      if (xrow0 < XRPP && py < XH) {
+        vec_t val;
+        if constexpr (XF == 0) {
+          val = xr[p][0];                                      // out-of-image vectors arrived as zeros
+        } else {
+          const bool ok = colok && gy >= 0 && gy < H;           // z of the padding is 0, not act(shift)
+          if constexpr (XF == 2) {
+            float best[VG], cand[VG];
+            VecWords<T>::unpack(xf ? xform(xr[p][0], 0) : xr[p][0], best);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              VecWords<T>::unpack(xf ? xform(xr[p][k], 0) : xr[p][k], cand);
+#pragma unroll
+              for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
+            }
+            val = fi_vec_select(ok, VecWords<T>::pack(best));
+          } else {
+            const unsigned vix = (unsigned)((nl * H + gy) * W + gx) * (xcs / VG) + xco / VG;
+            val = fi_vec_select(ok, xf ? xform(xr[p][0], vix) : xr[p][0]);
+          }
+        }
+        *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
+      }
+    }
+  };
+
+  f32x4 acc[MF][NF];
+  auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      // this lane's 8 contraction elements: tap t, channels cil .. cil+8 (CK % 8 == 0 keeps them inside one tap)
+      const int k0 = ks * KSTEP + kg * KV;
+      int t = k0 / CK;
+      const int cil = k0 % CK;
+      if (t > KK - 1) t = KK - 1;                               // padded K: the filter fragment is zero there
+      const int r = t / KS, s = t % KS;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const frag_t av = *reinterpret_cast<const frag_t*>(&xs[((wave * MF + m + r) * XW + li + s) * CKP + cil]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(wf[f][ks], av, acc[m][f]);
+      }
+#ifdef FI_THIN_SB
+      if ((ks + 1) % FI_THIN_SB == 0) __builtin_amdgcn_sched_barrier(0);   // bound how many fragment reads are hoisted
+#endif
+    }
+  };
+
+  // BatchNorm statistics of the stored values: per-lane partial sums over all tiles of the current group
+  float ssum[NF][4], ssq[NF][4];
+  auto stats_clear = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[f][r] = ssq[f][r] = 0.f;
+  };
+  auto stats_flush = [&](int grp) __attribute__((always_inline)) {
+    if (!a.stats) return;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = fi_row16_sum(ssum[f][r]), q = fi_row16_sum(ssq[f][r]);
+        if (li == 0) {
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = q;
+        }
+      }
+    fi_lds_barrier();
+    if (tid < BN * 2) {
+      const int c = tid >> 1, which = tid & 1;
+      if (c < cout) {
+        double tot = 0.0;
+#pragma unroll
+        for (int wv_ = 0; wv_ < 4; ++wv_) tot += (double)red[(wv_ * BN + c) * 2 + which];
+        const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
+        atomicAdd(&a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + c) * 2 + which], tot);
+      }
+    }
+    fi_lds_barrier();                                            // `red` may be rewritten by the next flush
+  };
+
+  auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
+    const int tx = tc.tx, ty = tc.ty, n = tc.n;
+    const int gx = tx * 16 + li;
+    const bool colok = gx < W;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gy = ty * TH + wave * MF + m;
+      const bool ok = colok && gy < H;
+      const float mk = ok ? 1.f : 0.f;
+      const unsigned pixo = (unsigned)((n * H + gy) * W + gx) * (unsigned)cout;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int cg = f * 16 + kg * 4;
+        T e[4];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = from_f32<T>(acc[m][f][r] + bv[f][r]);
+          v[r] = to_f32(e[r]) * mk;                             // tile overhang does not count
+        }
+        v2u q;
+        memcpy(&q, e, sizeof(q));
+        __builtin_amdgcn_raw_buffer_store_b64(q, ry, (ok && cg < cout) ? (pixo + (unsigned)cg) * esz : OOB, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ssum[f][r] += v[r];
+          ssq[f][r] += v[r] * v[r];
+        }
+      }
+    }
+  };
+
+  // ---- segments = runs of tiles of one statistics group (coefficients, seeds and accumulators belong to the group); inside
+  //      a segment the tile loop has conv_fwd_v2_kernel's ordering
+  const int tpi = a.tilesX * a.tilesY;
+  int t = t_begin;
+  while (t < t_end) {
+    const int grp = a.gimages > 0 ? (t / tpi) / a.gimages : 0;
+    const int seg_end = a.gimages > 0 ? min(t_end, (grp + 1) * a.gimages * tpi) : t_end;
+    load_coefs(grp);
+    stats_clear();
+    int cur = -1, nxt = t;
+    Tile tcur = tile_at(t), tnxt = tcur;
+    issue(tnxt, grp);
+    while (true) {
+      if (cur >= 0) {
+        mma();
+        fi_lds_barrier();                                        // every wave has read tile `cur` out of LDS
+      }
+      const int done = cur;
+      const Tile tdone = tcur;
+      if (nxt < seg_end) {
+        commit(tnxt, grp);                                      // waits for the loads issued a tile ago
+        cur = nxt;
+        tcur = tnxt;
+        ++nxt;
+        tnxt = tile_next(tnxt);
+        if (nxt < seg_end) issue(tnxt, grp);
+      }
+      if (done >= 0) epilogue(tdone);                           // its stores go out behind the loads just issued
+      if (done == cur) break;                                   // nothing was committed: the segment is finished
+      fi_lds_barrier();                                          // tile `cur` is in LDS
+    }
+    stats_flush(grp);
+    t = seg_end;
+  }
+}
+
+template <typename T, int NF, int CK>
+static int launch_conv_thin(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
+  constexpr int CKP = FiLdsStride<T, CK>::value;
+  const size_t lds = (size_t)(18 * 18 * CKP) * sizeof(T) + (size_t)4 * NF * 16 * 2 * sizeof(float);
+  const long ntile = (long)a.N * a.tilesX * a.tilesY;
+  long blocks = 256L * wgs_per_cu;
+  if (blocks > ntile) blocks = ntile;
+  const dim3 g((unsigned)blocks), b(256);
+  if (a.xf == 0)
+    hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 0>), g, b, lds, st, a);
+  else if (a.xf == 1)
+    hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 1>), g, b, lds, st, a);
+  else {
+    if constexpr (CK == 16)
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 2>), g, b, lds, st, a);
+    else
+      return FI_ERR_UNSUPPORTED;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad:  dw[co][t][ci] += sum_pix dy[pix][co] * x[pix + tap t][ci]
 //   GEMM view M = Cout, N = Cin (per tap), K = pixels.  A workgroup owns a (16*NFO) x (16*NFI)
 //   channel tile and walks spatial tiles (grid-stride), staging the x halo tile and the dy tile

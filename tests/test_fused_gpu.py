@@ -255,5 +255,17 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
                         # statistics of the STORED outputs (a few of which differ in their last bit), per-tile fp32 partial sums grouped
                         # by the tile height each kernel picked
                         assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=1e-2), (nf, ck, wgs)
+        if c0 + c1 <= 32 and cout <= 32 and not two:
+            for wgs in (1, 4):                              # the thin-layer kernel (filter in registers, buffer loads / stores)
+                L.conv_tuning(3, 0, 0, wgs)
+                got, st_got = run()
+                torch.cuda.synchronize()
+                for a, b in zip(got, want):
+                    if a is not None:
+                        d = (a.float() - b.float()).abs()
+                        assert bool((d <= 2 * ulp * b.float().abs() + 1e-3).all()), ("thin", wgs, float(d.max()))
+                        assert float((d > 0).float().mean()) < 2e-3, ("thin", wgs)
+                if st_want is not None:
+                    assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=1e-2), ("thin", wgs)
     finally:
         L.conv_tuning(-1)

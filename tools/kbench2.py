@@ -51,17 +51,22 @@ def main():
     ap.add_argument("--groups", type=int, default=7)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--only", default="")
+    ap.add_argument("--thin", action="store_true", help="only the one-tile kernel vs the thin-layer kernel, thin layers only")
     a = ap.parse_args()
     td = torch.bfloat16
     dev = "cuda"
     configs = [("v1", (0, 0, 0, 0))] + [(f"nf{nf}ck{ck}w{w}", (1, nf, ck, w)) for nf in (1, 2, 4) for ck in (16, 32)
-                                        for w in (2, 4)]
+                                        for w in (2, 4)] + [(f"thin_w{w}", (3, 0, 0, w)) for w in (2, 4, 8)]
+    if a.thin:
+        configs = [c for c in configs if c[0] == "v1" or c[0].startswith("thin")]
     tot = {}
     for mode in ("plain", "fused"):
         if a.only and a.only != mode:
             continue
         print(f"== {mode}: us per launch; best persistent config vs the one-tile kernel")
         for (f, c0, c1, cout, kind) in LAYERS:
+            if a.thin and (c0 + c1 > 32 or cout > 32):
+                continue
             H = int(a.size * f)
             G = a.groups if mode == "fused" else 1
             N = a.batch * G
@@ -87,9 +92,11 @@ def main():
                     L.conv2d_fwd(x0, x1, w, bias, y, None, st[0], ksize=3, cout=cout)
             res = {}
             for name, cfg in configs:
-                if cfg[0] and cfg[1] > 1 and (cfg[1] // 2) * 16 >= cout:
+                if cfg[0] == 1 and cfg[1] > 1 and (cfg[1] // 2) * 16 >= cout:
                     continue
-                if cfg[0] and pool and cfg[2] == 32:
+                if cfg[0] == 1 and pool and cfg[2] == 32:
+                    continue
+                if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
                     continue
                 L.conv_tuning(*cfg)
                 try:

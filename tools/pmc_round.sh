@@ -1,9 +1,9 @@
 #!/bin/bash
-# HBM traffic per kernel family for the round (two PMC passes; counters only, no other trace domains).
-# Run on the GPU box from the repo root: bash tools/pmc_round.sh r02_a
+# HBM traffic per kernel family for the round (two PMC passes; counters only, no other trace domains) over the launch mix
+# of the roofline object (bench.py --roofline-only).  Run on the GPU box from the repo root: bash tools/pmc_round.sh r02_a
 TAG=${1:-r02_a}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 4 --warmup 4 --round-iters 4 --loader-batches 2 --no-graph --no-cpu-baseline --no-roofline --no-fp32"
+ARGS="--roofline-only"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- python $ROOT/bench.py $ARGS > /tmp/pmc_$c.log 2>&1
