@@ -76,11 +76,12 @@ def test_transforming_loader_equals_bn_act_then_conv(dtype, case):
     torch.cuda.synchronize()
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     a, b = st_got.sum(1), st_want.sum(1)
-    assert torch.allclose(a, b, rtol=1e-9, atol=1e-9), float((a - b).abs().max())
+    # fp32 partial sums per tile (one-tile kernel) or per lane over a workgroup's tiles (thin-layer kernel), fp64 across them
+    assert torch.allclose(a, b, rtol=2e-6, atol=2e-3), float((a - b).abs().max())
     # statistics-only launch: nothing stored, same accumulators
     st_only = torch.zeros_like(st_want)
     L.conv2d_fwd_fused(y0, t0, x1, None, w, bias, None, st_only, ksize=k, groups=G, cout=cout, shared0=shared)
-    assert torch.allclose(st_only.sum(1), b, rtol=1e-9, atol=1e-9)
+    assert torch.allclose(st_only.sum(1), b, rtol=2e-6, atol=2e-3)
 
 
 def test_bn_finalize_groups_moves_the_running_statistics_like_consecutive_forwards():
