@@ -676,6 +676,7 @@ static int launch_conv_fwd(const ConvArgs& a, hipStream_t st) {
 #endif
 template <typename T, int KS, int NF, int CK, int XF>
 __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int TH = 16;
   constexpr int HALO = KS / 2, XW = 16 + 2 * HALO, XH = TH + 2 * HALO, KK = KS * KS;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
@@ -689,41 +690,56 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
   static_assert(CK > VG, "whole-vector channel counts only");
   typedef typename DT<T>::vec_t vec_t;
   typedef typename DT<T>::frag_t frag_t;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xs = reinterpret_cast<T*>(smem);                           // [XH*XW][CKP]
   T* ws = xs + XH * XW * CKP;                                   // [BN][WKP]
-  float* red = reinterpret_cast<float*>(ws + BN * WKP);         // [4 waves][BN][2]: statistics of a finished tile
+  float* red = reinterpret_cast<float*>(ws + BN * WKP);         // [4 waves][BN][2]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kg = lane >> 4;
   const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
   const int H = a.H, W = a.W;
-  const T* x0 = reinterpret_cast<const T*>(a.x0);
-  const T* x1 = reinterpret_cast<const T*>(a.x1);
-  const T* wg = reinterpret_cast<const T*>(a.w);
 
-  // ---- this workgroup's work: tiles t0 + k*tstep (k = 0, 1, ...) below t_end, output slab ct, nchunk chunks per tile
+  // ---- this workgroup's work: tiles t_first + k*tstep (k = 0, 1, ...) below t_end, output slab ct, nchunk chunks per tile
   const int ntile = a.N * a.tilesY * a.tilesX;
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, gx = gridDim.x >> 3;     // grid: a multiple of 8 * nct (host)
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, gxd = gridDim.x >> 3;    // grid: a multiple of 8 * nct (host)
   const int tpx = (ntile + 7) >> 3;
   const int t_end = min(ntile, (xcd + 1) * tpx);
-  const int ct = q % a.nct, tstep = gx / a.nct;
+  const int ct = q % a.nct, tstep = gxd / a.nct;
   const int t_first = xcd * tpx + q / a.nct;
   if (t_first >= t_end) return;
   const int nchunk = (cin + CK - 1) / CK;
   const bool w_resident = nchunk == 1;
 
-  f32x4 acc[MF][NF];
+  // ---- buffer resources (raw, range-checked: an offset beyond num_records reads zeros / drops the store): no clamped
+  //      addresses, no 64-bit address arithmetic, no zero-selects in the plain loader (see conv_thin_kernel)
+  constexpr unsigned esz = sizeof(T);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned hw = (unsigned)H * (unsigned)W;
+  const unsigned img0 = (XF != 0 && a.bcast0) ? (unsigned)a.gimages : (unsigned)a.N;
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.x0), 0, img0 * (XF == 2 ? 4u : 1u) * hw * (unsigned)a.c0 * esz, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.x1), 0, a.c1 ? (unsigned)a.N * hw * (unsigned)a.c1 * esz : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.w), 0, (unsigned)cout * KK * (unsigned)cin * esz, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry0 = __builtin_amdgcn_make_buffer_rsrc(
+      a.y0, 0, a.y0 ? (unsigned)a.N * hw * (unsigned)a.co0 * esz : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc(
+      a.y1, 0, (a.y1 && a.co1) ? (unsigned)a.N * hw * (unsigned)a.co1 * esz : 0u, 0x00020000);
 
-  // ---- staging geometry (as conv_fwd_kernel: a thread owns one vector column of the halo tile / the weight slab)
+  // ---- staging geometry (a thread owns one vector column of the halo tile / of the weight slab)
   constexpr int XCOLS = XW * VPP, XRPP = 256 / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
   constexpr int WCOLS = KK * VPP, WRPP = 256 / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
   static_assert(XRPP >= 1 && WRPP >= 1, "tile too wide for 256 threads");
   constexpr int NS = XF == 2 ? 4 : 1;
-  // Every phase below recomputes its thread geometry from an OPAQUE copy of the thread id: derived from `tid` directly,
-  // hipcc hoists a few dozen per-thread invariants (row offsets, LDS addresses, masks) of all phases out of the stage loop
-  // and keeps them live across it -- on top of the register set in flight and the accumulators that is hundreds of spills.
+  // Every phase recomputes its thread geometry from an OPAQUE copy of the thread id: derived from `tid` directly, hipcc
+  // hoists a few dozen per-thread invariants (row offsets, LDS addresses, masks) of all phases out of the stage loop and
+  // keeps them live across it -- with the register set in flight and 64 accumulators that spills (NF = 4).
 #define FI_V2_GEOMETRY()                                                     \
   int tid_ = tid;                                                            \
   asm volatile("" : "+v"(tid_));                                             \
@@ -735,111 +751,129 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
   const int wlds0 = wrow0 * WKP + wt * CK + wv * VG;                         \
   (void)xlds0; (void)wlds0; (void)xrow0; (void)wrow0; (void)xpx; (void)wt; (void)xv; (void)wv
 
+  struct Tile {
+    int tx, ty, n, grp;
+  };
+  auto tile_at = [&](int tile) {
+    Tile c;
+    c.tx = tile % a.tilesX;
+    c.ty = (tile / a.tilesX) % a.tilesY;
+    c.n = tile / (a.tilesX * a.tilesY);
+    c.grp = a.gimages > 0 ? c.n / a.gimages : 0;
+    return c;
+  };
+
   vec_t xr[XPASS][NS];          // the ONE register set of the stage in flight
   vec_t wr[WPASS];
 
-  auto issue = [&](int tile, int cb, bool with_w) __attribute__((always_inline)) {
+  // per-chunk source of this thread's channel vector
+  struct Src {
+    bool first, chok;
+    unsigned cs, co;            // channels of the source tensor, first channel inside it
+  };
+  auto src_of = [&](int cb, int xv, int xrow0) {
+    Src s;
+    const int ci = cb + xv * VG;
+    s.chok = ci < cin && xrow0 < XRPP;
+    const int cc = ci < cin ? ci : 0;
+    s.first = cc < a.c0;
+    s.cs = (unsigned)(s.first ? a.c0 : a.c1);
+    s.co = (unsigned)(s.first ? cc : cc - a.c0);
+    return s;
+  };
+
+  auto issue = [&](const Tile& tc, int cb, bool with_w) __attribute__((always_inline)) {
     FI_V2_GEOMETRY();
-    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
-    const int grp = a.gimages > 0 ? n / a.gimages : 0;
-    {
-      const int ci = cb + xv * VG;
-      const int cc = ci < cin ? ci : 0;
-      const bool first = cc < a.c0;
-      const int csrc = first ? cc : cc - a.c0;
-      const int cstride = first ? a.c0 : a.c1;
-      const T* colbase = (first ? x0 : x1) + csrc;
-      const int ns = (XF != 0 && first && a.bcast0) ? n - grp * a.gimages : n;
-      const int xcx = min(max(tx * 16 + xpx - HALO, 0), W - 1);
+    const Src s = src_of(cb, xv, xrow0);
+    const int gx = tc.tx * 16 + xpx - HALO;
+    const bool colok = s.chok && gx >= 0 && gx < W;
+    const int ns = (XF != 0 && s.first && a.bcast0) ? tc.n - tc.grp * a.gimages : tc.n;
 #pragma unroll
-      for (int p = 0; p < XPASS; ++p) {
-        const int gy = ty * TH + xrow0 + p * XRPP - HALO;
-        const int cy = min(max(gy, 0), H - 1);
-        if constexpr (XF == 2) {
-          const T* src = colbase + (size_t)((ns * 2 * H + 2 * cy) * (2 * W) + 2 * xcx) * cstride;
-          xr[p][0] = *reinterpret_cast<const vec_t*>(src);
-          xr[p][1] = *reinterpret_cast<const vec_t*>(src + cstride);
-          xr[p][2] = *reinterpret_cast<const vec_t*>(src + (size_t)2 * W * cstride);
-          xr[p][3] = *reinterpret_cast<const vec_t*>(src + (size_t)(2 * W + 1) * cstride);
-        } else {
-          xr[p][0] = *reinterpret_cast<const vec_t*>(colbase + (size_t)((ns * H + cy) * W + xcx) * cstride);
-        }
+    for (int p = 0; p < XPASS; ++p) {
+      const int gy = tc.ty * TH + xrow0 + p * XRPP - HALO;
+      const bool ok = colok && gy >= 0 && gy < H;
+      if constexpr (XF == 2) {
+        const unsigned o = ((unsigned)((ns * 2 * H + 2 * gy) * (2 * W) + 2 * gx) * s.cs + s.co) * esz;
+        const unsigned rowb = (unsigned)(2 * W) * s.cs * esz, pxb = s.cs * esz;
+        xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
+        xr[p][1] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + pxb : OOB, 0, 0));
+        xr[p][2] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb : OOB, 0, 0));
+        xr[p][3] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb + pxb : OOB, 0, 0));
+      } else {
+        const unsigned o = ((unsigned)((ns * H + gy) * W + gx) * s.cs + s.co) * esz;
+        const v4u v = s.first ? __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? o : OOB, 0, 0);
+        xr[p][0] = __builtin_bit_cast(vec_t, v);
       }
     }
     if (with_w) {
       const int ci = cb + wv * VG;
-      const T* colbase = wg + (size_t)wt * cin + (ci < cin ? ci : 0);
+      const bool chok = ci < cin && wrow0 < WRPP;
 #pragma unroll
       for (int p = 0; p < WPASS; ++p) {
-        const int gco = ct * BN + wrow0 + p * WRPP;
-        wr[p] = *reinterpret_cast<const vec_t*>(colbase + (size_t)(gco < cout ? gco : 0) * (KK * cin));
+        const int co = wrow0 + p * WRPP, gco = ct * BN + co;
+        const unsigned o = ((unsigned)(gco * KK + wt) * (unsigned)cin + (unsigned)ci) * esz;
+        wr[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, (chok && co < BN && gco < cout) ? o : OOB, 0, 0));
       }
     }
   };
 
-  auto commit = [&](int tile, int cb, bool with_w) __attribute__((always_inline)) {
+  auto commit = [&](const Tile& tc, int cb, bool with_w) __attribute__((always_inline)) {
     FI_V2_GEOMETRY();
-    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
-    const int grp = a.gimages > 0 ? n / a.gimages : 0;
-    {
-      const int ci = cb + xv * VG;
-      const bool chok = ci < cin;
-      const int cc = chok ? ci : 0;
-      const bool first = cc < a.c0;
-      const int csrc = first ? cc : cc - a.c0;
-      const int cstride = first ? a.c0 : a.c1;
-      const int xgx = tx * 16 + xpx - HALO;
-      const bool xcolok = xrow0 < XRPP && xgx >= 0 && xgx < W && chok;
-      float sc[VG], sh[VG];
-      bool xf = false, drop = false;
-      float slope = 1.f;
-      uint64_t seed = 0;
-      if constexpr (XF != 0) {
-        const float* scp = first ? a.t0.scale : a.t1.scale;
-        const float* shp = first ? a.t0.shift : a.t1.shift;
-        slope = first ? a.t0.slope : a.t1.slope;
-        xf = scp != nullptr;
+    const Src s = src_of(cb, xv, xrow0);
+    float sc[VG], sh[VG];
+    bool xf = false, drop = false;
+    float slope = 1.f;
+    uint64_t seed = 0;
+    if constexpr (XF != 0) {
+      const float* scp = s.first ? a.t0.scale : a.t1.scale;
+      const float* shp = s.first ? a.t0.shift : a.t1.shift;
+      slope = s.first ? a.t0.slope : a.t1.slope;
+      xf = scp != nullptr;
 #pragma unroll
-        for (int j = 0; j < VG; ++j) {
-          sc[j] = xf ? scp[(size_t)grp * cstride + csrc + j] : 1.f;
-          sh[j] = xf ? shp[(size_t)grp * cstride + csrc + j] : 0.f;
-        }
-        drop = XF == 1 && first && a.t0.drop_mode == FI_DROP_RNG_ELEM;
-        if (drop) {
-          seed = a.t0.seed + (uint64_t)grp * a.t0.seed_gstride;
-          if (a.t0.seed_offset) seed += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+      for (int j = 0; j < VG; ++j) {
+        sc[j] = xf ? scp[(unsigned)tc.grp * s.cs + s.co + j] : 1.f;
+        sh[j] = xf ? shp[(unsigned)tc.grp * s.cs + s.co + j] : 0.f;
+      }
+      drop = XF == 1 && s.first && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+      if (drop) {
+        seed = a.t0.seed + (uint64_t)tc.grp * a.t0.seed_gstride;
+        if (a.t0.seed_offset) seed += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+      }
+    }
+    auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
+      float f[VG];
+      VecWords<T>::unpack(raw, f);
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        const float v = f[j] * sc[j] + sh[j];
+        f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
+      }
+      if (drop) {
+#pragma unroll
+        for (int g4 = 0; g4 < VG / 4; ++g4) {
+          uint32_t rr[4];
+          fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
         }
       }
-      auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
-        float f[VG];
-        VecWords<T>::unpack(raw, f);
+      return VecWords<T>::pack(f);
+    };
+    const int gx = tc.tx * 16 + xpx - HALO;
+    const bool colok = s.chok && gx >= 0 && gx < W;
+    const int nl = tc.n - tc.grp * a.gimages;
 #pragma unroll
-        for (int j = 0; j < VG; ++j) {
-          const float v = f[j] * sc[j] + sh[j];
-          f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
-        }
-        if (drop) {
-#pragma unroll
-          for (int g4 = 0; g4 < VG / 4; ++g4) {
-            uint32_t rr[4];
-            fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
-          }
-        }
-        return VecWords<T>::pack(f);
-      };
-      const int nl = n - grp * a.gimages;
-      const int xcx = min(max(xgx, 0), W - 1);
-#pragma unroll
-      for (int p = 0; p < XPASS; ++p) {
-        const int py = xrow0 + p * XRPP;
-        const int gy = ty * TH + py - HALO;
-        if (xrow0 < XRPP && py < XH) {
-          const bool ok = xcolok && gy >= 0 && gy < H;
-          vec_t val;
+    for (int p = 0; p < XPASS; ++p) {
+      const int py = xrow0 + p * XRPP;
+      const int gy = tc.ty * TH + py - HALO;
+      if (xrow0 < XRPP && py < XH) {
+        vec_t val;
+        if constexpr (XF == 0) {
+          val = xr[p][0];                                      // out-of-image / beyond-Cin vectors arrived as zeros
+        } else {
+          const bool ok = colok && gy >= 0 && gy < H;           // z of the padding is 0, not act(shift)
           if constexpr (XF == 2) {
-            // z of the four source pixels, then the element-wise maximum (of the ROUNDED values, as fi_maxpool2_fwd sees them)
             float best[VG], cand[VG];
             VecWords<T>::unpack(xf ? xform(xr[p][0], 0) : xr[p][0], best);
 #pragma unroll
@@ -848,31 +882,25 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
 #pragma unroll
               for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
             }
-            val = fi_vec_select(ok, VecWords<T>::pack(best));      // values are exactly representable: pack does not round
-          } else if constexpr (XF == 1) {
-            const int cy = min(max(gy, 0), H - 1);
-            const unsigned vix = (unsigned)((nl * H + cy) * W + xcx) * (unsigned)(cstride / VG) + (unsigned)(csrc / VG);
-            val = fi_vec_select(ok, xf ? xform(xr[p][0], vix) : xr[p][0]);
+            val = fi_vec_select(ok, VecWords<T>::pack(best));
           } else {
-            val = fi_vec_select(ok, xr[p][0]);
+            const unsigned vix = (unsigned)((nl * H + gy) * W + gx) * (s.cs / VG) + s.co / VG;
+            val = fi_vec_select(ok, xf ? xform(xr[p][0], vix) : xr[p][0]);
           }
-          *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
         }
+        *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
       }
     }
     if (with_w) {
-      const int ci = cb + wv * VG;
-      const bool chok = ci < cin && wrow0 < WRPP;
 #pragma unroll
       for (int p = 0; p < WPASS; ++p) {
         const int co = wrow0 + p * WRPP;
-        if (wrow0 < WRPP && co < BN) {
-          *reinterpret_cast<vec_t*>(&ws[wlds0 + p * (WRPP * WKP)]) = fi_vec_select(chok && ct * BN + co < cout, wr[p]);
-        }
+        if (wrow0 < WRPP && co < BN) *reinterpret_cast<vec_t*>(&ws[wlds0 + p * (WRPP * WKP)]) = wr[p];
       }
     }
   };
 
+  f32x4 acc[MF][NF];
   auto mma = [&]() __attribute__((always_inline)) {
     int lane_ = lane;
     asm volatile("" : "+v"(lane_));
@@ -919,79 +947,96 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
     }
   };
 
-  auto epilogue = [&](int tile) __attribute__((always_inline)) {
-    int lane_ = lane;
-    asm volatile("" : "+v"(lane_));
-    const int li = lane_ & 15, kg = lane_ >> 4;
-    const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, n = tile / (a.tilesX * a.tilesY);
-    const int grp = a.gimages > 0 ? n / a.gimages : 0;
-    float ssum[NF][4], ssq[NF][4];
+  // BatchNorm statistics of the stored values: per-lane partial sums over all tiles of the current group, one cross-lane
+  // reduction and one round of fp64 atomics per group and workgroup
+  // (the four-fragment instantiations have no 48 registers to spare for that and for the bias: they reduce per tile)
+  constexpr bool DEFER = NF < 4;
+  float ssum[NF][4], ssq[NF][4];
+  auto stats_clear = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ssum[f][r] = ssq[f][r] = 0.f;
-    const int gx_ = tx * 16 + li;
+  };
+  auto stats_flush = [&](int grp) __attribute__((always_inline)) {
+    if (!a.stats) return;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int cg = ct * BN + f * 16 + kg * 4;
-      float bv[4];
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = (a.bias && cg + r < cout) ? a.bias[cg + r] : 0.f;
-      const bool second = cg >= a.co0;
-      const int cdst = second ? a.co1 : a.co0;
-      const int cofs = second ? cg - a.co0 : cg;
-      void* ybase = second ? a.y1 : a.y0;
-#pragma unroll
-      for (int m = 0; m < MF; ++m) {
-        const int gy = ty * TH + wave * MF + m;
-        if (gy < H && gx_ < W && cg < cout) {
-          const size_t o = (((size_t)n * H + gy) * W + gx_) * cdst + cofs;
-          float v[4];
-          T e[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            e[r] = from_f32<T>(acc[m][f][r] + bv[r]);
-            v[r] = to_f32(e[r]);
-          }
-          if (ybase) {
-            typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type out_t;
-            out_t qv;
-            memcpy(&qv, e, sizeof(qv));
-            *reinterpret_cast<out_t*>(reinterpret_cast<T*>(ybase) + o) = qv;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ssum[f][r] += v[r];
-            ssq[f][r] += v[r] * v[r];
-          }
+      for (int r = 0; r < 4; ++r) {
+        const float s = fi_row16_sum(ssum[f][r]), qv = fi_row16_sum(ssq[f][r]);
+        if (li == 0) {
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
+          red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = qv;
         }
       }
-    }
-    if (a.stats) {
+    fi_lds_barrier();
+    if (tid < BN * 2) {
+      const int c = tid >> 1, which = tid & 1;
+      const int co = ct * BN + c;
+      if (co < cout) {
+        double tot = 0.0;
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
+        for (int wv_ = 0; wv_ < 4; ++wv_) tot += (double)red[(wv_ * BN + c) * 2 + which];
+        const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
+        atomicAdd(&a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2 + which], tot);
+      }
+    }
+    fi_lds_barrier();
+  };
+
+  float bv[DEFER ? NF : 1][4];
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = ct * BN + f * 16 + kg * 4 + r;
+        bv[f][r] = (a.bias && co < cout) ? a.bias[co] : 0.f;
+      }
+  }
+
+  auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
+    if constexpr (!DEFER) stats_clear();
+    const int gx = tc.tx * 16 + li;
+    const bool colok = gx < W;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gy = tc.ty * TH + wave * MF + m;
+      const bool ok = colok && gy < H;
+      const float mk = ok ? 1.f : 0.f;
+      const unsigned pix = (unsigned)((tc.n * H + gy) * W + gx);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int cg = ct * BN + f * 16 + kg * 4;                // whole 4-channel groups inside one destination (host)
+        const bool second = cg >= a.co0;
+        T e[4];
+        float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float s = fi_row16_sum(ssum[f][r]), qq = fi_row16_sum(ssq[f][r]);
-          if (li == 0) {
-            red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 0] = s;
-            red[(wave * BN + f * 16 + kg * 4 + r) * 2 + 1] = qq;
-          }
+          float bias_r;
+          if constexpr (DEFER)
+            bias_r = bv[f][r];
+          else
+            bias_r = (a.bias && cg + r < cout) ? a.bias[cg + r] : 0.f;
+          e[r] = from_f32<T>(acc[m][f][r] + bias_r);
+          v[r] = to_f32(e[r]) * mk;                             // tile overhang does not count
         }
-      fi_lds_barrier();
-      if (tid < BN * 2) {
-        const int c = tid >> 1, which = tid & 1;
-        const int co = ct * BN + c;
-        if (co < cout) {
-          double tot = 0.0;
+        v2u qv;
+        memcpy(&qv, e, sizeof(qv));
+        const bool live = ok && cg < cout;
+        if (second)
+          __builtin_amdgcn_raw_buffer_store_b64(qv, ry1, live ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b64(qv, ry0, live ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
 #pragma unroll
-          for (int wv_ = 0; wv_ < 4; ++wv_) tot += (double)red[(wv_ * BN + c) * 2 + which];
-          const int slot = (blockIdx.x + tile) & (FI_STATS_SLOTS - 1);
-          atomicAdd(&a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2 + which], tot);
+        for (int r = 0; r < 4; ++r) {
+          ssum[f][r] += v[r];
+          ssq[f][r] += v[r] * v[r];
         }
       }
-      // `red` is rewritten only after the barrier that ends the next stage: every wave has passed this point by then
     }
+    if constexpr (!DEFER) stats_flush(tc.grp);
   };
 
   // ---- the stage loop.  `cur` = the stage whose operands are in LDS, `nxt` = the stage in flight / about to be committed.
@@ -999,16 +1044,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
   //      code: the register allocator sees each of them once).
   if (KCP > KC) {  // zero the K padding once: never overwritten by commit
     constexpr int PV = (KCP - KC) / VG;
-    for (int i = tid; i < BN * PV; i += 256) {
-      vec_t z;
-      memset(&z, 0, sizeof(z));
-      *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = z;
-    }
+    for (int i = tid; i < BN * PV; i += 256)
+      *reinterpret_cast<vec_t*>(&ws[(i / PV) * WKP + KC + (i % PV) * VG]) = make_uint4(0u, 0u, 0u, 0u);
   }
   int ctile = -1, cchunk = 0;                    // current stage (none yet)
   int ntile_ = t_first, nchunk_ = 0;             // next stage
+  Tile tcur = tile_at(t_first), tnxt = tcur;
+  int sgrp = tcur.grp;                           // group the statistics registers belong to
   bool first_w = true;
-  issue(ntile_, 0, true);
+  stats_clear();
+  issue(tnxt, 0, true);
   while (true) {
     if (ctile >= 0) {
       if (cchunk == 0) {
@@ -1020,29 +1065,40 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
       mma();
       fi_lds_barrier();                          // every wave has read the current stage out of LDS (only LDS is ordered)
     }
-    const int dtile = ctile;
     const bool done = ctile >= 0 && cchunk == nchunk - 1;
+    const Tile tdone = tcur;
     const bool have_next = ntile_ < t_end;
     if (have_next) {
-      commit(ntile_, nchunk_ * CK, first_w || !w_resident);     // waits for the loads issued a stage ago
+      commit(tnxt, nchunk_ * CK, first_w || !w_resident);       // waits for the loads issued a stage ago
       first_w = false;
       ctile = ntile_;
       cchunk = nchunk_;
+      tcur = tnxt;
       nchunk_ = cchunk + 1;
       if (nchunk_ == nchunk) {
         nchunk_ = 0;
         ntile_ = ctile + tstep;
+        if (ntile_ < t_end) tnxt = tile_at(ntile_);
       }
-      if (ntile_ < t_end) issue(ntile_, nchunk_ * CK, !w_resident);
+      if (ntile_ < t_end) issue(tnxt, nchunk_ * CK, !w_resident);
     }
-    // the finished tile's stores go out BEHIND the loads just issued (see the header comment)
-    if (done) epilogue(dtile);
+    if (done) {
+      // the finished tile's stores go out BEHIND the loads just issued (see the header comment)
+      if (DEFER && tdone.grp != sgrp) {          // its sums start a new statistics group
+        stats_flush(sgrp);
+        stats_clear();
+        sgrp = tdone.grp;
+      }
+      epilogue(tdone);
+    }
     if (!have_next) break;
     fi_lds_barrier();                            // the next stage is in LDS (ds_write only; the loads just issued stay in flight)
   }
+  if constexpr (DEFER) stats_flush(sgrp);
 }
 
 #undef FI_V2_GEOMETRY
+
 // more than 64 KB of dynamic LDS per workgroup has to be allowed per kernel (once; gfx950 has 160 KB per CU)
 static inline bool fi_allow_big_lds(const void* kernel) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
