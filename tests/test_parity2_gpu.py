@@ -121,8 +121,9 @@ def test_base_client_fit_evaluate_get_parameters_two_rounds_against_the_oracle(p
         elif "conv_conv.0.bias" in k or "conv_conv.4.bias" in k:
             continue                                  # true gradient 0: Adam turns round-off into +-lr steps
         elif "running_" in k:
-            # batch statistics of activations downstream of weights that differ by ~lr: a looser, relative bound
-            assert np.abs(a - b).max() < 5e-2 * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max())
+            # batch statistics of activations downstream of weights that differ by ~lr (deep layers amplify): the vectors agree in
+            # the L2 sense
+            assert np.linalg.norm(a - b) < 0.1 * max(np.linalg.norm(b), 1e-3), (k, np.linalg.norm(a - b), np.linalg.norm(b))
         else:
             # four AdamW steps of ~lr each per weight: an element whose tiny gradient changes sign between two fp32
             # realisations moves by up to 2 * lr per step (0.08 in all); the bulk agrees far better
