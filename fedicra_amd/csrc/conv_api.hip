@@ -23,6 +23,8 @@ int fi_conv_fwd_v2_bf16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hi
 int fi_conv_fwd_v2_f16_k3(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_thin_f16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -48,8 +50,8 @@ static long wgrad_blocks() {
   return v;
 }
 
-// which forward kernel: [0] -1 = FI_V2 from the environment (default: per-layer choice), 0 = one-tile kernel, 1 = persistent
-// kernel wherever it applies; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
+// which forward kernel: [0] -1 = FI_V2 from the environment (default 2: per-layer choice), 0 = one-tile kernel, 1 = persistent
+// kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 = wave-specialised kernel with 4 / 8 producer waves; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
 static long g_tune[4] = {-1, 0, 0, 0};
 static long env_v2() {
   static long v = env_long("FI_V2", 2);      // 2 = the measured per-layer rule
@@ -214,10 +216,35 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
     const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
     const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+    // wave-specialised form (conv_fwd_ws_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 32-bit
+    // byte offsets into every tensor
+    {
+      const long big = (long)d->N * d->H * d->W * 2;
+      const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 32 && cout >= 32 && plain && d->H >= 8 &&
+                        big * d->c0 * (a.xf == 2 ? 4 : 1) < (1L << 32) && big * d->c1 < (1L << 32) &&
+                        big * d->co0 < (1L << 32) && big * d->co1 < (1L << 32) && (long)cout * 9 * cin * 2 < (1L << 32);
+      // Chosen by default for the batched fused launches (the K-1 LC forwards of an iteration in one launch: >= 1024
+      // (tile, slab) items keep the persistent grid evenly loaded) with the transforming loader, 32+ channels in and out:
+      // 1.1-1.33x the one-tile kernel on every such layer of unet_lc (profiles/r02_k_kbench2_ws.txt); pooled sources and the
+      // 12-image launches of the gradient path measured behind it and stay where they were.
+      const long items = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout > 32 ? 64 : 32);
+      const bool ws_auto = v2 == 2 && a.xf == 1 && items >= 1024;
+      if (fits && (v2 == 4 || v2 == 5 || ws_auto)) {
+        const int pw = v2 == 4 ? 4 : 8;
+        int n4 = cout > 32 ? 4 : 2;
+        if (v2_nf == 2 || v2_nf == 4) n4 = (int)v2_nf;
+        int c4 = (a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
+        if (v2_ck && a.xf != 2) c4 = (int)v2_ck;
+        a.tilesY = fi_cdiv(d->H, 16);
+        a.nct = fi_cdiv(cout, n4 * 16);
+        return d->dtype == FI_F16 ? fi_conv_fwd_ws_f16(n4, c4, pw, (int)v2_wgs, a, st)
+                                  : fi_conv_fwd_ws_bf16(n4, c4, pw, (int)v2_wgs, a, st);
+      }
+    }
     // thin-layer form (conv_thin_kernel): the whole filter in registers -- Cin <= 32, Cout <= 32, one destination.
     // Chosen by default where tools/kbench2.py --thin measured it ahead of the one-tile kernel (profiles/r02_h_*): every
-    // 16-channel-output layer (1.3-1.55x), 32 outputs only with the plain transforming loader (1.1x; dropout / pooled
-    // sources: 0.97-1.03x, left with the one-tile kernel)
+    // 16-channel-output layer (1.45-1.6x), 32 outputs with the plain transforming loader (1.14x) or a pooled source (1.2x);
+    // 32 outputs behind dropout: 1.0x, left where it was (the wave-specialised form above takes the batched launches)
     {
       const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && cin <= 32 && cout <= 32 &&
                         cout % 4 == 0 && d->co1 == 0 && plain && d->H >= 8 &&
@@ -225,7 +252,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       const int n3 = cout > 16 ? 2 : 1;
       const int c3 = (cin > 16 && a.xf != 2) ? 32 : 16;
       const bool t0_drop = a.t0.drop_mode != FI_DROP_NONE;
-      const bool thin_auto = v2 == 2 && (n3 == 1 || (a.xf == 1 && !t0_drop));
+      const bool thin_auto = v2 == 2 && (n3 == 1 || (a.xf == 1 && !t0_drop) || a.xf == 2);
       if (fits && cin <= c3 && (v2 == 3 || thin_auto)) {
         a.tilesY = fi_cdiv(d->H, 16);
         a.nct = 1;

@@ -801,9 +801,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
         xr[p][3] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb + pxb : OOB, 0, 0));
       } else {
         const unsigned o = ((unsigned)((ns * H + gy) * W + gx) * s.cs + s.co) * esz;
-        const v4u v = s.first ? __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0)
-                              : __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? o : OOB, 0, 0);
-        xr[p][0] = __builtin_bit_cast(vec_t, v);
+        // (a per-lane choice of buffer resource would be lowered to a readfirstlane loop around the load)
+        if (a.c1 == 0) {
+          xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
+        } else {
+          const T* const xb = reinterpret_cast<const T*>(s.first ? a.x0 : a.x1);
+          xr[p][0] = *reinterpret_cast<const vec_t*>(xb + (ok ? o / esz : 0u));       // zeroed at commit when !ok
+        }
       }
     }
     if (with_w) {
@@ -870,7 +874,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
       if (xrow0 < XRPP && py < XH) {
         vec_t val;
         if constexpr (XF == 0) {
-          val = xr[p][0];                                      // out-of-image / beyond-Cin vectors arrived as zeros
+          // one source: out-of-image / beyond-Cin vectors arrived as zeros (range-checked buffer loads)
+          val = a.c1 == 0 ? xr[p][0] : fi_vec_select(colok && gy >= 0 && gy < H, xr[p][0]);
         } else {
           const bool ok = colok && gy >= 0 && gy < H;           // z of the padding is 0, not act(shift)
           if constexpr (XF == 2) {
@@ -1142,6 +1147,526 @@ static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel, fourth form: WAVE-SPECIALISED persistent workgroups (channel-rich layers)
+// ---------------------------------------------------------------------------------------------
+// Measured on the 64..256-channel layers (ISA counts + tools/kprobe.sh): per 32-channel chunk a wave of the one-tile kernel
+// issues ~700 vector instructions of staging (addresses, BatchNorm + LeakyReLU of the producer, ~600 more with dropout) for
+// 144 MFMAs, and the two phases alternate behind barriers -- the matrix cores idle through every staging phase of their
+// own workgroup and the staging waits out its own load latency: 18-30 % MFMA busy.  Here the two jobs run CONCURRENTLY on
+// every SIMD: a workgroup is 8 waves, waves 0-3 ("consumers") only read operand fragments from LDS and issue MFMAs, waves
+// 4-7 ("producers") only load, transform and write the NEXT stage into the other half of a double-buffered LDS tile.  One
+// barrier per stage.  The producers keep two register sets: the loads of stage s+2 are issued before stage s+1 is
+// transformed, so a load has a full stage (~1 us) to land.  Persistent: a workgroup walks a contiguous run of (slab, tile)
+// items, so the producers run ahead across tile boundaries while the consumers store a finished tile; BatchNorm statistics
+// stay in consumer registers over the run and reach the fp64 accumulators once per (group, slab) with one atomic per lane.
+// Same LDS layouts, operand mapping, transforms (XF) and rounding as the other forms; 3x3, 16-bit storage, 16-row tiles.
+#ifndef FI_WS_DEBUG
+#define FI_WS_DEBUG 0          // kernel A/B builds: 1 no MFMAs, 2 no loads, 4 no LDS commit, 8 no transform, 16 no epilogue
+#endif
+template <typename T, int NF, int CK, int XF, int PW>
+__global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs a) {
+  constexpr int NT = (4 + PW) * 64, PT = PW * 64;                // threads: all, producers
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  constexpr int KS = 3, TH = 16, HALO = 1, XW = 18, XH = 18, KK = 9;
+  constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
+  constexpr int CKP = FiLdsStride<T, CK>::value;
+  constexpr int KC = KK * CK;
+  constexpr int KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
+  constexpr int WKP = FiLdsStride<T, KCP>::value;
+  constexpr int BN = NF * 16, MF = 4, VPP = CK / VG;
+  constexpr int XTILE = XH * XW * CKP, WTILE = BN * WKP, STAGE = XTILE + WTILE;     // elements
+  static_assert(CK > VG, "whole-vector channel counts only");
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const lds = reinterpret_cast<T*>(smem);                    // [2 stages]{ xs[XH*XW][CKP], ws[BN][WKP] }, [4 waves] strip[3 * BN] floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
+  const int H = a.H, W = a.W;
+
+  // ---- this workgroup's run of items; item = slab * ntile + tile (slab-major: a run keeps its slab and statistics group)
+  const int ntile = a.N * a.tilesY * a.tilesX, tpi = a.tilesY * a.tilesX;
+  const int nitem = ntile * a.nct;
+  const int per = (nitem + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int i_begin = (int)blockIdx.x * per, i_end = min(nitem, i_begin + per);
+  if (i_begin >= i_end) return;
+  const int nchunk = (cin + CK - 1) / CK;
+  const int nstage = (i_end - i_begin) * nchunk;
+
+  constexpr unsigned esz = sizeof(T);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned hw = (unsigned)H * (unsigned)W;
+
+  struct Item {
+    int tx, ty, n, ct;
+  };
+  auto item_at = [&](int item) {
+    Item c;
+    c.ct = item / ntile;
+    const int tile = item - c.ct * ntile;
+    c.n = tile / tpi;
+    const int r = tile - c.n * tpi;
+    c.ty = r / a.tilesX;
+    c.tx = r - c.ty * a.tilesX;
+    return c;
+  };
+  auto item_next = [&](Item c) {
+    if (++c.tx == a.tilesX) {
+      c.tx = 0;
+      if (++c.ty == a.tilesY) {
+        c.ty = 0;
+        if (++c.n == a.N) {
+          c.n = 0;
+          ++c.ct;
+        }
+      }
+    }
+    return c;
+  };
+
+  if (KCP > KC) {  // zero the K padding of both weight tiles once: never overwritten by the producers
+    constexpr int PV = (KCP - KC) / VG;
+    for (int i = tid; i < 2 * BN * PV; i += NT) {
+      const int b = i / (BN * PV), j = i % (BN * PV);
+      *reinterpret_cast<vec_t*>(&lds[b * STAGE + XTILE + (j / PV) * WKP + KC + (j % PV) * VG]) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+
+  if (producer) {
+    // =============================================================================================== producers
+    // Loads here are branch-free and fixed in number per stage: the compiler's wait-count bookkeeping must be able to tell
+    // "the older register set has landed" from "everything has landed" (a conditional or looped load -- e.g. the
+    // readfirstlane loop a per-lane choice of buffer resource turns into -- makes every later wait a vmcnt(0), which
+    // serialises a stage's load latency behind its transform).  Hence: per-lane 64-bit base pointers for the two sources
+    // (plain global loads; lanes outside the image read element 0 of their tensor and are zeroed at commit), one buffer
+    // resource for the weights, and the run's tail issues dead stages (`live` = false) instead of skipping them.
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w), 0, (unsigned)cout * KK * (unsigned)cin * esz, 0x00020000);
+
+    // staging geometry: a producer thread owns one vector column of the halo tile / of the weight slab
+    constexpr int XCOLS = XW * VPP, XRPP = PT / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
+    constexpr int WCOLS = KK * VPP, WRPP = PT / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
+    static_assert(XRPP >= 1 && WRPP >= 1, "tile too wide for the producer threads");
+    constexpr int NS = XF == 2 ? 4 : 1;
+    const int ptid = tid - 256;
+    const int xcol = ptid % XCOLS, xrow0 = ptid / XCOLS;
+    const int xpx = xcol / VPP, xv = xcol % VPP;
+    const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;
+    const int wcol = ptid % WCOLS, wrow0 = ptid / WCOLS;
+    const int wt = wcol / VPP, wv = wcol % VPP;
+    const int wlds0 = XTILE + wrow0 * WKP + wt * CK + wv * VG;
+
+    // a register set = everything stage k needs between its issue and its commit
+    struct Set {
+      vec_t x[XPASS][NS];
+      vec_t w[WPASS];
+      float sc[XF != 0 ? VG : 1], sh[XF != 0 ? VG : 1];
+      unsigned flags;           // bit p: pass p is inside the image; bit 16: source 0; bit 17: transform active
+      unsigned vix0;            // dropout element-vector index of pass 0
+    };
+    Set S0, S1;
+    const bool drop0 = XF == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+    uint64_t seed_base = 0;
+    if (drop0) {
+      seed_base = a.t0.seed;
+      if (a.t0.seed_offset) seed_base += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+    }
+    const T* const x0p = reinterpret_cast<const T*>(a.x0);
+    const T* const x1p = reinterpret_cast<const T*>(a.x1);
+    const float* const dummy = reinterpret_cast<const float*>(a.w);        // >= 32 readable bytes for inactive lanes
+
+    // addresses advance by a per-thread constant from pass to pass: one add and one select per load
+    const unsigned wstep = (unsigned)(WRPP * KK) * (unsigned)cin * esz;
+    auto issue = [&](Set& S, const Item& it, int cb, bool live) __attribute__((always_inline)) {
+#if FI_WS_DEBUG & 2
+      return;
+#endif
+      const int ci = cb + xv * VG;
+      const bool chok = live && ci < cin && xrow0 < XRPP;
+      const int cc = ci < cin ? ci : 0;
+      const bool first = cc < a.c0;
+      const unsigned cs = (unsigned)(first ? a.c0 : a.c1), co = (unsigned)(first ? cc : cc - a.c0);
+      const T* const xb = first ? x0p : x1p;
+      const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+      const int nl = it.n - grp * a.gimages;
+      const int ns = (XF != 0 && first && a.bcast0) ? nl : it.n;
+      const int gx = it.tx * 16 + xpx - HALO;
+      const int gy0 = it.ty * TH + xrow0 - HALO;
+      const bool colok = chok && (unsigned)gx < (unsigned)W;
+      unsigned flags = first ? 0x10000u : 0u;
+      if constexpr (XF == 2) {
+        const unsigned o0 = (unsigned)((ns * 2 * H + 2 * gy0) * (2 * W) + 2 * gx) * cs + co;
+        const unsigned rowe = (unsigned)(2 * W) * cs, step = (unsigned)(2 * XRPP) * rowe;
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+          const bool ok = colok && (unsigned)(gy0 + p * XRPP) < (unsigned)H;
+          flags |= ok ? (1u << p) : 0u;
+          const unsigned o = ok ? o0 + (unsigned)p * step : 0u, re = ok ? rowe : 0u, pe = ok ? cs : 0u;
+          S.x[p][0] = *reinterpret_cast<const vec_t*>(xb + o);
+          S.x[p][1] = *reinterpret_cast<const vec_t*>(xb + o + pe);
+          S.x[p][2] = *reinterpret_cast<const vec_t*>(xb + o + re);
+          S.x[p][3] = *reinterpret_cast<const vec_t*>(xb + o + re + pe);
+        }
+      } else {
+        const unsigned o0 = (unsigned)((ns * H + gy0) * W + gx) * cs + co;
+        const unsigned step = (unsigned)(XRPP * W) * cs;
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+          const bool ok = colok && (unsigned)(gy0 + p * XRPP) < (unsigned)H;
+          flags |= ok ? (1u << p) : 0u;
+          S.x[p][0] = *reinterpret_cast<const vec_t*>(xb + (ok ? o0 + (unsigned)p * step : 0u));
+        }
+      }
+      {
+        const int wci = cb + wv * VG;
+        const int gco0 = it.ct * BN + wrow0;
+        const bool wok = live && wci < cin && wrow0 < WRPP;
+        const int lim = min(BN, cout - it.ct * BN);              // uniform: rows of the slab that exist
+        const unsigned o0 = ((unsigned)(gco0 * KK + wt) * (unsigned)cin + (unsigned)wci) * esz;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) {
+          const bool ok = wok && wrow0 + p * WRPP < lim;
+          S.w[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? o0 + (unsigned)p * wstep : OOB, 0, 0));
+        }
+      }
+      if constexpr (XF != 0) {
+        const float* scp = first ? a.t0.scale : a.t1.scale;
+        const float* shp = first ? a.t0.shift : a.t1.shift;
+        const bool act = chok && scp != nullptr;
+        flags |= act ? 0x20000u : 0u;
+        const unsigned cofs = act ? (unsigned)grp * cs + co : 0u;
+        scp = act ? scp : dummy;
+        shp = act ? shp : dummy;
+#pragma unroll
+        for (int j = 0; j < VG; j += 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(scp + cofs + j);
+          const float4 h4 = *reinterpret_cast<const float4*>(shp + cofs + j);
+          S.sc[j] = s4.x, S.sc[j + 1] = s4.y, S.sc[j + 2] = s4.z, S.sc[j + 3] = s4.w;
+          S.sh[j] = h4.x, S.sh[j + 1] = h4.y, S.sh[j + 2] = h4.z, S.sh[j + 3] = h4.w;
+        }
+        S.vix0 = (unsigned)((nl * H + gy0) * W + gx) * (cs / VG) + co / VG;
+      }
+      S.flags = flags;
+    };
+
+    auto commit = [&](Set& S, const Item& it, int buf) __attribute__((always_inline)) {
+#if FI_WS_DEBUG & 4
+      return;
+#endif
+      T* const xs = lds + buf * STAGE;
+      const bool first = (S.flags & 0x10000u) != 0;
+      float slope = 1.f;
+      bool xf = false, drop = false;
+      uint64_t seed = 0;
+      unsigned vstep = 0;
+      if constexpr (XF != 0) {
+        slope = first ? a.t0.slope : a.t1.slope;
+        xf = (S.flags & 0x20000u) != 0;
+#if FI_WS_DEBUG & 8
+        xf = false;
+#endif
+        if constexpr (XF == 1) {
+          drop = drop0 && first;
+          const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+          seed = seed_base + (uint64_t)grp * a.t0.seed_gstride;
+          vstep = (unsigned)(XRPP * W) * ((unsigned)(first ? a.c0 : a.c1) / VG);
+        }
+      }
+      auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
+        float f[VG];
+        VecWords<T>::unpack(raw, f);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          const float v = f[j] * S.sc[XF != 0 ? j : 0] + S.sh[XF != 0 ? j : 0];
+          f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
+        }
+        if (drop) {
+#pragma unroll
+          for (int g4 = 0; g4 < VG / 4; ++g4) {
+            uint32_t rr[4];
+            fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
+          }
+        }
+        return VecWords<T>::pack(f);
+      };
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int py = xrow0 + p * XRPP;
+        if (xrow0 < XRPP && py < XH) {
+          const bool ok = (S.flags >> p) & 1u;                  // outside the image (or beyond Cin): z = 0, not act(shift)
+          vec_t val;
+          if constexpr (XF == 0) {
+            val = fi_vec_select(ok, S.x[p][0]);
+          } else if constexpr (XF == 2) {
+            float best[VG], cand[VG];
+            VecWords<T>::unpack(xf ? xform(S.x[p][0], 0) : S.x[p][0], best);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              VecWords<T>::unpack(xf ? xform(S.x[p][k], 0) : S.x[p][k], cand);
+#pragma unroll
+              for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
+            }
+            val = fi_vec_select(ok, VecWords<T>::pack(best));
+          } else {
+            val = fi_vec_select(ok, xf ? xform(S.x[p][0], S.vix0 + (unsigned)p * vstep) : S.x[p][0]);
+          }
+          *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < WPASS; ++p) {
+        const int col = wrow0 + p * WRPP;
+        if (wrow0 < WRPP && col < BN) *reinterpret_cast<vec_t*>(&xs[wlds0 + p * (WRPP * WKP)]) = S.w[p];
+      }
+    };
+
+    // cursors: `ci_` = the stage to issue next, `cc_` = the stage to commit next (one behind)
+    Item it_i = item_at(i_begin), it_c = it_i;
+    int ch_i = 0, ch_c = 0, k_i = 0;
+    auto adv_i = [&]() __attribute__((always_inline)) {
+      ++k_i;
+      if (++ch_i == nchunk) {
+        ch_i = 0;
+        it_i = item_next(it_i);
+      }
+    };
+    auto adv_c = [&]() __attribute__((always_inline)) {
+      if (++ch_c == nchunk) {
+        ch_c = 0;
+        it_c = item_next(it_c);
+      }
+    };
+    // prologue: stage 0 into buffer 0, stage 1 in flight
+    issue(S0, it_i, ch_i * CK, true);
+    adv_i();
+    issue(S1, it_i, ch_i * CK, k_i < nstage);
+    adv_i();
+    commit(S0, it_c, 0);
+    adv_c();
+    fi_lds_barrier();
+    for (int s = 0; s < nstage; s += 2) {
+      // stage s is being consumed from buffer 0: issue s+2 into set 0, commit s+1 (set 1) into buffer 1
+      issue(S0, it_i, ch_i * CK, k_i < nstage);
+      adv_i();
+      if (s + 1 < nstage) {
+        commit(S1, it_c, 1);
+        adv_c();
+      }
+      fi_lds_barrier();
+      if (s + 1 >= nstage) break;
+      // stage s+1 is being consumed from buffer 1: issue s+3 into set 1, commit s+2 (set 0) into buffer 0
+      issue(S1, it_i, ch_i * CK, k_i < nstage);
+      adv_i();
+      if (s + 2 < nstage) {
+        commit(S0, it_c, 0);
+        adv_c();
+      }
+      fi_lds_barrier();
+    }
+  } else {
+    // =============================================================================================== consumers
+    const int li = lane & 15, kg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t ry0 = __builtin_amdgcn_make_buffer_rsrc(
+        a.y0, 0, a.y0 ? (unsigned)a.N * hw * (unsigned)a.co0 * esz : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc(
+        a.y1, 0, (a.y1 && a.co1) ? (unsigned)a.N * hw * (unsigned)a.co1 * esz : 0u, 0x00020000);
+
+    f32x4 acc[MF][NF];
+    // One consumer wave per SIMD: nothing else hides its LDS latency, so the fragment reads are software-pipelined by hand
+    // and pinned with scheduling barriers -- the reads of contraction step k+1 are issued before the 4 x NF MFMAs of step k.
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+      const T* const xs = lds + buf * STAGE;
+      const T* const ws = xs + XTILE;
+      constexpr int NKS = KCP / KSTEP;                           // contraction steps: taps (CK = 32) or tap pairs (CK = 16)
+      frag_t A[2][MF], B[2][NF];
+      auto fetch = [&](int ks, int q) __attribute__((always_inline)) {
+        const int k0 = ks * KSTEP + kg * KV;
+        int t = k0 / CK;
+        const int cil = k0 % CK;
+        if (t > KK - 1) t = KK - 1;                              // padded K: the weight fragment is zero there
+        const int r = t / KS, sx = t % KS;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) B[q][f] = *reinterpret_cast<const frag_t*>(&ws[(f * 16 + li) * WKP + k0]);
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+          A[q][m] = *reinterpret_cast<const frag_t*>(&xs[((wave * MF + m + r) * XW + li + sx) * CKP + cil]);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) fetch(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[m][f] = mfma16(B[ks & 1][f], A[ks & 1][m], acc[m][f]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // BatchNorm statistics and the bias live in a wave-private strip of LDS ([sum BN][sum of squares BN][bias BN] floats):
+    // the consumer's registers are taken by the accumulators and two sets of operand fragments.  Per tile the wave folds
+    // its 4 x NF fragments over rows and lanes (DPP) and adds the BN pairs to the strip; the strip reaches the fp64
+    // accumulators once per (group, slab) of the run.  A wave's own LDS accesses execute in order: no barrier involved.
+    float* const strip = reinterpret_cast<float*>(lds + 2 * STAGE) + wave * (3 * BN);
+    auto stats_clear = [&]() __attribute__((always_inline)) {
+      if (lane < BN) strip[lane] = strip[BN + lane] = 0.f;
+    };
+    auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
+      if (!a.stats) return;
+      const int slot = (blockIdx.x * 4 + wave) & (FI_STATS_SLOTS - 1);
+      const int co = ct * BN + lane;
+      if (lane < BN && co < cout) {
+        double* const dst = &a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2];
+        atomicAdd(dst, (double)strip[lane]);
+        atomicAdd(dst + 1, (double)strip[BN + lane]);
+      }
+    };
+    auto load_bias = [&](int ct) __attribute__((always_inline)) {
+      const int co = ct * BN + lane;
+      if (lane < BN) strip[2 * BN + lane] = (a.bias && co < cout) ? a.bias[co] : 0.f;
+    };
+    auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+      const int gx = it.tx * 16 + li;
+      const bool colok = gx < W;
+      float ps[NF][4], pq[NF][4];
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ps[f][r] = pq[f][r] = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const float4 bv = *reinterpret_cast<const float4*>(&strip[2 * BN + f * 16 + kg * 4]);
+        const float bvr[4] = {bv.x, bv.y, bv.z, bv.w};
+        const int cg = it.ct * BN + f * 16 + kg * 4;             // whole 4-channel groups inside one destination (host)
+        const bool second = cg >= a.co0;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const int gy = it.ty * TH + wave * MF + m;
+          const bool ok = colok && gy < H;
+          const float mk = ok ? 1.f : 0.f;
+          const unsigned pix = (unsigned)((it.n * H + gy) * W + gx);
+          T e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = from_f32<T>(acc[m][f][r] + bvr[r]);
+            const float v = to_f32(e[r]) * mk;                   // tile overhang does not count
+            ps[f][r] += v;
+            pq[f][r] += v * v;
+          }
+          v2u qv;
+          memcpy(&qv, e, sizeof(qv));
+          const bool live = ok && cg < cout;
+          if (a.co1 == 0) {
+            __builtin_amdgcn_raw_buffer_store_b64(qv, ry0, live ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b64(qv, ry0, (live && !second) ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(qv, ry1, (live && second) ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
+          }
+        }
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          float4 sv, qv;
+          sv.x = fi_row16_sum(ps[f][0]), sv.y = fi_row16_sum(ps[f][1]), sv.z = fi_row16_sum(ps[f][2]), sv.w = fi_row16_sum(ps[f][3]);
+          qv.x = fi_row16_sum(pq[f][0]), qv.y = fi_row16_sum(pq[f][1]), qv.z = fi_row16_sum(pq[f][2]), qv.w = fi_row16_sum(pq[f][3]);
+          if (li == 0) {
+            float4* const sp = reinterpret_cast<float4*>(&strip[f * 16 + kg * 4]);
+            float4* const qp = reinterpret_cast<float4*>(&strip[BN + f * 16 + kg * 4]);
+            const float4 s0 = *sp, q0 = *qp;
+            *sp = make_float4(s0.x + sv.x, s0.y + sv.y, s0.z + sv.z, s0.w + sv.w);
+            *qp = make_float4(q0.x + qv.x, q0.y + qv.y, q0.z + qv.z, q0.w + qv.w);
+          }
+        }
+      }
+    };
+
+    Item it = item_at(i_begin);
+    int ch = 0;
+    int sgrp = a.gimages > 0 ? it.n / a.gimages : 0, sct = it.ct;
+    stats_clear();
+    load_bias(sct);
+    auto consume = [&](int buf) __attribute__((always_inline)) {
+      if (ch == 0) {
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#if !(FI_WS_DEBUG & 1)
+      mma(buf);
+#endif
+      if (++ch == nchunk) {
+        ch = 0;
+        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+        if (grp != sgrp || it.ct != sct) {                      // the finished tile starts a new (group, slab)
+          stats_flush(sgrp, sct);
+          stats_clear();
+          if (it.ct != sct) load_bias(it.ct);
+          sgrp = grp;
+          sct = it.ct;
+        }
+#if !(FI_WS_DEBUG & 16)
+        epilogue(it);
+#endif
+        it = item_next(it);
+      }
+    };
+    fi_lds_barrier();                                            // stage 0 is in buffer 0
+    for (int s = 0; s < nstage; s += 2) {
+      consume(0);
+      fi_lds_barrier();
+      if (s + 1 >= nstage) break;
+      consume(1);
+      fi_lds_barrier();
+    }
+    stats_flush(sgrp, sct);
+  }
+}
+
+template <typename T, int NF, int CK, int PW>
+static int launch_conv_fwd_ws(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
+  constexpr int XW = 18, XH = 18, KK = 9;
+  constexpr int KSTEP = DT<T>::KSTEP;
+  constexpr int KC = KK * CK, KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
+  constexpr int CKP = FiLdsStride<T, CK>::value, WKP = FiLdsStride<T, KCP>::value;
+  constexpr int BN = NF * 16;
+  const size_t lds = (size_t)2 * (XH * XW * CKP + BN * WKP) * sizeof(T) + (size_t)4 * 3 * BN * sizeof(float);
+  const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
+  long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
+  if (blocks > nitem) blocks = nitem;
+  const dim3 g((unsigned)blocks), b((4 + PW) * 64);
+  if (a.xf == 0) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws_kernel<T, NF, CK, 0, PW>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_ws_kernel<T, NF, CK, 0, PW>), g, b, lds, st, a);
+  } else if (a.xf == 1) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws_kernel<T, NF, CK, 1, PW>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_ws_kernel<T, NF, CK, 1, PW>), g, b, lds, st, a);
+  } else {
+    if constexpr (CK * (int)sizeof(T) <= 32) {                   // pooled sources: 4 raw vectors per staged one -> narrow chunks
+      static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws_kernel<T, NF, CK, 2, PW>);
+      (void)big;
+      hipLaunchKernelGGL((conv_fwd_ws_kernel<T, NF, CK, 2, PW>), g, b, lds, st, a);
+    } else {
+      return FI_ERR_UNSUPPORTED;
+    }
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward kernel, third form: the THIN layers (Cin <= 32, Cout <= 32: full and half resolution of the U-Net)
 // ---------------------------------------------------------------------------------------------
 // Measured (tools/kprobe.sh, ISA counts): at 16 or 32 channels the one-tile kernel is VALU-ISSUE bound, not memory bound --
@@ -1162,7 +1687,9 @@ static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 // Register budget: a 168-register cap (3 waves per SIMD) made the one-fragment instantiations 10-15 % faster than letting
 // hipcc take 158-190 registers unasked (it schedules for the occupancy it is promised); the two-fragment ones spill under
 // any cap worth having and are left alone (profiles/r02_h_thin_variants.txt).
-template <typename T, int NF, int CK, int XF>
+// TWO: the input is a concatenation of two tensors (c1 != 0) -- a compile-time split, so that the single-source loader is
+// straight-line buffer loads (a run-time branch per load measured 1.3-1.7x slower on the 16-channel layers).
+template <typename T, int NF, int CK, int XF, bool TWO>
 __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int KS = 3, TH = 16, HALO = 1, XW = 18, XH = 18, KK = 9;
@@ -1233,7 +1760,7 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
   const int xpx = xcol / VPP, xv = xcol % VPP;
   const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;
   const int xc = xv * VG;                                       // first channel of this thread's vector
-  const bool xfirst = xc < a.c0;                                // which source it comes from
+  const bool xfirst = !TWO || xc < a.c0;                        // which source it comes from
   const bool xchan = xc < cin && xrow0 < XRPP;
   const unsigned xcs = (unsigned)(xfirst ? a.c0 : a.c1), xco = (unsigned)(xfirst ? xc : xc - a.c0);
 
@@ -1277,9 +1804,15 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
         xr[p][3] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb + pxb : OOB, 0, 0));
       } else {
         const unsigned o = ((unsigned)((ns * H + gy) * W + gx) * xcs + xco) * esz;
-        const v4u v = xfirst ? __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0)
-                             : __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? o : OOB, 0, 0);
-        xr[p][0] = __builtin_bit_cast(vec_t, v);
+        // one resource per load instruction (a per-lane choice of resource is lowered to a readfirstlane loop): two sources
+        // go through per-lane base pointers and plain global loads; their out-of-image lanes read element 0 and are
+        // zeroed at commit
+        if constexpr (!TWO) {
+          xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
+        } else {
+          const T* const xb = reinterpret_cast<const T*>(xfirst ? a.x0 : a.x1);
+          xr[p][0] = *reinterpret_cast<const vec_t*>(xb + (ok ? o / esz : 0u));
+        }
       }
     }
   };
@@ -1339,7 +1872,8 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
       if (xrow0 < XRPP && py < XH) {
         vec_t val;
         if constexpr (XF == 0) {
-          val = xr[p][0];                                      // out-of-image vectors arrived as zeros
+          // one source: out-of-image vectors arrived as zeros (range-checked buffer loads)
+          val = !TWO ? xr[p][0] : fi_vec_select(colok && gy >= 0 && gy < H, xr[p][0]);
         } else {
           const bool ok = colok && gy >= 0 && gy < H;           // z of the padding is 0, not act(shift)
           if constexpr (XF == 2) {
@@ -1498,15 +2032,24 @@ static int launch_conv_thin(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
   long blocks = 256L * wgs_per_cu;
   if (blocks > ntile) blocks = ntile;
   const dim3 g((unsigned)blocks), b(256);
-  if (a.xf == 0)
-    hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 0>), g, b, lds, st, a);
-  else if (a.xf == 1)
-    hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 1>), g, b, lds, st, a);
-  else {
-    if constexpr (CK == 16)
-      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 2>), g, b, lds, st, a);
-    else
+  if (a.xf == 0) {
+    if (a.c1 == 0) {
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 0, false>), g, b, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 0, true>), g, b, lds, st, a);
+    }
+  } else if (a.xf == 1) {
+    if (a.c1 == 0) {
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 1, false>), g, b, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 1, true>), g, b, lds, st, a);
+    }
+  } else {
+    if constexpr (CK == 16) {
+      hipLaunchKernelGGL((conv_thin_kernel<T, NF, CK, 2, false>), g, b, lds, st, a);        // pooled sources: c1 == 0 (host)
+    } else {
       return FI_ERR_UNSUPPORTED;
+    }
   }
   FI_CHECK_LAUNCH();
   return 0;

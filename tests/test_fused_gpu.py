@@ -268,5 +268,21 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
                         assert float((d > 0).float().mean()) < 2e-3, ("thin", wgs)
                 if st_want is not None:
                     assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=1e-2), ("thin", wgs)
+        if c0 + c1 >= 32 and cout > 16:
+            # the wave-specialised kernel (producer / consumer waves, double-buffered LDS stages), every slab width / chunk;
+            # wgs = workgroups per CU of the persistent grid (1 = the product's; 8 = one item per workgroup at these sizes)
+            for nf in ([2, 4] if cout > 32 else [2]):
+                for ck in ([16] if pool else [16, 32]):
+                    for form, wgs in ((4, 1), (4, 8), (5, 1), (5, 8)):       # 4 / 5 = four / eight producer waves
+                        L.conv_tuning(form, nf, ck, wgs)
+                        got, st_got = run()
+                        torch.cuda.synchronize()
+                        for a, b in zip(got, want):
+                            if a is not None:
+                                d = (a.float() - b.float()).abs()
+                                assert bool((d <= 2 * ulp * b.float().abs() + 1e-3).all()), ("ws", form, nf, ck, wgs, float(d.max()))
+                                assert float((d > 0).float().mean()) < 2e-3, ("ws", form, nf, ck, wgs)
+                        if st_want is not None:
+                            assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=1e-2), ("ws", form, nf, ck, wgs)
     finally:
         L.conv_tuning(-1)

@@ -146,7 +146,16 @@ def test_base_client_fit_evaluate_get_parameters_two_rounds_against_the_oracle(p
     # best-model checkpoints of BaseClient._validate (flower_common.py:106-113)
     import os
     names = os.listdir(tmp_path)
-    assert "client_0_async_unet_best_model.pth" in names and any(n.startswith("client_1_async_iter_") for n in names)
+    for cid in range(K):
+        d = folded["client_%d_val_mean_dice" % cid]
+        # a checkpoint exists exactly when the Dice beat the initial best_performance of 0.0 (strict '>', as the reference)
+        assert (("client_%d_async_unet_best_model.pth" % cid) in names) == (d > 0.0), (cid, d, names)
+        assert any(n.startswith("client_%d_async_iter_" % cid) for n in names) == (d > 0.0)
+    # ... and the save path itself: a second evaluate after lowering the bar writes both files with the reference's names
+    clients[0].best_performance = -1.0
+    clients[0].evaluate(fl.EvaluateIns(parameters=params, config={"iter_global": rounds, "stage": "evaluate"}))
+    names = os.listdir(tmp_path)
+    assert "client_0_async_unet_best_model.pth" in names and any(n.startswith("client_0_async_iter_") for n in names)
     sd = torch.load(os.path.join(tmp_path, "client_0_async_unet_best_model.pth"))
     assert list(sd.keys()) == list(refs[0].state_dict().keys())
 

@@ -51,21 +51,30 @@ def main():
     ap.add_argument("--groups", type=int, default=7)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--only", default="")
+    ap.add_argument("--layers", default="", help="comma-separated layer indices (LAYERS order) to restrict the sweep to")
+    ap.add_argument("--ws", action="store_true", help="only the one-tile kernel vs the wave-specialised kernel")
     ap.add_argument("--thin", action="store_true", help="only the one-tile kernel vs the thin-layer kernel, thin layers only")
     a = ap.parse_args()
     td = torch.bfloat16
     dev = "cuda"
     configs = [("v1", (0, 0, 0, 0))] + [(f"nf{nf}ck{ck}w{w}", (1, nf, ck, w)) for nf in (1, 2, 4) for ck in (16, 32)
-                                        for w in (2, 4)] + [(f"thin_w{w}", (3, 0, 0, w)) for w in (2, 4, 8)]
+                                        for w in (2, 4)] + [(f"thin_w{w}", (3, 0, 0, w)) for w in (2, 4, 8)] + \
+        [(f"ws{pw}_nf{nf}ck{ck}", (4 if pw == 4 else 5, nf, ck, 1)) for pw in (4, 8) for nf in (2, 4) for ck in (16, 32)]
     if a.thin:
         configs = [c for c in configs if c[0] == "v1" or c[0].startswith("thin")]
+    if a.ws:
+        configs = [c for c in configs if c[0] == "v1" or c[0].startswith("ws")]
     tot = {}
     for mode in ("plain", "fused"):
         if a.only and a.only != mode:
             continue
         print(f"== {mode}: us per launch; best persistent config vs the one-tile kernel")
-        for (f, c0, c1, cout, kind) in LAYERS:
+        for li, (f, c0, c1, cout, kind) in enumerate(LAYERS):
+            if a.layers and str(li) not in a.layers.split(","):
+                continue
             if a.thin and (c0 + c1 > 32 or cout > 32):
+                continue
+            if a.ws and (c0 + c1 < 32 or cout <= 16):
                 continue
             H = int(a.size * f)
             G = a.groups if mode == "fused" else 1
@@ -97,6 +106,8 @@ def main():
                 if cfg[0] == 1 and pool and cfg[2] == 32:
                     continue
                 if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
+                    continue
+                if cfg[0] in (4, 5) and (c0 + c1 < 32 or cout <= 16 or (cfg[1] == 4 and cout <= 32) or (pool and cfg[2] == 32)):
                     continue
                 L.conv_tuning(*cfg)
                 try:
