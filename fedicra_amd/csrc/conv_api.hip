@@ -51,7 +51,7 @@ static long wgrad_blocks() {
 }
 
 // which forward kernel: [0] -1 = FI_V2 from the environment (default 2: per-layer choice), 0 = one-tile kernel, 1 = persistent
-// kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 = wave-specialised kernel with 4 / 8 producer waves; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
+// kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 / 6 = wave-specialised kernel with 4 / 8 / 2 x 4 producer waves; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
 static long g_tune[4] = {-1, 0, 0, 0};
 static long env_v2() {
   static long v = env_long("FI_V2", 2);      // 2 = the measured per-layer rule
@@ -221,7 +221,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     {
       const long big = (long)d->N * d->H * d->W * 2;
       const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 32 && cout >= 32 && plain && d->H >= 8 &&
-                        big * d->c0 * (a.xf == 2 ? 4 : 1) < (1L << 32) && big * d->c1 < (1L << 32) &&
+                        d->co0 % 8 == 0 && d->co1 % 8 == 0 && big * d->c0 * (a.xf == 2 ? 4 : 1) < (1L << 32) && big * d->c1 < (1L << 32) &&
                         big * d->co0 < (1L << 32) && big * d->co1 < (1L << 32) && (long)cout * 9 * cin * 2 < (1L << 32);
       // Chosen by default for the batched fused launches (the K-1 LC forwards of an iteration in one launch: >= 1024
       // (tile, slab) items keep the persistent grid evenly loaded) with the transforming loader, 32+ channels in and out:
@@ -229,8 +229,10 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // 12-image launches of the gradient path measured behind it and stay where they were.
       const long items = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout > 32 ? 64 : 32);
       const bool ws_auto = v2 == 2 && a.xf == 1 && items >= 1024;
-      if (fits && (v2 == 4 || v2 == 5 || ws_auto)) {
-        const int pw = v2 == 4 ? 4 : 8;
+      if (fits && (v2 == 4 || v2 == 5 || v2 == 6 || ws_auto)) {
+        // 8 consumer + 2 x 4 producer waves where the tile is wide enough to feed them (64+ outputs, measured 3-10 % ahead
+        // of 4 + 8); 32-output slabs and the statistics-only head measured ahead with 4 + 8
+        const int pw = v2 == 4 ? 4 : (v2 == 6 ? 44 : (v2 == 5 ? 8 : ((cout >= 64 && y0) ? 44 : 8)));
         int n4 = cout > 32 ? 4 : 2;
         if (v2_nf == 2 || v2_nf == 4) n4 = (int)v2_nf;
         int c4 = (a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
@@ -247,7 +249,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // 32 outputs behind dropout: 1.0x, left where it was (the wave-specialised form above takes the batched launches)
     {
       const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && cin <= 32 && cout <= 32 &&
-                        cout % 4 == 0 && d->co1 == 0 && plain && d->H >= 8 &&
+                        cout % 8 == 0 && d->co1 == 0 && plain && d->H >= 8 &&
                         (long)d->N * d->H * d->W * (cin > cout ? cin : cout) * 2 * (a.xf == 2 ? 4 : 1) < (1L << 32);
       const int n3 = cout > 16 ? 2 : 1;
       const int c3 = (cin > 16 && a.xf != 2) ? 32 : 16;

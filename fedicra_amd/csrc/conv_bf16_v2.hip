@@ -15,11 +15,14 @@ int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStre
   return FI_ERR_UNSUPPORTED;
 }
 
-#define WS_CASE(NF_, CK_) \
-  if (nf == NF_ && ck == CK_) \
-    return pw == 8 ? launch_conv_fwd_ws<bf16_t, NF_, CK_, 8>(a, wgs_per_cu, st) : launch_conv_fwd_ws<bf16_t, NF_, CK_, 4>(a, wgs_per_cu, st);
+#define WS_CASE(NF_, CK_)                                                         \
+  if (nf == NF_ && ck == CK_) {                                                   \
+    if (pw == 44) return launch_conv_fwd_ws<bf16_t, NF_, CK_, 44>(a, wgs_per_cu, st); \
+    if (pw == 8) return launch_conv_fwd_ws<bf16_t, NF_, CK_, 8>(a, wgs_per_cu, st);   \
+    return launch_conv_fwd_ws<bf16_t, NF_, CK_, 4>(a, wgs_per_cu, st);                \
+  }
 
-// pw = producer waves per workgroup (4 or 8) beside the 4 consumer waves
+// pw = producer waves per workgroup: 4 or 8 beside 4 consumer waves; 44 = two alternating teams of 4 beside 8 consumer waves
 int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st) {
   WS_CASE(2, 16) WS_CASE(4, 16) WS_CASE(2, 32) WS_CASE(4, 32)
   return FI_ERR_UNSUPPORTED;

@@ -1163,9 +1163,17 @@ static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 #ifndef FI_WS_DEBUG
 #define FI_WS_DEBUG 0          // kernel A/B builds: 1 no MFMAs, 2 no loads, 4 no LDS commit, 8 no transform, 16 no epilogue
 #endif
+// PW = 8: 4 consumer waves (4 tile rows each) + one team of 8 producer waves with two register sets (above).
+// PW = 44 ("duo"): 8 consumer waves (2 tile rows each) + TWO teams of 4 producer waves that alternate stages, one register
+//   set each -- 16 waves, 128 registers.  Two consumer waves per SIMD share its matrix pipe, so one wave's fragment reads and
+//   its epilogue (~750 instructions per tile: bias, rounding, stores, statistics) run under the other's MFMAs instead of
+//   idling the pipe; a team issues stage s+2 in one iteration and transforms / commits it in the next, so its loads need no
+//   wait-count bookkeeping (vmcnt(0) at commit is exact) and the coefficients are fetched at commit.
 template <typename T, int NF, int CK, int XF, int PW>
-__global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs a) {
-  constexpr int NT = (4 + PW) * 64, PT = PW * 64;                // threads: all, producers
+__global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs a) {
+  constexpr bool DUO = PW == 44;
+  constexpr int CW = DUO ? 8 : 4;                                // consumer waves
+  constexpr int NT = DUO ? 1024 : (4 + PW) * 64, PT = DUO ? 256 : PW * 64;        // threads: all, one producer team
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int KS = 3, TH = 16, HALO = 1, XW = 18, XH = 18, KK = 9;
   constexpr int VG = DT<T>::VG, KSTEP = DT<T>::KSTEP, KV = DT<T>::KV;
@@ -1173,7 +1181,7 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
   constexpr int KC = KK * CK;
   constexpr int KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
   constexpr int WKP = FiLdsStride<T, KCP>::value;
-  constexpr int BN = NF * 16, MF = 4, VPP = CK / VG;
+  constexpr int BN = NF * 16, MF = TH / CW, VPP = CK / VG;
   constexpr int XTILE = XH * XW * CKP, WTILE = BN * WKP, STAGE = XTILE + WTILE;     // elements
   static_assert(CK > VG, "whole-vector channel counts only");
   typedef typename DT<T>::vec_t vec_t;
@@ -1182,11 +1190,11 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const lds = reinterpret_cast<T*>(smem);                    // [2 stages]{ xs[XH*XW][CKP], ws[BN][WKP] }, [4 waves] strip[3 * BN] floats
+  T* const lds = reinterpret_cast<T*>(smem);                    // [2 stages]{ xs[XH*XW][CKP], ws[BN][WKP] }, [consumer waves] strip[3 * BN] floats
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;
+  const bool producer = wave >= CW;
   const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
   const int H = a.H, W = a.W;
 
@@ -1254,7 +1262,8 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
     constexpr int WCOLS = KK * VPP, WRPP = PT / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
     static_assert(XRPP >= 1 && WRPP >= 1, "tile too wide for the producer threads");
     constexpr int NS = XF == 2 ? 4 : 1;
-    const int ptid = tid - 256;
+    const int team = DUO ? (wave - CW) >> 2 : 0;
+    const int ptid = tid - CW * 64 - team * 256;
     const int xcol = ptid % XCOLS, xrow0 = ptid / XCOLS;
     const int xpx = xcol / VPP, xv = xcol % VPP;
     const int xlds0 = (xrow0 * XW + xpx) * CKP + xv * VG;
@@ -1266,11 +1275,12 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
     struct Set {
       vec_t x[XPASS][NS];
       vec_t w[WPASS];
-      float sc[XF != 0 ? VG : 1], sh[XF != 0 ? VG : 1];
+      float sc[(XF != 0 && !DUO) ? VG : 1], sh[(XF != 0 && !DUO) ? VG : 1];
+      unsigned cofs;            // (duo) element offset of this thread's coefficients, fetched at commit
       unsigned flags;           // bit p: pass p is inside the image; bit 16: source 0; bit 17: transform active
       unsigned vix0;            // dropout element-vector index of pass 0
     };
-    Set S0, S1;
+    Set S0, S1;                 // (duo: S0 only)
     const bool drop0 = XF == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM;
     uint64_t seed_base = 0;
     if (drop0) {
@@ -1341,14 +1351,17 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
         const bool act = chok && scp != nullptr;
         flags |= act ? 0x20000u : 0u;
         const unsigned cofs = act ? (unsigned)grp * cs + co : 0u;
-        scp = act ? scp : dummy;
-        shp = act ? shp : dummy;
+        S.cofs = cofs;
+        if constexpr (!DUO) {
+          scp = act ? scp : dummy;
+          shp = act ? shp : dummy;
 #pragma unroll
-        for (int j = 0; j < VG; j += 4) {
-          const float4 s4 = *reinterpret_cast<const float4*>(scp + cofs + j);
-          const float4 h4 = *reinterpret_cast<const float4*>(shp + cofs + j);
-          S.sc[j] = s4.x, S.sc[j + 1] = s4.y, S.sc[j + 2] = s4.z, S.sc[j + 3] = s4.w;
-          S.sh[j] = h4.x, S.sh[j + 1] = h4.y, S.sh[j + 2] = h4.z, S.sh[j + 3] = h4.w;
+          for (int j = 0; j < VG; j += 4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(scp + cofs + j);
+            const float4 h4 = *reinterpret_cast<const float4*>(shp + cofs + j);
+            S.sc[j] = s4.x, S.sc[j + 1] = s4.y, S.sc[j + 2] = s4.z, S.sc[j + 3] = s4.w;
+            S.sh[j] = h4.x, S.sh[j + 1] = h4.y, S.sh[j + 2] = h4.z, S.sh[j + 3] = h4.w;
+          }
         }
         S.vix0 = (unsigned)((nl * H + gy0) * W + gx) * (cs / VG) + co / VG;
       }
@@ -1365,9 +1378,24 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
       bool xf = false, drop = false;
       uint64_t seed = 0;
       unsigned vstep = 0;
+      float csc[VG], csh[VG];                                   // this thread's 8 scale / shift values
       if constexpr (XF != 0) {
         slope = first ? a.t0.slope : a.t1.slope;
         xf = (S.flags & 0x20000u) != 0;
+        if constexpr (DUO) {
+          const float* const scp = xf ? (first ? a.t0.scale : a.t1.scale) : dummy;
+          const float* const shp = xf ? (first ? a.t0.shift : a.t1.shift) : dummy;
+#pragma unroll
+          for (int j = 0; j < VG; j += 4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(scp + S.cofs + j);
+            const float4 h4 = *reinterpret_cast<const float4*>(shp + S.cofs + j);
+            csc[j] = s4.x, csc[j + 1] = s4.y, csc[j + 2] = s4.z, csc[j + 3] = s4.w;
+            csh[j] = h4.x, csh[j + 1] = h4.y, csh[j + 2] = h4.z, csh[j + 3] = h4.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VG; ++j) csc[j] = S.sc[j], csh[j] = S.sh[j];
+        }
 #if FI_WS_DEBUG & 8
         xf = false;
 #endif
@@ -1383,7 +1411,7 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
         VecWords<T>::unpack(raw, f);
 #pragma unroll
         for (int j = 0; j < VG; ++j) {
-          const float v = f[j] * S.sc[XF != 0 ? j : 0] + S.sh[XF != 0 ? j : 0];
+          const float v = f[j] * csc[j] + csh[j];
           f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
         }
         if (drop) {
@@ -1428,48 +1456,82 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
       }
     };
 
-    // cursors: `ci_` = the stage to issue next, `cc_` = the stage to commit next (one behind)
-    Item it_i = item_at(i_begin), it_c = it_i;
-    int ch_i = 0, ch_c = 0, k_i = 0;
-    auto adv_i = [&]() __attribute__((always_inline)) {
-      ++k_i;
-      if (++ch_i == nchunk) {
-        ch_i = 0;
-        it_i = item_next(it_i);
-      }
-    };
-    auto adv_c = [&]() __attribute__((always_inline)) {
-      if (++ch_c == nchunk) {
-        ch_c = 0;
-        it_c = item_next(it_c);
-      }
-    };
-    // prologue: stage 0 into buffer 0, stage 1 in flight
-    issue(S0, it_i, ch_i * CK, true);
-    adv_i();
-    issue(S1, it_i, ch_i * CK, k_i < nstage);
-    adv_i();
-    commit(S0, it_c, 0);
-    adv_c();
-    fi_lds_barrier();
-    for (int s = 0; s < nstage; s += 2) {
-      // stage s is being consumed from buffer 0: issue s+2 into set 0, commit s+1 (set 1) into buffer 1
-      issue(S0, it_i, ch_i * CK, k_i < nstage);
+    if constexpr (!DUO) {
+      // cursors: `it_i` = the stage to issue next, `it_c` = the stage to commit next (one behind)
+      Item it_i = item_at(i_begin), it_c = it_i;
+      int ch_i = 0, ch_c = 0, k_i = 0;
+      auto adv_i = [&]() __attribute__((always_inline)) {
+        ++k_i;
+        if (++ch_i == nchunk) {
+          ch_i = 0;
+          it_i = item_next(it_i);
+        }
+      };
+      auto adv_c = [&]() __attribute__((always_inline)) {
+        if (++ch_c == nchunk) {
+          ch_c = 0;
+          it_c = item_next(it_c);
+        }
+      };
+      // prologue: stage 0 into buffer 0, stage 1 in flight
+      issue(S0, it_i, ch_i * CK, true);
       adv_i();
-      if (s + 1 < nstage) {
-        commit(S1, it_c, 1);
-        adv_c();
-      }
-      fi_lds_barrier();
-      if (s + 1 >= nstage) break;
-      // stage s+1 is being consumed from buffer 1: issue s+3 into set 1, commit s+2 (set 0) into buffer 0
       issue(S1, it_i, ch_i * CK, k_i < nstage);
       adv_i();
-      if (s + 2 < nstage) {
-        commit(S0, it_c, 0);
-        adv_c();
+      commit(S0, it_c, 0);
+      adv_c();
+      fi_lds_barrier();
+      for (int s = 0; s < nstage; s += 2) {
+        // stage s is being consumed from buffer 0: issue s+2 into set 0, commit s+1 (set 1) into buffer 1
+        issue(S0, it_i, ch_i * CK, k_i < nstage);
+        adv_i();
+        if (s + 1 < nstage) {
+          commit(S1, it_c, 1);
+          adv_c();
+        }
+        fi_lds_barrier();
+        if (s + 1 >= nstage) break;
+        // stage s+1 is being consumed from buffer 1: issue s+3 into set 1, commit s+2 (set 0) into buffer 0
+        issue(S1, it_i, ch_i * CK, k_i < nstage);
+        adv_i();
+        if (s + 2 < nstage) {
+          commit(S0, it_c, 0);
+          adv_c();
+        }
+        fi_lds_barrier();
+      }
+    } else {
+      // team g owns the stages of parity g: while stage s is consumed, team (s & 1) issues stage s+2 and the other team
+      // commits stage s+1 into buffer (s+1) & 1
+      Item it = item_at(i_begin);
+      int ch = 0, k = 0;                                         // this team's current stage
+      auto adv = [&]() __attribute__((always_inline)) {
+        ++k;
+        if (++ch == nchunk) {
+          ch = 0;
+          it = item_next(it);
+        }
+      };
+      if (team == 0) {
+        issue(S0, it, 0, true);
+        commit(S0, it, 0);                                       // stage 0
+        adv();
+        adv();
+      } else {
+        adv();
+        issue(S0, it, ch * CK, k < nstage);                      // stage 1 in flight
       }
       fi_lds_barrier();
+      for (int s = 0; s < nstage; ++s) {
+        if ((s & 1) == team) {
+          issue(S0, it, ch * CK, k < nstage);                    // k == s + 2
+        } else {
+          if (s + 1 < nstage) commit(S0, it, (s + 1) & 1);       // k == s + 1
+          adv();
+          adv();
+        }
+        fi_lds_barrier();
+      }
     }
   } else {
     // =============================================================================================== consumers
@@ -1522,7 +1584,7 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
     };
     auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
       if (!a.stats) return;
-      const int slot = (blockIdx.x * 4 + wave) & (FI_STATS_SLOTS - 1);
+      const int slot = (blockIdx.x * CW + wave) & (FI_STATS_SLOTS - 1);
       const int co = ct * BN + lane;
       if (lane < BN && co < cout) {
         double* const dst = &a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2];
@@ -1534,6 +1596,9 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
       const int co = ct * BN + lane;
       if (lane < BN) strip[2 * BN + lane] = (a.bias && co < cout) ? a.bias[co] : 0.f;
     };
+    // Stores: global stores are issue-bound (~7 B/clk/CU as 8-byte stores): two tile rows swap halves across the 16-lane
+    // rows of the wave (v_permlane16_swap) so that a lane holds 8 consecutive channels of ONE pixel -- half as many, 16-byte
+    // stores.  A statistics-only launch (no destination) issues none.
     auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
       const int gx = it.tx * 16 + li;
       const bool colok = gx < W;
@@ -1546,30 +1611,39 @@ __global__ __launch_bounds__((4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs 
       for (int f = 0; f < NF; ++f) {
         const float4 bv = *reinterpret_cast<const float4*>(&strip[2 * BN + f * 16 + kg * 4]);
         const float bvr[4] = {bv.x, bv.y, bv.z, bv.w};
-        const int cg = it.ct * BN + f * 16 + kg * 4;             // whole 4-channel groups inside one destination (host)
+        const int cg = it.ct * BN + f * 16 + (kg >> 1) * 8;      // the 8 channels this lane stores (whole groups per destination: host)
         const bool second = cg >= a.co0;
 #pragma unroll
-        for (int m = 0; m < MF; ++m) {
-          const int gy = it.ty * TH + wave * MF + m;
-          const bool ok = colok && gy < H;
-          const float mk = ok ? 1.f : 0.f;
-          const unsigned pix = (unsigned)((it.n * H + gy) * W + gx);
-          T e[4];
+        for (int mp = 0; mp < MF; mp += 2) {
+          v2u q[2];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            e[r] = from_f32<T>(acc[m][f][r] + bvr[r]);
-            const float v = to_f32(e[r]) * mk;                   // tile overhang does not count
-            ps[f][r] += v;
-            pq[f][r] += v * v;
+          for (int h = 0; h < 2; ++h) {
+            const int m = mp + h;
+            const bool okm = colok && it.ty * TH + wave * MF + m < H;
+            const float mk = okm ? 1.f : 0.f;
+            T e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              e[r] = from_f32<T>(acc[m][f][r] + bvr[r]);
+              const float v = to_f32(e[r]) * mk;                 // tile overhang does not count
+              ps[f][r] += v;
+              pq[f][r] += v * v;
+            }
+            memcpy(&q[h], e, sizeof(v2u));
           }
-          v2u qv;
-          memcpy(&qv, e, sizeof(qv));
-          const bool live = ok && cg < cout;
-          if (a.co1 == 0) {
-            __builtin_amdgcn_raw_buffer_store_b64(qv, ry0, live ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
-          } else {
-            __builtin_amdgcn_raw_buffer_store_b64(qv, ry0, (live && !second) ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(qv, ry1, (live && second) ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
+          if (a.y0) {
+            const v2u lo = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
+            const v2u hi = __builtin_amdgcn_permlane16_swap(q[0].y, q[1].y, false, false);
+            const v4u out = {lo.x, hi.x, lo.y, hi.y};            // channels cg .. cg+7 of pixel row mp + (kg & 1)
+            const int gy = it.ty * TH + wave * MF + mp + (kg & 1);
+            const bool live = colok && gy < H && cg < cout;
+            const unsigned pix = (unsigned)((it.n * H + gy) * W + gx);
+            if (a.co1 == 0) {
+              __builtin_amdgcn_raw_buffer_store_b128(out, ry0, live ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(out, ry0, (live && !second) ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(out, ry1, (live && second) ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
+            }
           }
         }
       }
@@ -1640,11 +1714,12 @@ static int launch_conv_fwd_ws(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
   constexpr int KC = KK * CK, KCP = ((KC + KSTEP - 1) / KSTEP) * KSTEP;
   constexpr int CKP = FiLdsStride<T, CK>::value, WKP = FiLdsStride<T, KCP>::value;
   constexpr int BN = NF * 16;
-  const size_t lds = (size_t)2 * (XH * XW * CKP + BN * WKP) * sizeof(T) + (size_t)4 * 3 * BN * sizeof(float);
+  constexpr int CW = PW == 44 ? 8 : 4, NT = PW == 44 ? 1024 : (4 + PW) * 64;
+  const size_t lds = (size_t)2 * (XH * XW * CKP + BN * WKP) * sizeof(T) + (size_t)CW * 3 * BN * sizeof(float);
   const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
   long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
   if (blocks > nitem) blocks = nitem;
-  const dim3 g((unsigned)blocks), b((4 + PW) * 64);
+  const dim3 g((unsigned)blocks), b(NT);
   if (a.xf == 0) {
     static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws_kernel<T, NF, CK, 0, PW>);
     (void)big;
@@ -1956,37 +2031,42 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
     fi_lds_barrier();                                            // `red` may be rewritten by the next flush
   };
 
+  // Stores are issue-bound as 8-byte stores (~7 B/clk/CU): two tile rows swap halves across the wave's 16-lane rows
+  // (v_permlane16_swap), a lane then holds 8 consecutive channels of ONE pixel -- half as many, 16-byte stores (Cout % 8 == 0: host).
   auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
     const int tx = tc.tx, ty = tc.ty, n = tc.n;
     const int gx = tx * 16 + li;
     const bool colok = gx < W;
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int gy = ty * TH + wave * MF + m;
-      const bool ok = colok && gy < H;
-      const float mk = ok ? 1.f : 0.f;
-      const unsigned pixo = (unsigned)((n * H + gy) * W + gx) * (unsigned)cout;
+    for (int f = 0; f < NF; ++f) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const int cg = f * 16 + kg * 4;
-        T e[4];
-        float v[4];
+      for (int mp = 0; mp < MF; mp += 2) {
+        v2u q[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e[r] = from_f32<T>(acc[m][f][r] + bv[f][r]);
-          v[r] = to_f32(e[r]) * mk;                             // tile overhang does not count
+        for (int h = 0; h < 2; ++h) {
+          const int m = mp + h;
+          const float mk = (colok && ty * TH + wave * MF + m < H) ? 1.f : 0.f;
+          T e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = from_f32<T>(acc[m][f][r] + bv[f][r]);
+            const float v = to_f32(e[r]) * mk;                  // tile overhang does not count
+            ssum[f][r] += v;
+            ssq[f][r] += v * v;
+          }
+          memcpy(&q[h], e, sizeof(v2u));
         }
-        v2u q;
-        memcpy(&q, e, sizeof(q));
-        __builtin_amdgcn_raw_buffer_store_b64(q, ry, (ok && cg < cout) ? (pixo + (unsigned)cg) * esz : OOB, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ssum[f][r] += v[r];
-          ssq[f][r] += v[r] * v[r];
-        }
+        const v2u lo = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
+        const v2u hi = __builtin_amdgcn_permlane16_swap(q[0].y, q[1].y, false, false);
+        const v4u out = {lo.x, hi.x, lo.y, hi.y};                // channels cg .. cg+7 of pixel row mp + (kg & 1)
+        const int gy = ty * TH + wave * MF + mp + (kg & 1);
+        const int cg = f * 16 + (kg >> 1) * 8;
+        const unsigned o = ((unsigned)((n * H + gy) * W + gx) * (unsigned)cout + (unsigned)cg) * esz;
+        __builtin_amdgcn_raw_buffer_store_b128(out, ry, (colok && gy < H && cg < cout) ? o : OOB, 0, 0);
       }
     }
   };
+
 
   // ---- segments = runs of tiles of one statistics group (coefficients, seeds and accumulators belong to the group); inside
   //      a segment the tile loop has conv_fwd_v2_kernel's ordering

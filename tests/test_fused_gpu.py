@@ -273,7 +273,7 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
             # wgs = workgroups per CU of the persistent grid (1 = the product's; 8 = one item per workgroup at these sizes)
             for nf in ([2, 4] if cout > 32 else [2]):
                 for ck in ([16] if pool else [16, 32]):
-                    for form, wgs in ((4, 1), (4, 8), (5, 1), (5, 8)):       # 4 / 5 = four / eight producer waves
+                    for form, wgs in ((4, 1), (5, 1), (5, 8), (6, 1), (6, 8)):       # 4 / 5 / 6 = 4 / 8 / 2 x 4 producer waves
                         L.conv_tuning(form, nf, ck, wgs)
                         got, st_got = run()
                         torch.cuda.synchronize()

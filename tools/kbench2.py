@@ -59,7 +59,7 @@ def main():
     dev = "cuda"
     configs = [("v1", (0, 0, 0, 0))] + [(f"nf{nf}ck{ck}w{w}", (1, nf, ck, w)) for nf in (1, 2, 4) for ck in (16, 32)
                                         for w in (2, 4)] + [(f"thin_w{w}", (3, 0, 0, w)) for w in (2, 4, 8)] + \
-        [(f"ws{pw}_nf{nf}ck{ck}", (4 if pw == 4 else 5, nf, ck, 1)) for pw in (4, 8) for nf in (2, 4) for ck in (16, 32)]
+        [(f"ws{pw}_nf{nf}ck{ck}", ({4: 4, 8: 5, 44: 6}[pw], nf, ck, 1)) for pw in (8, 44) for nf in (2, 4) for ck in (16, 32)]
     if a.thin:
         configs = [c for c in configs if c[0] == "v1" or c[0].startswith("thin")]
     if a.ws:
@@ -107,7 +107,7 @@ def main():
                     continue
                 if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
                     continue
-                if cfg[0] in (4, 5) and (c0 + c1 < 32 or cout <= 16 or (cfg[1] == 4 and cout <= 32) or (pool and cfg[2] == 32)):
+                if cfg[0] in (4, 5, 6) and (c0 + c1 < 32 or cout <= 16 or (cfg[1] == 4 and cout <= 32) or (pool and cfg[2] == 32)):
                     continue
                 L.conv_tuning(*cfg)
                 try:
