@@ -118,6 +118,44 @@ template <> struct VecWords<f16_t> {
   }
 };
 
+// Four fp32 values -> the 4-element group as stored (two 32-bit words of rounded 16-bit pairs, or a float4), and the values
+// AS STORED back in fp32 (what the BatchNorm statistics are taken of).  Typed 32-bit words only: an epilogue that fills a
+// T[4] and copies it out is reassembled by hipcc byte by byte (~8 extra instructions per pair).
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+  typedef float4 q_t;
+  static __device__ __forceinline__ q_t pack(float (&v)[4]) { return make_float4(v[0], v[1], v[2], v[3]); }
+  static __device__ __forceinline__ void unpack(const q_t& q, float (&v)[4]) { v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w; }
+};
+template <> struct Quad<bf16_t> {
+  typedef uint2 q_t;
+  static __device__ __forceinline__ void unpack(const q_t& q, float (&v)[4]) {
+    v[0] = __uint_as_float(q.x << 16), v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16), v[3] = __uint_as_float(q.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ q_t pack(float (&v)[4]) {                 // round to nearest even, as from_f32<bf16_t>
+    bf16x2_t a, b;
+    a[0] = (bf16_t)v[0], a[1] = (bf16_t)v[1], b[0] = (bf16_t)v[2], b[1] = (bf16_t)v[3];
+    const q_t q = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    unpack(q, v);
+    return q;
+  }
+};
+template <> struct Quad<f16_t> {
+  typedef uint2 q_t;
+  static __device__ __forceinline__ void unpack(const q_t& q, float (&v)[4]) {
+    const f16x2_t a = __builtin_bit_cast(f16x2_t, q.x), b = __builtin_bit_cast(f16x2_t, q.y);
+    v[0] = (float)a[0], v[1] = (float)a[1], v[2] = (float)b[0], v[3] = (float)b[1];
+  }
+  static __device__ __forceinline__ q_t pack(float (&v)[4]) {                 // overflow -> inf (GradScaler's signal)
+    f16x2_t a, b;
+    a[0] = (f16_t)v[0], a[1] = (f16_t)v[1], b[0] = (f16_t)v[2], b[1] = (f16_t)v[3];
+    const q_t q = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    unpack(q, v);
+    return q;
+  }
+};
+
 // Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32_dpp (quad xor 1, quad
 // xor 2, half-row mirror, row mirror).  The same pairings as an xor butterfly -- fp addition commutes, so the same bits --
 // without its four ds_bpermute round trips through the LDS unit (what __shfl_xor compiles to).

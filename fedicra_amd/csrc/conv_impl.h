@@ -523,22 +523,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             }
             if (ybase) *yp = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            union {
-              T e[4];
-              typename std::conditional<sizeof(T) == 2, uint2, float4>::type q;
-            } u;
+            typedef typename Quad<T>::q_t q_t;
             T* yp = reinterpret_cast<T*>(ybase) + o;
             if (!PLAIN && accum && ybase) {
-              u.q = *reinterpret_cast<decltype(u.q)*>(yp);
+              float old4[4];
+              Quad<T>::unpack(*reinterpret_cast<const q_t*>(yp), old4);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += to_f32(u.e[r]);
+              for (int r = 0; r < 4; ++r) v[r] += old4[r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              u.e[r] = from_f32<T>(v[r]);
-              v[r] = to_f32(u.e[r]);
-            }
-            if (ybase) *reinterpret_cast<decltype(u.q)*>(yp) = u.q;     // NULL destination: statistics-only launch
+            const q_t q = Quad<T>::pack(v);                              // v := the values as stored
+            if (ybase) *reinterpret_cast<q_t*>(yp) = q;                  // NULL destination: statistics-only launch
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1015,7 +1009,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
       for (int f = 0; f < NF; ++f) {
         const int cg = ct * BN + f * 16 + kg * 4;                // whole 4-channel groups inside one destination (host)
         const bool second = cg >= a.co0;
-        T e[4];
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1024,11 +1017,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_v2_kernel(ConvArgs a) {
             bias_r = bv[f][r];
           else
             bias_r = (a.bias && cg + r < cout) ? a.bias[cg + r] : 0.f;
-          e[r] = from_f32<T>(acc[m][f][r] + bias_r);
-          v[r] = to_f32(e[r]) * mk;                             // tile overhang does not count
+          v[r] = acc[m][f][r] + bias_r;
         }
-        v2u qv;
-        memcpy(&qv, e, sizeof(qv));
+        const v2u qv = __builtin_bit_cast(v2u, Quad<T>::pack(v));        // v := the values as stored
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= mk;                         // tile overhang does not count
         const bool live = ok && cg < cout;
         if (second)
           __builtin_amdgcn_raw_buffer_store_b64(qv, ry1, live ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
@@ -1621,15 +1614,15 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
             const int m = mp + h;
             const bool okm = colok && it.ty * TH + wave * MF + m < H;
             const float mk = okm ? 1.f : 0.f;
-            T e[4];
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[m][f][r] + bvr[r];
+            q[h] = __builtin_bit_cast(v2u, Quad<T>::pack(v));    // v := the values as stored
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              e[r] = from_f32<T>(acc[m][f][r] + bvr[r]);
-              const float v = to_f32(e[r]) * mk;                 // tile overhang does not count
-              ps[f][r] += v;
-              pq[f][r] += v * v;
+              ps[f][r] += v[r] * mk;                             // tile overhang does not count
+              pq[f][r] += (v[r] * mk) * v[r];
             }
-            memcpy(&q[h], e, sizeof(v2u));
           }
           if (a.y0) {
             const v2u lo = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
@@ -2046,15 +2039,15 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
         for (int h = 0; h < 2; ++h) {
           const int m = mp + h;
           const float mk = (colok && ty * TH + wave * MF + m < H) ? 1.f : 0.f;
-          T e[4];
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[m][f][r] + bv[f][r];
+          q[h] = __builtin_bit_cast(v2u, Quad<T>::pack(v));      // v := the values as stored
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            e[r] = from_f32<T>(acc[m][f][r] + bv[f][r]);
-            const float v = to_f32(e[r]) * mk;                  // tile overhang does not count
-            ssum[f][r] += v;
-            ssq[f][r] += v * v;
+            ssum[f][r] += v[r] * mk;                             // tile overhang does not count
+            ssq[f][r] += (v[r] * mk) * v[r];
           }
-          memcpy(&q[h], e, sizeof(v2u));
         }
         const v2u lo = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
         const v2u hi = __builtin_amdgcn_permlane16_swap(q[0].y, q[1].y, false, false);
