@@ -275,3 +275,55 @@ def test_config3_unet_lc_512_forward_matches_oracle():
         got = m(x.to(DEV), None)
     assert (got[0].cpu() - want[0]).abs().max().item() < 2e-4 * max(1.0, want[0].abs().max().item())
     assert (got[6][-1].cpu() - want[6][-1]).abs().max().item() < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- configs[3]: 3D U-Net 128^3, bf16
+# (S, c0, c1, cout): 3x3x3 convs of unet_3D (feature_scale 4) at the sizes a 2 x 1 x 128^3 patch batch runs them
+C4_LAYERS = [(128, 16, 0, 16), (64, 32, 0, 32), (32, 64, 0, 64), (32, 64, 32, 32), (64, 32, 16, 16)]
+
+
+@pytest.mark.parametrize("layer", C4_LAYERS, ids=lambda l: "{}^3_{}+{}to{}".format(*l))
+def test_config4_conv3d_instancenorm_at_full_size_bf16(layer):
+    """configs[3] (4 clients, 3D U-Net, 2 x 128^3 patches, bf16) at its own layer sizes, through size-independent properties:
+    (a) the adjoint identities tying the depth-sliced forward, dgrad and wgrad together -- <conv(x; w), g> = <x, dgrad(g)>
+    = <w, wgrad(x, g)> (bias 0), all three products of 16-bit operands accumulated in fp32, compared in fp64 to bf16 output
+    rounding (2^-8 per element, random signs: relative 4e-3 on sums of 1e6+ terms);  (b) the fused InstanceNorm3d + ReLU
+    (per-sample fp64 statistics accumulated by the centre depth tap's epilogue) against fp32 InstanceNorm + ReLU of the HIP
+    convolution's own output: element-wise to bf16 resolution, and the first two moments per (sample, channel) over the
+    whole volume to 0.5 % / 1 %."""
+    from fedicra_amd import ops3d
+    S, c0, c1, cout = layer
+    Nb, cin, dt = 2, c0 + c1, torch.bfloat16
+    conv = torch.nn.Conv3d(cin, cout, 3, 1, 1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_((rnd(*conv.weight.shape, seed=21) * (1.7 / np.sqrt(27 * cin))).to(dt).float())
+        conv.bias.zero_()
+    x0 = rnd(Nb, S, S, S, c0, seed=22).to(dt).to(DEV).requires_grad_(True)
+    x1 = rnd(Nb, S, S, S, c1, seed=23).to(dt).to(DEV).requires_grad_(True) if c1 else None
+    g = rnd(Nb, S, S, S, cout, seed=24).to(dt).to(DEV)
+    y = ops3d.conv3d(x0, x1, conv, norm=False)
+    assert y.dtype == dt and y.shape == (Nb, S, S, S, cout)
+    y.backward(g)
+    torch.cuda.synchronize()
+    lhs = dot(y.detach(), g)
+    via_x = dot(x0.detach(), x0.grad) + (dot(x1.detach(), x1.grad) if c1 else 0.0)
+    via_w = dot(conv.weight.detach(), conv.weight.grad)
+    scale = max(abs(lhs), float(y.detach().float().norm()) * float(g.float().norm()) * 1e-3)
+    assert abs(lhs - via_x) <= 4e-3 * scale, (lhs, via_x)
+    assert abs(lhs - via_w) <= 4e-3 * scale, (lhs, via_w)
+    # (b) fused InstanceNorm + ReLU of the same convolution
+    with torch.no_grad():
+        z = ops3d.conv3d(x0.detach(), None if x1 is None else x1.detach(), conv, norm=True)
+        yf = y.detach().float()
+        mean = yf.mean(dim=(1, 2, 3), keepdim=True)
+        var = yf.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        ref = torch.relu((yf - mean) * torch.rsqrt(var + 1e-5))
+        err = (z.float() - ref).abs()
+        assert float(err.max()) <= 3e-2 * max(1.0, float(ref.max())), float(err.max())
+        assert float(err.mean()) <= 2e-3, float(err.mean())
+        assert float((z < 0).sum()) == 0
+        # moments of the normalised volume, from the HIP output: E[relu(n)] and E[relu(n)^2] of a unit normal-ish field
+        # are not fixed numbers, the reference's are: compare the two per (sample, channel)
+        m1, m1r = z.float().mean(dim=(1, 2, 3)), ref.mean(dim=(1, 2, 3))
+        m2, m2r = (z.float() ** 2).mean(dim=(1, 2, 3)), (ref ** 2).mean(dim=(1, 2, 3))
+        assert torch.allclose(m1, m1r, rtol=5e-3, atol=2e-3) and torch.allclose(m2, m2r, rtol=1e-2, atol=2e-3)
