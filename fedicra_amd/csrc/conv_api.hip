@@ -244,17 +244,15 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       }
     }
     // thin-layer form (conv_thin_kernel): the whole filter in registers -- Cin <= 32, Cout <= 32, one destination.
-    // Chosen by default where tools/kbench2.py --thin measured it ahead of the one-tile kernel (profiles/r02_h_*): every
-    // 16-channel-output layer (1.45-1.6x), 32 outputs with the plain transforming loader (1.14x) or a pooled source (1.2x);
-    // 32 outputs behind dropout: 1.0x, left where it was (the wave-specialised form above takes the batched launches)
+    // Chosen by default wherever it applies: tools/kbench2.py --thin measures it ahead of the one-tile kernel on every such
+    // layer (profiles/r02_n_kbench2_thin.txt: 16 outputs 1.25-1.7x, 32 outputs 1.07-1.47x, plain and batched launches alike)
     {
       const bool fits = !f32 && d->ksize == 3 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cin >= 16 && cin <= 32 && cout <= 32 &&
                         cout % 8 == 0 && d->co1 == 0 && plain && d->H >= 8 &&
                         (long)d->N * d->H * d->W * (cin > cout ? cin : cout) * 2 * (a.xf == 2 ? 4 : 1) < (1L << 32);
       const int n3 = cout > 16 ? 2 : 1;
       const int c3 = (cin > 16 && a.xf != 2) ? 32 : 16;
-      const bool t0_drop = a.t0.drop_mode != FI_DROP_NONE;
-      const bool thin_auto = v2 == 2 && (n3 == 1 || (a.xf == 1 && !t0_drop) || a.xf == 2);
+      const bool thin_auto = v2 == 2;
       if (fits && cin <= c3 && (v2 == 3 || thin_auto)) {
         a.tilesY = fi_cdiv(d->H, 16);
         a.nct = 1;

@@ -1854,35 +1854,50 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
     return c;
   };
   vec_t xr[XPASS][NS];
+  // offsets advance by a per-thread constant from pass to pass (one add, one compare, one select per load); the image
+  // tests of the passes are kept as bits for the commit
+  const unsigned xstep = (unsigned)(XRPP * (XF == 2 ? 4 : 1)) * (unsigned)W * xcs * esz;
+  unsigned okbits = 0;
   auto issue = [&](const Tile& tc, int grp) __attribute__((always_inline)) {
     const int tx = tc.tx, ty = tc.ty, n = tc.n;
     const int ns = (XF != 0 && xfirst && a.bcast0) ? n - grp * a.gimages : n;
     const int gx = tx * 16 + xpx - HALO;
-    const bool colok = xchan && gx >= 0 && gx < W;
+    const int gy0 = ty * TH + xrow0 - HALO;
+    const bool colok = xchan && (unsigned)gx < (unsigned)W;
+    unsigned bits = 0;
+    if constexpr (XF == 2) {
+      const unsigned rowb = (unsigned)(2 * W) * xcs * esz, pxb = xcs * esz;
 #pragma unroll
-    for (int p = 0; p < XPASS; ++p) {
-      const int gy = ty * TH + xrow0 + p * XRPP - HALO;
-      const bool ok = colok && gy >= 0 && gy < H;
-      if constexpr (XF == 2) {
+      for (int p = 0; p < XPASS; ++p) {
+        const int gy = gy0 + p * XRPP;
+        const bool ok = colok && (unsigned)gy < (unsigned)H;
+        bits |= ok ? (1u << p) : 0u;
+        // (offsets recomputed per pass: carried in registers they cost the two-fragment instantiations their occupancy)
         const unsigned o = ((unsigned)((ns * 2 * H + 2 * gy) * (2 * W) + 2 * gx) * xcs + xco) * esz;
-        const unsigned rowb = (unsigned)(2 * W) * xcs * esz, pxb = xcs * esz;
         xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
         xr[p][1] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + pxb : OOB, 0, 0));
         xr[p][2] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb : OOB, 0, 0));
         xr[p][3] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o + rowb + pxb : OOB, 0, 0));
-      } else {
-        const unsigned o = ((unsigned)((ns * H + gy) * W + gx) * xcs + xco) * esz;
-        // one resource per load instruction (a per-lane choice of resource is lowered to a readfirstlane loop): two sources
-        // go through per-lane base pointers and plain global loads; their out-of-image lanes read element 0 and are
-        // zeroed at commit
+      }
+    } else {
+      const unsigned o0 = ((unsigned)((ns * H + gy0) * W + gx) * xcs + xco) * esz;
+      // one resource per load instruction (a per-lane choice of resource is lowered to a readfirstlane loop): two sources
+      // go through per-lane base pointers and plain global loads; their out-of-image lanes read element 0 and are
+      // zeroed at commit
+      const char* const xb = reinterpret_cast<const char*>(xfirst ? a.x0 : a.x1);
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const bool ok = colok && (unsigned)(gy0 + p * XRPP) < (unsigned)H;
+        bits |= ok ? (1u << p) : 0u;
+        const unsigned o = o0 + (unsigned)p * xstep;
         if constexpr (!TWO) {
           xr[p][0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(r0, ok ? o : OOB, 0, 0));
         } else {
-          const T* const xb = reinterpret_cast<const T*>(xfirst ? a.x0 : a.x1);
-          xr[p][0] = *reinterpret_cast<const vec_t*>(xb + (ok ? o / esz : 0u));
+          xr[p][0] = *reinterpret_cast<const vec_t*>(xb + (ok ? o : 0u));
         }
       }
     }
+    okbits = bits;
   };
 
   // transform state of the current statistics group (XF != 0): this thread's 8 scale / shift values, its dropout seed
@@ -1929,35 +1944,34 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
   };
 
   auto commit = [&](const Tile& tc, int grp) __attribute__((always_inline)) {
-    const int tx = tc.tx, ty = tc.ty, n = tc.n;
-    const int gx = tx * 16 + xpx - HALO;
-    const bool colok = xchan && gx >= 0 && gx < W;
-    const int nl = n - grp * a.gimages;
+    // dropout stream position of pass 0 (element-vector index inside the group's tensor), advancing by a constant per pass
+    unsigned vix0 = 0, vstep = 0;
+    if constexpr (XF == 1) {
+      const int nl = tc.n - grp * a.gimages;
+      vix0 = (unsigned)((nl * H + tc.ty * TH + xrow0 - HALO) * W + tc.tx * 16 + xpx - HALO) * (xcs / VG) + xco / VG;
+      vstep = (unsigned)(XRPP * W) * (xcs / VG);
+    }
 #pragma unroll
     for (int p = 0; p < XPASS; ++p) {
       const int py = xrow0 + p * XRPP;
-      const int gy = ty * TH + py - HALO;
       if (xrow0 < XRPP && py < XH) {
+        const bool ok = (okbits >> p) & 1u;                     // inside the image (and a real channel vector)
         vec_t val;
         if constexpr (XF == 0) {
           // one source: out-of-image vectors arrived as zeros (range-checked buffer loads)
-          val = !TWO ? xr[p][0] : fi_vec_select(colok && gy >= 0 && gy < H, xr[p][0]);
-        } else {
-          const bool ok = colok && gy >= 0 && gy < H;           // z of the padding is 0, not act(shift)
-          if constexpr (XF == 2) {
-            float best[VG], cand[VG];
-            VecWords<T>::unpack(xf ? xform(xr[p][0], 0) : xr[p][0], best);
+          val = !TWO ? xr[p][0] : fi_vec_select(ok, xr[p][0]);
+        } else if constexpr (XF == 2) {                         // z of the padding is 0, not act(shift)
+          float best[VG], cand[VG];
+          VecWords<T>::unpack(xf ? xform(xr[p][0], 0) : xr[p][0], best);
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
-              VecWords<T>::unpack(xf ? xform(xr[p][k], 0) : xr[p][k], cand);
+          for (int k = 1; k < 4; ++k) {
+            VecWords<T>::unpack(xf ? xform(xr[p][k], 0) : xr[p][k], cand);
 #pragma unroll
-              for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
-            }
-            val = fi_vec_select(ok, VecWords<T>::pack(best));
-          } else {
-            const unsigned vix = (unsigned)((nl * H + gy) * W + gx) * (xcs / VG) + xco / VG;
-            val = fi_vec_select(ok, xf ? xform(xr[p][0], vix) : xr[p][0]);
+            for (int j = 0; j < VG; ++j) best[j] = cand[j] > best[j] ? cand[j] : best[j];
           }
+          val = fi_vec_select(ok, VecWords<T>::pack(best));
+        } else {
+          val = fi_vec_select(ok, xf ? xform(xr[p][0], vix0 + (unsigned)p * vstep) : xr[p][0]);
         }
         *reinterpret_cast<vec_t*>(&xs[xlds0 + p * (XRPP * XW * CKP)]) = val;
       }
@@ -2026,7 +2040,9 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
 
   // Stores are issue-bound as 8-byte stores (~7 B/clk/CU): two tile rows swap halves across the wave's 16-lane rows
   // (v_permlane16_swap), a lane then holds 8 consecutive channels of ONE pixel -- half as many, 16-byte stores (Cout % 8 == 0: host).
-  auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
+  // (FULL: the tile lies inside the image -- the common case; no overhang mask on the statistics)
+  auto epilogue_t = [&](const Tile& tc, auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int tx = tc.tx, ty = tc.ty, n = tc.n;
     const int gx = tx * 16 + li;
     const bool colok = gx < W;
@@ -2038,15 +2054,16 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mp + h;
-          const float mk = (colok && ty * TH + wave * MF + m < H) ? 1.f : 0.f;
+          const float mk = (FULL || (colok && ty * TH + wave * MF + m < H)) ? 1.f : 0.f;
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[m][f][r] + bv[f][r];
           q[h] = __builtin_bit_cast(v2u, Quad<T>::pack(v));      // v := the values as stored
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            ssum[f][r] += v[r] * mk;                             // tile overhang does not count
-            ssq[f][r] += (v[r] * mk) * v[r];
+            const float vm = FULL ? v[r] : v[r] * mk;             // tile overhang does not count
+            ssum[f][r] += vm;
+            ssq[f][r] += vm * v[r];
           }
         }
         const v2u lo = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
@@ -2058,6 +2075,13 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
         __builtin_amdgcn_raw_buffer_store_b128(out, ry, (colok && gy < H && cg < cout) ? o : OOB, 0, 0);
       }
     }
+  };
+  auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
+    // (two copies of the epilogue cost the two-fragment instantiations 10-15 %: they keep the masked form only)
+    if (NF == 1 && tc.tx * 16 + 16 <= W && tc.ty * TH + TH <= H)
+      epilogue_t(tc, std::true_type());
+    else
+      epilogue_t(tc, std::false_type());
   };
 
 

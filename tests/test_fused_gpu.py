@@ -162,7 +162,8 @@ def test_probe_heatmaps_declines_when_it_does_not_apply():
     x = loader(1, 2, 32, cid=0, device=DEV)[0]["image"].unsqueeze(1)
     net = net_factory(argparse.Namespace(min_num_clients=3, cid=0), net_type="unet_lc", in_chns=1, class_num=2).cuda().train()
     with torch.no_grad():
-        assert net.probe_heatmaps(x, [1, 2]) is None          # no device RNG stream in this context
+        with ops.use_context(ops.new_context()):              # (a fresh context: an earlier test's may carry a stream)
+            assert net.probe_heatmaps(x, [1, 2]) is None      # no device RNG stream in this context
         ctx = ops.new_context()
         ctx.seed_offset = torch.zeros(1, dtype=torch.int32, device=DEV)
         with ops.use_context(ctx):
