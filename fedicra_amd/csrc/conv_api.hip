@@ -229,11 +229,17 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // 12-image launches of the gradient path measured behind it and stay where they were.
       const long items = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout > 32 ? 64 : 32);
       const bool ws_auto = v2 == 2 && a.xf == 1 && items >= 1024;
-      if (fits && (v2 == 4 || v2 == 5 || v2 == 6 || ws_auto)) {
+      // ... and for the plain launches of the gradient path (forward, dgrad, ALA: 12 images) with 64+ channels in and out:
+      // 4 + 8 waves, 32-channel slabs below 256 outputs -- 1.05x (128^2) to 1.2-1.56x (64^2, 32^2) the one-tile kernel, ahead
+      // of the persistent form on the layers that one had (profiles/r02_o_kbench2_ws_plain.txt)
+      const long items2 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout >= 256 ? 64 : 32);
+      const bool ws_plain = v2 == 2 && a.xf == 0 && cin >= 64 && cout >= 64 && items2 >= 192;
+      if (fits && (v2 == 4 || v2 == 5 || v2 == 6 || ws_auto || ws_plain)) {
         // 8 consumer + 2 x 4 producer waves where the tile is wide enough to feed them (64+ outputs, measured 3-10 % ahead
         // of 4 + 8); 32-output slabs and the statistics-only head measured ahead with 4 + 8
-        const int pw = v2 == 4 ? 4 : (v2 == 6 ? 44 : (v2 == 5 ? 8 : ((cout >= 64 && y0) ? 44 : 8)));
+        const int pw = v2 == 4 ? 4 : (v2 == 6 ? 44 : (v2 == 5 ? 8 : ((cout >= 64 && y0 && !ws_plain) ? 44 : 8)));
         int n4 = cout > 32 ? 4 : 2;
+        if (ws_plain && v2 == 2) n4 = cout >= 256 ? 4 : 2;
         if (v2_nf == 2 || v2_nf == 4) n4 = (int)v2_nf;
         int c4 = (a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
         if (v2_ck && a.xf != 2) c4 = (int)v2_ck;

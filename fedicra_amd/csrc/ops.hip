@@ -751,6 +751,44 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
   }
 }
 
+// Row form for the big launches (the batched LC forwards up-sample 84 images at a time): the flat form above spends ~250
+// vector instructions per 16-byte output vector, most of them three 32-bit divisions and the row's interpolation weights --
+// it is VALU-bound at 3.2 TB/s.  Here a workgroup owns output rows (row index and row weights are wave-uniform scalars),
+// a thread walks the row's vectors with a shift for the channel-vector split (C / VG a power of two).  The interpolation
+// expression is the flat form's, operand for operand: the two give the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int h,
+                                                                int w, int C, float sh, float sw, int cv_shift) {
+  constexpr int VG = DT<T>::VG;
+  const int Ho = 2 * h, Wo = 2 * w, rowv = Wo << cv_shift;       // vectors per output row
+  const int nrows = N * Ho;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int n = row / Ho, oy = row - n * Ho;
+    int y0, y1;
+    float ly0, ly1;
+    lin_coord(oy, h, sh, y0, y1, ly0, ly1);
+    const T* const r0 = x + ((size_t)n * h + y0) * w * C;
+    const T* const r1 = x + ((size_t)n * h + y1) * w * C;
+    T* const yo = y + (size_t)row * Wo * C;
+    for (int i = threadIdx.x; i < rowv; i += 256) {
+      const int ox = i >> cv_shift, cv = i - (ox << cv_shift);
+      int x0, x1;
+      float lx0, lx1;
+      lin_coord(ox, w, sw, x0, x1, lx0, lx1);
+      const int o0 = x0 * C + cv * VG, o1 = x1 * C + cv * VG;
+      float a00[VG], a01[VG], a10[VG], a11[VG], o[VG];
+      load_vec<T>(r0 + o0, a00);
+      load_vec<T>(r0 + o1, a01);
+      load_vec<T>(r1 + o0, a10);
+      load_vec<T>(r1 + o1, a11);
+#pragma unroll
+      for (int j = 0; j < VG; ++j)
+        o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+      store_vec<T>(yo + (size_t)i * VG, o);
+    }
+  }
+}
+
 // backward as a gather: for every input pixel collect the outputs whose 2x2 footprint touches it.
 // Along one axis the outputs touching input coordinate i are a contiguous run of at most 5 (the open interval
 // (i-1, i+1) / scale has length 4 + 2/(in-1)): `lo` = its first output, wt[k] = the weight output lo+k gives to i
@@ -863,32 +901,41 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 
 static inline float up_scale(int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
 
-extern "C" int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream) {
-  if (!x || !y) return FI_ERR_NULL;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == FI_F32) {
-    if (C % 4) return FI_ERR_SHAPE;
-    const long nvec = (long)N * 4 * h * w * (C / 4);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const float*)x,
-                       (float*)y, N, h, w, C, up_scale(h), up_scale(w));
-  } else if (dtype == FI_BF16) {
-    if (C % 8) return FI_ERR_SHAPE;
-    const long nvec = (long)N * 4 * h * w * (C / 8);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
-                       (const bf16_t*)x, (bf16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
-  } else if (dtype == FI_F16) {
-    if (C % 8) return FI_ERR_SHAPE;
-    const long nvec = (long)N * 4 * h * w * (C / 8);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st,
-                       (const f16_t*)x, (f16_t*)y, N, h, w, C, up_scale(h), up_scale(w));
+// launches big enough to be VALU-bound in the flat form take the row form (FI_UP_ROWS=0 keeps the flat form: A/B runs)
+template <typename T>
+static int launch_upsample_fwd(const void* x, void* y, int N, int h, int w, int C, hipStream_t st) {
+  constexpr int VG = DT<T>::VG;
+  if (C % VG) return FI_ERR_SHAPE;
+  const int CV = C / VG;
+  const long nvec = (long)N * 4 * h * w * CV;
+  if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+  static const long rows_min = [] {
+    const char* v = getenv("FI_UP_ROWS_MIN");
+    return v ? atol(v) : (1L << 21);
+  }();
+  int shift = 0;
+  while ((1 << shift) < CV) ++shift;
+  const long rowv = (long)2 * w * CV;
+  if ((1 << shift) == CV && nvec >= rows_min && rowv >= 256 && (long)N * 2 * h < (1L << 31)) {
+    long blocks = (long)N * 2 * h;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(upsample_fwd_rows_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)y, N, h, w, C,
+                       up_scale(h), up_scale(w), shift);
   } else {
-    return FI_ERR_DTYPE;
+    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(nvec, 256 * 2)), dim3(256), 0, st, (const T*)x, (T*)y, N, h, w, C,
+                       up_scale(h), up_scale(w));
   }
   FI_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream) {
+  if (!x || !y) return FI_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FI_F32) return launch_upsample_fwd<float>(x, y, N, h, w, C, st);
+  if (dtype == FI_BF16) return launch_upsample_fwd<bf16_t>(x, y, N, h, w, C, st);
+  if (dtype == FI_F16) return launch_upsample_fwd<f16_t>(x, y, N, h, w, C, st);
+  return FI_ERR_DTYPE;
 }
 
 extern "C" int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate,

@@ -287,3 +287,28 @@ def test_persistent_forward_kernel_equals_the_one_tile_kernel(dtype, case):
                             assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=1e-2), ("ws", form, nf, ck, wgs)
     finally:
         L.conv_tuning(-1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_upsample_row_form_equals_the_flat_form_bit_for_bit(dtype):
+    """fi_upsample2x_fwd picks the row form (one output row per workgroup, no divisions) for launches of >= 2^21 vectors -- the
+    batched LC forwards -- and the flat form below that: the same interpolation expression, so one batched launch equals its
+    images up-sampled one by one; and both agree with F.interpolate(align_corners=True)."""
+    from fedicra_amd import _lib as L
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+    vg = 4 if dtype == "fp32" else 8
+    for (N, h, w, C) in [(20, 128, 128, 4 * vg // 2), (12, 64, 96, 8 * vg), (5, 256, 256, 2 * vg)]:
+        gen = torch.Generator().manual_seed(N * 1000 + C)
+        x = torch.randn(N, h, w, C, generator=gen).to(DEV).to(td)
+        assert N * 4 * h * w * (C // vg) >= (1 << 21) > 4 * h * w * (C // vg)         # batched: row form; one image: flat form
+        y = torch.empty(N, 2 * h, 2 * w, C, dtype=td, device=DEV)
+        L.upsample2x_fwd(x, y)
+        y1 = torch.empty_like(y)
+        for n in range(N):
+            L.upsample2x_fwd(x[n:n + 1], y1[n:n + 1])
+        torch.cuda.synchronize()
+        assert torch.equal(y, y1), float((y.float() - y1.float()).abs().max())
+        ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+        # fp32: the source coordinate o * (in-1)/(out-1) carries ~1e-7 * out of rounding on either side -> 1e-4 of a unit step
+        tol = 3e-4 if dtype == "fp32" else 2e-2
+        assert float((y.float().permute(0, 3, 1, 2) - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
