@@ -108,8 +108,10 @@ int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t
 /* Measurement hook (tools/kbench.py, tests): which forward kernel fi_conv2d_fwd[_fused] launches.  v2 = -1: the library's
  * per-layer choice (default), 0: the one-tile kernel everywhere, 1: the persistent kernel wherever it applies (16-bit
  * storage, 3x3, whole-vector channel counts, plain epilogue), 3: the thin-layer kernel (filter in registers) wherever it
- * applies (additionally Cin, Cout <= 32, one destination); nf / ck / wgs_per_cu = 0 keep the defaults, else force the
- * persistent kernel's slab width (1, 2, 4 fragments of 16 channels), channel chunk (16, 32) and workgroups per CU.
+ * applies (additionally Cin, Cout <= 32, Cout % 8 == 0, one destination), 4 / 5 / 6: the wave-specialised kernel (producer /
+ * consumer waves, double-buffered LDS stages; additionally Cin, Cout >= 32, destinations of whole 8-channel groups) with
+ * 4 + 4, 4 + 8 or 8 + 2x4 consumer + producer waves; nf / ck / wgs_per_cu = 0 keep the defaults, else force the slab width
+ * (1, 2, 4 fragments of 16 channels; 2 or 4 for the wave-specialised kernel), channel chunk (16, 32) and workgroups per CU.
  * Process-wide, not thread-safe.  The kernels compute the same products in fp32; only the ORDER in which the channel chunks
  * are accumulated follows the chunk width, so two configurations agree to fp32 round-off (a bf16 output may differ in its
  * last bit for a few elements in 10^5), and bit for bit when their chunk widths agree. */
