@@ -332,8 +332,15 @@ class MyModel(nn.Module):
                         ops.bump_weights_epoch()              # temp's weights were rewritten through raw pointers
                         continue
                     if st["x"] is None or st["x"].shape != x.shape:
-                        st["x"], st["y"] = torch.empty_like(x), torch.empty_like(y)
-                        st["graph"], st["warm"] = None, False
+                        # static buffers + captured iteration PER BATCH SHAPE (a short last batch keeps its own pair)
+                        shapes = st.setdefault("shapes", {})
+                        if st["x"] is not None:
+                            shapes[tuple(st["x"].shape)] = (st["x"], st["y"], st["graph"], st["warm"], st.get("loss"))
+                        if tuple(x.shape) in shapes:
+                            st["x"], st["y"], st["graph"], st["warm"], st["loss"] = shapes[tuple(x.shape)]
+                        else:
+                            st["x"], st["y"] = torch.empty_like(x), torch.empty_like(y)
+                            st["graph"], st["warm"] = None, False
                     st["x"].copy_(x, non_blocking=True)
                     st["y"].copy_(y, non_blocking=True)
                     if not st["warm"]:                        # first batch ever: eager (allocations, operand packs)

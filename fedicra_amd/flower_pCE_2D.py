@@ -53,7 +53,8 @@ class MyClient(BaseClient):
         self.best_performance = 0.0
         self.use_graph = bool(getattr(args, "use_graph", False))
         self.optimizer = None
-        self._steps = {}
+        self._steps = {}                                     # captured iterations of the current batch shape, by freeze phase
+        self._shapes = {}                                    # batch shape -> (x buffer, y buffer, its captured iterations)
         self._xbuf = self._ybuf = None
         self.last_losses = []
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
@@ -77,9 +78,13 @@ class MyClient(BaseClient):
         if self.args.img_class == "faz":
             x = x.unsqueeze(1)                               # flower_pCE_2D.py:77
         if self._xbuf is None or self._xbuf.shape != x.shape:
-            self._xbuf = torch.empty(x.shape, dtype=torch.float32, device=dev)
-            self._ybuf = torch.empty(y.shape, dtype=torch.uint8, device=dev)
-            self._steps = {}
+            # static buffers and captured steps are kept PER BATCH SHAPE: the short last batch of an epoch (drop_last=False,
+            # as the reference's DataLoader) gets its own pair instead of invalidating the full-size graphs twice per epoch
+            key = tuple(x.shape)
+            if key not in self._shapes:
+                self._shapes[key] = (torch.empty(x.shape, dtype=torch.float32, device=dev),
+                                     torch.empty(y.shape, dtype=torch.uint8, device=dev), {})
+            self._xbuf, self._ybuf, self._steps = self._shapes[key]
         self._xbuf.copy_(x, non_blocking=True)
         self._ybuf.copy_(y, non_blocking=True)
         return self._xbuf, self._ybuf

@@ -645,3 +645,36 @@ def test_head_models_match_reference_golden(golden):
         ops.flush_wgrad()
         for k, p in m.named_parameters():
             assert_ck(p.grad.float().cpu(), g[f"{tag}/grad/{k}"], rtol=5e-3, atol=1e-6, what=f"{tag} grad {k}")
+
+
+def test_captured_steps_are_cached_per_batch_shape(monkeypatch):
+    """drop_last=False (the reference's DataLoader default) ends an epoch with a short batch: its static buffers and its
+    captured iteration live beside the full-size ones -- after the first pass over the loader no shape change captures or
+    runs eagerly again, and the short batch trains (its loss is finite and moves)."""
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet
+    from helpers import loader
+    captures = []
+    real = torch.cuda.CUDAGraph
+
+    class Counting(real):
+        def __new__(cls, *a, **k):
+            captures.append(1)
+            return super().__new__(cls, *a, **k)
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Counting)
+    full = loader(2, 4, 64, cid=0)
+    short = loader(1, 2, 64, cid=1)
+    batches = [full[0], full[1], short[0]]                    # 4, 4, 2 images: an epoch of 10 with batch size 4
+    args = _args(use_graph=True, iters=9)
+    net = _mk(UNet, 1, 2)
+    client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+    client._train({"iter_global": 9, "iters": 9, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    # per shape: eager first use, capture at the second, replay from then on -> exactly two captures in three epochs
+    assert len(captures) == 2, len(captures)
+    assert len(client._shapes) == 2 and all(len(v[2]) == 1 for v in client._shapes.values())
+    assert np.isfinite(client.last_losses).all() and len(client.last_losses) == 9
+    n0 = len(captures)
+    client._train({"iter_global": 12, "iters": 3, "eval_iters": 10, "batch_size": 4, "stage": "fit"})
+    assert len(captures) == n0                                # a later round replays all of it
