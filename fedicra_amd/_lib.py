@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -703,6 +703,12 @@ def ala_update(w, temp, grad, local, glob, eta, skip=None):
 
 def global_avgmax(x, avg, mx, amax):
     N, H, W, Cc = _dev(x).shape
+    S = lib().fi_global_avgmax_ranges(dt(x.dtype), N, H * W, Cc)
+    if S >= 2:                                               # large maps: pixel ranges on separate workgroups
+        ws = torch.empty(N * S * 3 * Cc, dtype=torch.float32, device=x.device)
+        _chk(lib().fi_global_avgmax_split(dt(x.dtype), ptr(x), ptr(avg), ptr(mx), ptr(amax), N, H * W, Cc, ptr(ws),
+                                          C.c_long(ws.numel() * 4), stream()), "fi_global_avgmax_split")
+        return
     _chk(lib().fi_global_avgmax(dt(x.dtype), ptr(x), ptr(avg), ptr(mx), ptr(amax), N, H * W, Cc, stream()),
          "fi_global_avgmax")
 

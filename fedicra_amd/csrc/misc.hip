@@ -601,6 +601,115 @@ extern "C" int fi_global_avgmax(int dtype, const void* x, float* avg, float* mx,
   return 0;
 }
 
+// Split form for the full-resolution maps (PCS pools 12 or 84 images of 512 x 512 x 16: the (N, C/64) grid above is 12-84
+// workgroups with a quarter of their lanes busy, 1.3 TB/s).  Stage 1: grid (S, N), a workgroup reduces one pixel range of one
+// image with 16-byte loads (thread = pixel lane x channel vector), lanes combined through LDS in lane order; its partial
+// (sum, max, first arg-max) goes to workspace[n][s][3][C].  Stage 2 folds the S partials of an image in range order.
+// Every order is fixed: deterministic; ties keep the lowest pixel index (first occurrence in scan order), as above.
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgmax_part_kernel(const T* __restrict__ x, float* __restrict__ part, int HW,
+                                                                 int C, int S) {
+  constexpr int VG = DT<T>::VG;
+  typedef typename DT<T>::vec_t vec_t;
+  extern __shared__ float sh[];                 // [PL][C] sums, [PL][C] maxima, [PL][C] indices (as int)
+  const int CV = C / VG, PL = 256 / CV;         // pixel lanes per workgroup (CV divides 256: host)
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int chunk = (HW + S - 1) / S, p0 = s * chunk, p1 = min(HW, p0 + chunk);
+  float sum[VG], mx[VG];
+  int mi[VG];
+#pragma unroll
+  for (int j = 0; j < VG; ++j) sum[j] = 0.f, mx[j] = -INFINITY, mi[j] = 0;
+  const T* const base = x + (size_t)n * HW * C + cv * VG;
+  for (int p = p0 + pl; p < p1; p += PL) {
+    float v[VG];
+    VecWords<T>::unpack(*reinterpret_cast<const vec_t*>(base + (size_t)p * C), v);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      sum[j] += v[j];
+      if (v[j] > mx[j]) mx[j] = v[j], mi[j] = p;
+    }
+  }
+  float* ss = sh;
+  float* sm = sh + PL * C;
+  int* si = reinterpret_cast<int*>(sh + 2 * PL * C);
+#pragma unroll
+  for (int j = 0; j < VG; ++j) {
+    ss[pl * C + cv * VG + j] = sum[j];
+    sm[pl * C + cv * VG + j] = mx[j];
+    si[pl * C + cv * VG + j] = mi[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float ts = 0.f, tm = -INFINITY;
+    int ti = 0;
+    for (int q = 0; q < PL; ++q) {
+      ts += ss[q * C + c];
+      const float m = sm[q * C + c];
+      const int i = si[q * C + c];
+      if (m > tm || (m == tm && i < ti)) tm = m, ti = i;
+    }
+    float* dst = part + ((size_t)n * S + s) * 3 * C;
+    dst[c] = ts;
+    dst[C + c] = tm;
+    reinterpret_cast<int*>(dst)[2 * C + c] = ti;
+  }
+}
+
+static __global__ __launch_bounds__(256) void global_avgmax_fold_kernel(const float* __restrict__ part, float* __restrict__ avg,
+                                                                        float* __restrict__ mx, int* __restrict__ amax, int HW,
+                                                                        int C, int S) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float ts = 0.f, tm = -INFINITY;
+    int ti = 0;
+    for (int s = 0; s < S; ++s) {
+      const float* src = part + ((size_t)n * S + s) * 3 * C;
+      ts += src[c];
+      const float m = src[C + c];
+      const int i = reinterpret_cast<const int*>(src)[2 * C + c];
+      if (m > tm || (m == tm && i < ti)) tm = m, ti = i;
+    }
+    avg[(size_t)n * C + c] = ts / (float)HW;
+    mx[(size_t)n * C + c] = tm;
+    if (amax) amax[(size_t)n * C + c] = ti;
+  }
+}
+
+// pixel ranges per image the split form wants for this shape (0: use fi_global_avgmax); workspace = N * S * 3 * C floats
+extern "C" int fi_global_avgmax_ranges(int dtype, int N, int HW, int C) {
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (N < 1 || HW < 1 || C < vg || C % vg || 256 % (C / vg) || C > 256) return 0;
+  if ((long)HW * C < (1L << 17)) return 0;                   // small maps: one workgroup per (image, 64 channels) is enough
+  long S = 2048 / N;
+  if (S > HW / 128) S = HW / 128;
+  return S < 2 ? 0 : (int)S;
+}
+
+extern "C" int fi_global_avgmax_split(int dtype, const void* x, float* avg, float* mx, int* amax, int N, int HW, int C,
+                                      float* workspace, long workspace_bytes, void* stream) {
+  if (!x || !avg || !mx || !workspace) return FI_ERR_NULL;
+  const int S = fi_global_avgmax_ranges(dtype, N, HW, C);
+  if (S < 2) return FI_ERR_UNSUPPORTED;
+  if (workspace_bytes < (long)N * S * 3 * C * (long)sizeof(float)) return FI_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8, PL = 256 / (C / vg);
+  const size_t lds = (size_t)3 * PL * C * sizeof(float);
+  const dim3 g(S, N), b(256);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(global_avgmax_part_kernel<float>, g, b, lds, st, (const float*)x, workspace, HW, C, S);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(global_avgmax_part_kernel<bf16_t>, g, b, lds, st, (const bf16_t*)x, workspace, HW, C, S);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(global_avgmax_part_kernel<f16_t>, g, b, lds, st, (const f16_t*)x, workspace, HW, C, S);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  hipLaunchKernelGGL(global_avgmax_fold_kernel, dim3(N), dim3(256), 0, st, workspace, avg, mx, amax, HW, C, S);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void channel_gate_fwd_kernel(const T* __restrict__ x, const float* __restrict__ h,
                                                                T* __restrict__ y, long n_elem, int HW, int C) {

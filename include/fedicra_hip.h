@@ -410,6 +410,13 @@ int fi_ala_update(float* w, float* temp, const float* grad, const float* local, 
  * PersonalizedChannelSelection (unet.py:103-144): global avg / max pool over H*W per (n,c);
  * amax (int32 [N,C], may be NULL) = pixel index of the first maximum (AdaptiveMaxPool2d backward). */
 int fi_global_avgmax(int dtype, const void* x, float* avg, float* mx, int* amax, int N, int HW, int C, void* stream);
+/* Split form of the same pooling for large maps (networks/unet.py:96-100 pools the full-resolution feature map): pixel
+ * ranges reduced by separate workgroups into a caller workspace and folded in range order -- deterministic, ties keep the
+ * first pixel.  fi_global_avgmax_ranges -> S (0: shape not worth splitting / unsupported: use fi_global_avgmax);
+ * workspace >= N * S * 3 * C floats. */
+int fi_global_avgmax_ranges(int dtype, int N, int HW, int C);
+int fi_global_avgmax_split(int dtype, const void* x, float* avg, float* mx, int* amax, int N, int HW, int C,
+                           float* workspace, long workspace_bytes, void* stream);
 /* y = x * (1 + h[n][c])   (x*h + x) */
 int fi_channel_gate_fwd(int dtype, const void* x, const float* h, void* y, int N, int HW, int C, void* stream);
 /* dx = dy*(1+h) + davg[n][c]/HW + (pixel == amax[n][c] ? dmx[n][c] : 0);

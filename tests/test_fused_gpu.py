@@ -312,3 +312,38 @@ def test_upsample_row_form_equals_the_flat_form_bit_for_bit(dtype):
         # fp32: the source coordinate o * (in-1)/(out-1) carries ~1e-7 * out of rounding on either side -> 1e-4 of a unit step
         tol = 3e-4 if dtype == "fp32" else 2e-2
         assert float((y.float().permute(0, 3, 1, 2) - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_split_global_pooling_equals_the_one_workgroup_form(dtype):
+    """fi_global_avgmax_split (PCS pooling of the full-resolution maps: pixel ranges on separate workgroups, folded in range
+    order) against the one-workgroup-per-image form and torch: maxima and FIRST arg-max identical (ties planted across range
+    and lane boundaries), means to fp32 round-off of a different summation order; replays are bit-identical."""
+    from fedicra_amd import _lib as L
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+    for (N, H, W, C) in [(12, 512, 512, 16), (3, 256, 384, 32), (5, 128, 128, 64)]:
+        gen = torch.Generator().manual_seed(N + C)
+        x = torch.randn(N, H, W, C, generator=gen).to(td)
+        x[:, 3, 5, :] = 9.0
+        x[:, H // 2, 7, :] = 9.0                               # the same maximum again, later in scan order
+        x[:, H - 1, W - 1, : C // 2] = 9.0
+        xd = x.to(DEV)
+        S = L.lib().fi_global_avgmax_ranges(L.dt(td), N, H * W, C)
+        assert S >= 2, (N, H, W, C)
+        out = []
+        for _ in range(2):
+            avg, mx = torch.empty(N, C, device=DEV), torch.empty(N, C, device=DEV)
+            am = torch.empty(N, C, dtype=torch.int32, device=DEV)
+            L.global_avgmax(xd, avg, mx, am)                   # takes the split form at these sizes
+            out.append((avg.clone(), mx.clone(), am.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(out[0], out[1]))
+        avg1, mx1 = torch.empty(N, C, device=DEV), torch.empty(N, C, device=DEV)
+        am1 = torch.empty(N, C, dtype=torch.int32, device=DEV)
+        rc = L.lib().fi_global_avgmax(L.dt(td), L.ptr(xd), L.ptr(avg1), L.ptr(mx1), L.ptr(am1), N, H * W, C, L.stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        avg, mx, am = out[0]
+        assert torch.equal(mx, mx1) and torch.equal(am, am1)
+        assert torch.equal(am.cpu().long(), torch.full((N, C), 3 * W + 5))
+        ref = x.float().mean((1, 2))
+        assert torch.allclose(avg.cpu(), ref, rtol=0, atol=2e-5) and torch.allclose(avg, avg1, rtol=0, atol=2e-5)
