@@ -741,9 +741,10 @@ extern "C" int fi_channel_gate_fwd(int dtype, const void* x, const float* h, voi
   return 0;
 }
 
-// grid (N, ceil(C/64)); block 256 = 4 pixel lanes x 64 channels.  dh by LDS reduction over pixel lanes.
-template <typename T>
-__global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+// grid (N, ceil(C/64)); block = PLN pixel lanes x 64 channels (PLN = 16 for maps of 256+ pixels: the grid is only
+// N * C/64 workgroups, the lanes are where the parallelism is).  dh by LDS reduction over the pixel lanes, in lane order.
+template <typename T, int PLN>
+__global__ __launch_bounds__(64 * PLN) void channel_gate_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const float* __restrict__ h,
                                                                const int* __restrict__ amax,
                                                                const float* __restrict__ davg,
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const T* __restri
     const float ga = davg ? davg[(size_t)n * C + c] / (float)HW : 0.f;
     const float gm = dmx ? dmx[(size_t)n * C + c] : 0.f;
     const int am = amax ? amax[(size_t)n * C + c] : -1;
-    for (int p = pl; p < HW; p += 4) {
+    for (int p = pl; p < HW; p += PLN) {
       const size_t o = ((size_t)n * HW + p) * C + c;
       const float g = to_f32(dy[o]);
       s += g * to_f32(x[o]);
@@ -765,10 +766,15 @@ __global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const T* __restri
       dx[o] = from_f32<T>(v);
     }
   }
-  __shared__ float ss[4][64];
+  __shared__ float ss[PLN][64];
   ss[pl][l] = s;
   __syncthreads();
-  if (pl == 0 && c < C && dh) dh[(size_t)n * C + c] = ss[0][l] + ss[1][l] + ss[2][l] + ss[3][l];
+  if (pl == 0 && c < C && dh) {
+    float t = ss[0][l];
+#pragma unroll
+    for (int q = 1; q < PLN; ++q) t += ss[q][l];
+    dh[(size_t)n * C + c] = t;
+  }
 }
 
 extern "C" int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, const float* h, const int* amax,
@@ -776,18 +782,27 @@ extern "C" int fi_channel_gate_bwd(int dtype, const void* x, const void* dy, con
                                    void* stream) {
   if (!x || !dy || !h || !dx) return FI_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(N, fi_cdiv(C, 64)), b(256);
+  const dim3 g(N, fi_cdiv(C, 64));
+  const bool wide = HW >= 256;
+  const dim3 b(wide ? 1024 : 256);
+#define FI_GATE_BWD(T_)                                                                                              \
+  do {                                                                                                             \
+    if (wide)                                                                                                      \
+      hipLaunchKernelGGL((channel_gate_bwd_kernel<T_, 16>), g, b, 0, st, (const T_*)x, (const T_*)dy, h, amax, davg, \
+                         dmx, (T_*)dx, dh, HW, C);                                                                 \
+    else                                                                                                           \
+      hipLaunchKernelGGL((channel_gate_bwd_kernel<T_, 4>), g, b, 0, st, (const T_*)x, (const T_*)dy, h, amax, davg,  \
+                         dmx, (T_*)dx, dh, HW, C);                                                                 \
+  } while (0)
   if (dtype == FI_F32)
-    hipLaunchKernelGGL(channel_gate_bwd_kernel<float>, g, b, 0, st, (const float*)x, (const float*)dy, h, amax, davg,
-                       dmx, (float*)dx, dh, HW, C);
+    FI_GATE_BWD(float);
   else if (dtype == FI_BF16)
-    hipLaunchKernelGGL(channel_gate_bwd_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)x, (const bf16_t*)dy, h, amax,
-                       davg, dmx, (bf16_t*)dx, dh, HW, C);
+    FI_GATE_BWD(bf16_t);
   else if (dtype == FI_F16)
-    hipLaunchKernelGGL(channel_gate_bwd_kernel<f16_t>, g, b, 0, st, (const f16_t*)x, (const f16_t*)dy, h, amax,
-                       davg, dmx, (f16_t*)dx, dh, HW, C);
+    FI_GATE_BWD(f16_t);
   else
     return FI_ERR_DTYPE;
+#undef FI_GATE_BWD
   FI_CHECK_LAUNCH();
   return 0;
 }
