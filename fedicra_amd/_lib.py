@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -47,6 +47,9 @@ class FiBnAct(C.Structure):
     _fields_ = [("dtype", C.c_int), ("pixels", C.c_long), ("C", C.c_int), ("hw", C.c_int), ("slope", C.c_float),
                 ("drop_mode", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64), ("mask", C.c_void_p),
                 ("seed_offset", C.c_void_p)]
+
+
+FI_ERR_UNSUPPORTED = -3                                    # include/fedicra_hip.h
 
 
 class FiError(RuntimeError):
@@ -626,6 +629,30 @@ def conv3d_fwd(x0, x1, w_taps, bias, y, stats, *, ksize, y_f32=False):
     stride = 0 if stats is None else stats.stride(0)
     _chk(lib().fi_conv3d_fwd(C.byref(d), D, ptr(x0), ptr(x1), _taps_array(w_taps), ptr(bias), ptr(y), ptr(stats),
                              C.c_long(stride), stream()), "fi_conv3d_fwd")
+
+
+def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):
+    """One-launch 3x3x3 convolution (w_all [Cout][9][3][cin]); y written.  -> False when the shape is not covered."""
+    N, D, H, W, c0 = _dev(x0).shape
+    c1 = 0 if x1 is None else x1.shape[4]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, y.shape[4], 0, 0, 0, 0)
+    stride = 0 if stats is None else stats.stride(0)
+    rc = lib().fi_conv3d_fwd_fused(C.byref(d), D, ptr(x0), ptr(x1), ptr(w_all), ptr(bias), ptr(y), ptr(stats),
+                                   C.c_long(stride), stream())
+    if rc == FI_ERR_UNSUPPORTED:
+        return False
+    _chk(rc, "fi_conv3d_fwd_fused")
+    return True
+
+
+def conv3d_dgrad_fused(dy, wt_all, d0, d1, *, ksize):
+    N, D, H, W, cout = _dev(dy).shape
+    d = FiConv(dt(dy.dtype), N, H, W, ksize, cout, 0, d0.shape[4], 0 if d1 is None else d1.shape[4], 0, 0, 0)
+    rc = lib().fi_conv3d_dgrad_fused(C.byref(d), D, ptr(dy), ptr(wt_all), ptr(d0), ptr(d1), stream())
+    if rc == FI_ERR_UNSUPPORTED:
+        return False
+    _chk(rc, "fi_conv3d_dgrad_fused")
+    return True
 
 
 def conv3d_dgrad(dy, wt_taps, d0, d1, *, ksize):

@@ -79,7 +79,7 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
 
 static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
                          const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
-                         double* stats, long stats_group_stride, void* stream);
+                         double* stats, long stats_group_stride, void* stream, int depth = 0);
 
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
@@ -121,7 +121,7 @@ static int fill_xform(const FiInXform* t, InXform* o, int is_second) {
 
 static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
                          const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
-                         double* stats, long stats_group_stride, void* stream) {
+                         double* stats, long stats_group_stride, void* stream, int depth) {
   if (!d || !x0 || !w) return FI_ERR_NULL;
   if (!y0 && (!stats || y1)) return FI_ERR_NULL;          // y0 == NULL: statistics-only launch (nothing is stored)
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
@@ -208,6 +208,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
   a.tilesX = fi_cdiv(d->W, 16);
   a.tilesY = fi_cdiv(d->H, th);
   a.nct = nct;
+  a.depth = 0;
 #ifdef FI_TRACE
   a.trace = g_trace;
 #endif
@@ -227,6 +228,22 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // (tile, slab) items keep the persistent grid evenly loaded) with the transforming loader, 32+ channels in and out:
       // 1.1-1.33x the one-tile kernel on every such layer of unet_lc (profiles/r02_k_kbench2_ws.txt); pooled sources and the
       // 12-image launches of the gradient path measured behind it and stay where they were.
+      if (depth > 0) {
+        // one-launch 3x3x3 convolution (fi_conv3d_*): the depth taps are channel groups of the contraction; 16-output layers take
+        // a half-filled 32-channel slab (they are memory-bound)
+        const int cr = d->c0 + d->c1;
+        const bool ok3 = !f32 && d->ksize == 3 && a.xf == 0 && plain && d->c0 % 8 == 0 && d->c1 % 8 == 0 && cr >= 16 && cout >= 16 &&
+                         d->co0 % 8 == 0 && d->co1 % 8 == 0 && d->H >= 8 && d->N % depth == 0 &&
+                         big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
+                         big * d->co1 < (1L << 32) && (long)cout * 27 * cr * 2 < (1L << 32);
+        if (!ok3) return FI_ERR_UNSUPPORTED;
+        const int n4 = cout > 32 ? 4 : 2;
+        a.depth = depth;
+        a.tilesY = fi_cdiv(d->H, 16);
+        a.nct = fi_cdiv(cout, n4 * 16);
+        const int pw = cout >= 64 ? 44 : 8;
+        return d->dtype == FI_F16 ? fi_conv_fwd_ws_f16(n4, 32, pw, 0, a, st) : fi_conv_fwd_ws_bf16(n4, 32, pw, 0, a, st);
+      }
       const long items = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout > 32 ? 64 : 32);
       const bool ws_auto = v2 == 2 && a.xf == 1 && items >= 1024;
       // ... and for the plain launches of the gradient path (forward, dgrad, ALA: 12 images) with 64+ channels in and out:
@@ -515,6 +532,35 @@ extern "C" int fi_conv3d_fwd(const FiConv* d, int D, const void* x0, const void*
       if (rc) return rc;
     }
   return 0;
+}
+
+// One-launch form (conv_fwd_ws_kernel with depth taps): every slice of every volume is an image of ONE implicit GEMM whose
+// contraction runs over 9 in-plane taps x 3 depth taps x channels; w_all = the filter as [Cout][k*k][3][c0 + c1] (the three
+// per-tap operands of fi_conv3d_fwd interleaved), y is WRITTEN (no zeroing, no read-modify-write passes), the statistics are
+// per volume.  FI_ERR_UNSUPPORTED when the shape is not covered (fp32, 1x1x1, channel counts that are not multiples of 8,
+// fewer than 16 channels): the caller falls back to fi_conv3d_fwd.
+extern "C" int fi_conv3d_fwd_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* w_all, const float* bias,
+                                   void* y, double* stats, long stats_stride, void* stream) {
+  if (!d || !x0 || !w_all || !y) return FI_ERR_NULL;
+  if (D < 1 || d->co1 != 0 || (d->c1 > 0 && !x1)) return FI_ERR_SHAPE;
+  if (d->ksize != 3 || d->accumulate0 || d->accumulate1 || d->y_f32) return FI_ERR_UNSUPPORTED;
+  if ((long)d->N * D > 0x7fffffffL) return FI_ERR_UNSUPPORTED;
+  FiConv s = *d;
+  s.N = d->N * D;
+  return conv_fwd_impl(&s, nullptr, nullptr, D, 0, x0, x1, w_all, bias, y, nullptr, stats, stats_stride, stream, D);
+}
+
+// dgrad of the same: d->c0 = channels of dy, d->co0 / co1 = channels of the (possibly concatenated) input; wt_all = the
+// flipped / transposed filter as [c_in][k*k][3][Cout] with the depth taps reversed; d0 / d1 are WRITTEN.
+extern "C" int fi_conv3d_dgrad_fused(const FiConv* d, int D, const void* dy, const void* wt_all, void* d0, void* d1,
+                                     void* stream) {
+  if (!d || !dy || !wt_all || !d0) return FI_ERR_NULL;
+  if (D < 1 || d->c1 != 0 || (d->co1 > 0 && !d1)) return FI_ERR_SHAPE;
+  if (d->ksize != 3 || d->accumulate0 || d->accumulate1 || d->y_f32) return FI_ERR_UNSUPPORTED;
+  if ((long)d->N * D > 0x7fffffffL) return FI_ERR_UNSUPPORTED;
+  FiConv s = *d;
+  s.N = d->N * D;
+  return conv_fwd_impl(&s, nullptr, nullptr, 0, 0, dy, nullptr, wt_all, nullptr, d0, d1, nullptr, 0, stream, D);
 }
 
 // dgrad: d->c0 = channels of dy, d->co0 / co1 = channels of the (possibly concatenated) input; d0 / d1 accumulate

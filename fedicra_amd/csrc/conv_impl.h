@@ -52,6 +52,10 @@ struct ConvArgs {
   int c0, c1, co0, co1;
   int acc0, acc1, y_f32;
   int tilesX, tilesY, nct;
+  int depth;                 // > 0 (wave-specialised form only): 3x3x3 convolution over volumes of `depth` consecutive slices --
+                             // an "image" is a slice, the depth taps are three channel groups of the contraction (K =
+                             // 9 taps x 3 depth taps x (c0 + c1) channels, filter [Cout][9][3][c0 + c1]); slices outside the
+                             // volume read as zero
 #ifdef FI_TRACE
   long long* trace;   // [workgroups][8] timestamps (tools/ktrace.py); debug builds only
 #endif
@@ -1188,7 +1192,8 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= CW;
-  const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
+  const int cr = a.c0 + a.c1;                                   // channels of one slice of the (concatenated) input
+  const int cin = (a.depth > 0 ? 3 : 1) * cr, cout = a.co0 + a.co1;      // contraction channels per tap: depth taps x channels
   const int H = a.H, W = a.W;
 
   // ---- this workgroup's run of items; item = slab * ntile + tile (slab-major: a run keeps its slab and statistics group)
@@ -1292,16 +1297,27 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
 #endif
       const int ci = cb + xv * VG;
       const bool chok = live && ci < cin && xrow0 < XRPP;
-      const int cc = ci < cin ? ci : 0;
+      int cc = ci < cin ? ci : 0;
+      int kdi = 1;                                               // depth tap of this thread's channel vector (2D: the centre)
+      if (a.depth > 0) {
+        kdi = cc >= 2 * cr ? 2 : (cc >= cr ? 1 : 0);
+        cc -= kdi * cr;
+      }
       const bool first = cc < a.c0;
       const unsigned cs = (unsigned)(first ? a.c0 : a.c1), co = (unsigned)(first ? cc : cc - a.c0);
       const T* const xb = first ? x0p : x1p;
       const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
       const int nl = it.n - grp * a.gimages;
-      const int ns = (XF != 0 && first && a.bcast0) ? nl : it.n;
+      int ns = (XF != 0 && first && a.bcast0) ? nl : it.n;
+      bool sliceok = true;
+      if (a.depth > 0) {                                         // slice it.n of its volume + (kdi - 1): zero outside the volume
+        const int d = it.n % a.depth + kdi - 1;
+        sliceok = d >= 0 && d < a.depth;
+        ns = it.n + kdi - 1;
+      }
       const int gx = it.tx * 16 + xpx - HALO;
       const int gy0 = it.ty * TH + xrow0 - HALO;
-      const bool colok = chok && (unsigned)gx < (unsigned)W;
+      const bool colok = chok && sliceok && (unsigned)gx < (unsigned)W;
       unsigned flags = first ? 0x10000u : 0u;
       if constexpr (XF == 2) {
         const unsigned o0 = (unsigned)((ns * 2 * H + 2 * gy0) * (2 * W) + 2 * gx) * cs + co;

@@ -61,6 +61,9 @@ class _FiModule(nn.Module):
 
 
 def set_compute_dtype(model: nn.Module, dtype):
+    own = getattr(type(model), "set_compute_dtype", None)
+    if callable(own):                                      # the 3D models (unet_3D, unet_3D_lc, VNet) carry their own
+        return model.set_compute_dtype(dtype)
     dt = _DTYPES[dtype] if isinstance(dtype, str) else dtype
     for m in model.modules():
         if isinstance(m, _FiModule):

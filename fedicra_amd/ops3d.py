@@ -4,7 +4,9 @@
 Volumes are dense NDHWC tensors ``[N, D, H, W, C]`` in the compute dtype, i.e. D consecutive NHWC slices, so the 2D
 kernels of libfedicra_hip.so do the heavy lifting:
 
-* ``Conv3d(3x3x3, pad 1)`` (fi_conv3d_fwd / dgrad / wgrad) = for each depth tap kd one 3x3 implicit-GEMM launch over the slices that tap reaches,
+* ``Conv3d(3x3x3, pad 1)`` forward / dgrad (16-bit storage, 16+ channels): ONE implicit GEMM over all slices of all volumes with
+  the depth taps as channel groups of the contraction (fi_conv3d_fwd_fused / dgrad_fused); otherwise, and for wgrad
+  (fi_conv3d_fwd / dgrad / wgrad): for each depth tap kd one 3x3 implicit-GEMM launch over the slices that tap reaches,
   accumulating into the output volume (the centre tap goes last: it covers every slice, so its epilogue sees the
   finished sums and produces the per-channel statistics);
 * ``InstanceNorm3d(affine=False) + ReLU`` = the fused BN-finalize/apply kernel run per sample (batch statistics of
@@ -23,17 +25,47 @@ from . import _lib as L
 from . import ops
 
 
+_pack_cache = {}               # id(weight) -> (weakref, key, {what: operand}): the packed operands of the current weights
+
+
+def _cached(weight, dtype, what, build):
+    """Packed operands are rebuilt when the weights change -- in place (``_version``) or through raw pointers (fused AdamW / ALA
+    kernels / graph replay: ops.weights_epoch) -- not at every forward and backward call."""
+    import weakref
+    key = (weight._version, ops.weights_epoch(), dtype, weight.data_ptr(), torch.cuda.is_current_stream_capturing())
+    ent = _pack_cache.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != key:
+        if len(_pack_cache) > 4096:
+            _pack_cache.clear()
+        ent = (weakref.ref(weight), key, {})
+        _pack_cache[id(weight)] = ent
+    if what not in ent[2]:
+        ent[2][what] = build()
+    return ent[2][what]
+
+
 def _w_taps(weight, dtype, mode):
     """Conv3d weight [Cout,Cin,kD,kH,kW] -> per depth tap the packed 2D operand ([Cout][kH*kW][Cin] forward,
     flipped/transposed for dgrad)."""
-    cout, cin, kd, kh, kw = weight.shape
-    out = []
-    for t in range(kd):
-        wk = weight[:, :, t].permute(0, 2, 3, 1).contiguous().float()          # [Cout,kH,kW,Cin] fp32
-        dst = torch.empty(cout * kh * kw * cin, dtype=dtype, device=weight.device)
-        L.pack_weights(wk, dst, cout, kh * kw, cin, mode)
-        out.append(dst)
-    return out
+    def build():
+        cout, cin, kd, kh, kw = weight.shape
+        out = []
+        for t in range(kd):
+            wk = weight[:, :, t].permute(0, 2, 3, 1).contiguous().float()          # [Cout,kH,kW,Cin] fp32
+            dst = torch.empty(cout * kh * kw * cin, dtype=dtype, device=weight.device)
+            L.pack_weights(wk, dst, cout, kh * kw, cin, mode)
+            out.append(dst)
+        return out
+    return _cached(weight, dtype, ("taps", mode), build)
+
+
+def _fused_ok(dt, ydt, kd, ksize, x0, x1, cout):
+    """Shapes fi_conv3d_*_fused covers (the library re-checks and answers FI_ERR_UNSUPPORTED otherwise)."""
+    if dt == torch.float32 or ydt != dt or kd != 3 or ksize != 3:
+        return False
+    c0 = x0.shape[4]
+    c1 = 0 if x1 is None else x1.shape[4]
+    return c0 % 8 == 0 and c1 % 8 == 0 and c0 + c1 >= 16 and cout >= 16 and cout % 8 == 0 and x0.shape[2] >= 8
 
 
 class _Conv3d(Function):
@@ -46,11 +78,21 @@ class _Conv3d(Function):
         dev, dt = x0.device, x0.dtype
         wp = _w_taps(weight, dt, 0)
         ydt = torch.float32 if (y_f32 and not norm) else dt
-        y = torch.zeros((N, D, H, W, cout), dtype=ydt, device=dev)
         stats = torch.zeros((N, L.STATS_SLOTS * cout * 2), dtype=torch.float64, device=dev) if norm else None
-        # every (sample, depth tap) 2D launch is issued by ONE C-ABI call (fi_conv3d_fwd)
-        L.conv3d_fwd(x0.contiguous(), None if x1 is None else x1.contiguous(), wp, bias, y, stats, ksize=ksize,
-                     y_f32=ydt == torch.float32 and dt != torch.float32)
+        x0c, x1c = x0.contiguous(), None if x1 is None else x1.contiguous()
+        y = None
+        if _fused_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
+            # ONE implicit GEMM over all slices of all volumes, the depth taps as channel groups of its contraction: y is
+            # written once (the per-tap form below reads and rewrites it twice more)
+            y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
+            w_all = _cached(weight, dt, "all0", lambda: torch.stack([t.view(cout, ksize * ksize, cin) for t in wp],
+                                                                     dim=2).contiguous())               # [Cout][9][3][Cin]
+            if not L.conv3d_fwd_fused(x0c, x1c, w_all, bias, y, stats, ksize=ksize):
+                y = None
+        if y is None:
+            y = torch.zeros((N, D, H, W, cout), dtype=ydt, device=dev)
+            # every (sample, depth tap) 2D launch is issued by ONE C-ABI call (fi_conv3d_fwd)
+            L.conv3d_fwd(x0c, x1c, wp, bias, y, stats, ksize=ksize, y_f32=ydt == torch.float32 and dt != torch.float32)
         if not norm:
             ctx.save_for_backward(x0, x1, weight)
             ctx.norm, ctx.has_bias = False, bias is not None
@@ -88,9 +130,19 @@ class _Conv3d(Function):
         dx0 = dx1 = gw = gb = None
         if need_x0 or need_x1:
             wt = _w_taps(weight, dt, 1)
-            d0 = torch.zeros_like(x0)
-            d1 = None if x1 is None else torch.zeros_like(x1)
-            L.conv3d_dgrad(dy.contiguous(), wt, d0, d1, ksize=ksize)
+            dyc = dy.contiguous()
+            done = False
+            if _fused_ok(dt, dt, kd, ksize, dyc, None, c0) and (x1 is None or x1.shape[4] % 8 == 0):
+                d0 = torch.empty_like(x0)
+                d1 = None if x1 is None else torch.empty_like(x1)
+                # the depth taps reversed: input slice d + j - 1 of dy meets the filter's depth tap 2 - j
+                wt_all = _cached(weight, dt, "all1", lambda: torch.stack([t.view(cin, ksize * ksize, cout) for t in wt[::-1]],
+                                                                          dim=2).contiguous())
+                done = L.conv3d_dgrad_fused(dyc, wt_all, d0, d1, ksize=ksize)
+            if not done:
+                d0 = torch.zeros_like(x0)
+                d1 = None if x1 is None else torch.zeros_like(x1)
+                L.conv3d_dgrad(dyc, wt, d0, d1, ksize=ksize)
             dx0 = d0 if need_x0 else None
             dx1 = d1 if need_x1 else None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):

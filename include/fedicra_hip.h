@@ -138,6 +138,15 @@ int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void*
 int fi_conv3d_fwd(const FiConv* d, int D, const void* x0, const void* x1, const void* const* w_taps, const float* bias,
                   void* y, double* stats, long stats_stride, void* stream);
 int fi_conv3d_dgrad(const FiConv* d, int D, const void* dy, const void* const* wt_taps, void* d0, void* d1, void* stream);
+/* One-launch forms (16-bit storage, 3x3x3, channel counts multiples of 8 and >= 16): the slices of all volumes are the images of
+ * ONE implicit GEMM, the depth taps three channel groups of its contraction.  w_all = [Cout][k*k][3][c0 + c1] (the per-tap
+ * operands of fi_conv3d_fwd interleaved); wt_all = [c_in][k*k][3][Cout] with the depth taps reversed.  Outputs are WRITTEN (no
+ * zeroing by the caller), statistics per volume as above.  d->accumulate* must be 0.  FI_ERR_UNSUPPORTED: shape not covered --
+ * fall back to the per-tap forms.  Replaces the same reference calls as fi_conv3d_fwd / fi_conv3d_dgrad
+ * (networks/utils.py:224-245 UnetConv3: nn.Conv3d(3,3,3) + InstanceNorm3d + ReLU). */
+int fi_conv3d_fwd_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* w_all, const float* bias, void* y,
+                        double* stats, long stats_stride, void* stream);
+int fi_conv3d_dgrad_fused(const FiConv* d, int D, const void* dy, const void* wt_all, void* d0, void* d1, void* stream);
 long fi_conv3d_wgrad_workspace(const FiConv* d, int D);
 int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_taps, float* dbias,
                     void* workspace, long workspace_bytes, void* stream);
