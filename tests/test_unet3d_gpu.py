@@ -158,3 +158,52 @@ def test_unet3d_bf16_and_train_mode_dropout(golden):
     assert not torch.equal(a, b)
     a.square().mean().backward()
     assert all(torch.isfinite(p.grad).all().item() for p in m32.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 16, 0, 16, 5, 21, 19), (1, 24, 8, 40, 3, 16, 33), (3, 64, 32, 64, 2, 9, 16)])
+def test_one_launch_conv3d_equals_the_per_tap_form(dtype, case):
+    """fi_conv3d_fwd_fused / dgrad_fused (one implicit GEMM over all slices, depth taps as channel groups, output written once)
+    against fi_conv3d_fwd / dgrad (one launch per depth tap accumulating into the volume) on ragged volumes, two sources and
+    two gradient destinations: the same products, fp32-accumulated in a different grouping and rounded to 16 bits once
+    instead of three times -- they agree to the storage type's resolution, and the per-volume statistics to the accumulated rounding of their terms."""
+    from fedicra_amd import _lib as L
+    from fedicra_amd import ops3d
+    N, c0, c1, cout, D, H, W = case
+    cin = c0 + c1
+    w = (rnd(cout, cin, 3, 3, 3, seed=31) * (1.7 / (27 * cin) ** 0.5)).to(DEV)
+    bias = (rnd(cout, seed=32) * 0.1).to(DEV)
+    x0 = rnd(N, D, H, W, c0, seed=33).to(dtype).to(DEV)
+    x1 = rnd(N, D, H, W, c1, seed=34).to(dtype).to(DEV) if c1 else None
+    wp = ops3d._w_taps(w, dtype, 0)
+    w_all = torch.stack([t.view(cout, 9, cin) for t in wp], dim=2).contiguous()
+    y0 = torch.zeros(N, D, H, W, cout, dtype=dtype, device=DEV)
+    s0 = torch.zeros(N, L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=DEV)
+    L.conv3d_fwd(x0, x1, wp, bias, y0, s0, ksize=3)
+    y1 = torch.full((N, D, H, W, cout), float("nan"), dtype=dtype, device=DEV)          # written, not accumulated
+    s1 = torch.zeros_like(s0)
+    assert L.conv3d_fwd_fused(x0, x1, w_all, bias, y1, s1, ksize=3)
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    d = (y1.float() - y0.float()).abs()
+    # (the per-tap form rounds its running sum after every tap: up to an ulp of the LARGEST partial sum, which may exceed |y|)
+    assert bool((d <= 4 * ulp * (y0.float().abs() + 1.0)).all()), float(d.max())
+    t0 = s0.view(N, L.STATS_SLOTS, cout, 2).sum(1)
+    t1 = s1.view(N, L.STATS_SLOTS, cout, 2).sum(1)
+    # sums of D*H*W outputs that differ by up to an ulp each, with random signs
+    assert torch.allclose(t1, t0, rtol=5e-3, atol=8 * ulp * (D * H * W) ** 0.5), float((t1 - t0).abs().max())
+    # dgrad into the two sources
+    dy = rnd(N, D, H, W, cout, seed=35).to(dtype).to(DEV)
+    wt = ops3d._w_taps(w, dtype, 1)
+    wt_all = torch.stack([t.view(cin, 9, cout) for t in wt[::-1]], dim=2).contiguous()
+    a0 = torch.zeros_like(x0)
+    a1 = None if x1 is None else torch.zeros_like(x1)
+    L.conv3d_dgrad(dy, wt, a0, a1, ksize=3)
+    b0 = torch.full_like(x0, float("nan"))
+    b1 = None if x1 is None else torch.full_like(x1, float("nan"))
+    assert L.conv3d_dgrad_fused(dy, wt_all, b0, b1, ksize=3)
+    torch.cuda.synchronize()
+    for a, b in ((a0, b0), (a1, b1)):
+        if a is not None:
+            d = (b.float() - a.float()).abs()
+            assert bool((d <= 4 * ulp * (a.float().abs() + 1.0)).all()), float(d.max())
