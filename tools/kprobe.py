@@ -15,7 +15,14 @@ from fedicra_amd import _lib as L  # noqa: E402
 def parse_cfg(s):
     if s == "v1":
         return (0, 0, 0, 0)
+    if s == "auto":                                     # the library's own per-layer choice
+        return (-1, 0, 0, 0)
+    if s == "thin":
+        return (3, 0, 0, 0)
     import re
+    m = re.fullmatch(r"ws(\d+)nf(\d)", s)               # wave-specialised: ws8nf4 / ws44nf4 ...
+    if m:
+        return ({4: 4, 8: 5, 44: 6}[int(m.group(1))], int(m.group(2)), 0, 0)
     m = re.fullmatch(r"nf(\d)ck(\d+)w(\d)", s)
     return (1, int(m.group(1)), int(m.group(2)), int(m.group(3)))
 
