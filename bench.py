@@ -98,6 +98,11 @@ class Federation:
             n_abs = sum(all_n[world:])
             absent = (DeviceWeights(net.flat_state.clone(), net.flat_counters.clone()), n_abs)
         self.agg = WeightedAllReduce(all_n[cid], device=dev, constant_term=absent)
+        if world > 1:
+            # communicator creation (seconds, once) must not land inside a timed region, whatever --warmup is
+            import torch.distributed as dist
+            dist.all_reduce(torch.zeros(1, device=dev if dist.get_backend() == "nccl" else "cpu"))
+            torch.cuda.synchronize()
         self.iter_global = 60                            # > 50: the ALA branch runs (flower_common.py:524-526)
         self.agg_events = []
 
