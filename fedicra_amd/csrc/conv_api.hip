@@ -249,14 +249,18 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // ... and for the plain launches of the gradient path (forward, dgrad, ALA: 12 images) with 64+ channels in and out:
       // 4 + 8 waves, 32-channel slabs below 256 outputs -- 1.05x (128^2) to 1.2-1.56x (64^2, 32^2) the one-tile kernel, ahead
       // of the persistent form on the layers that one had (profiles/r02_o_kbench2_ws_plain.txt)
-      const long items2 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout >= 256 ? 64 : 32);
-      const bool ws_plain = v2 == 2 && a.xf == 0 && cin >= 64 && cout >= 64 && items2 >= 192;
+      // (128+ input channels: from 48 items on -- the 16^2 / 32^2 maps of a 256^2 input, 1.1-1.66x; 64..127: from 768 items on,
+      //  at fewer the one-tile kernel is level or ahead)
+      const long tiles2 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
+      const long items_nf2 = tiles2 * fi_cdiv(cout, 32), items_nf4 = tiles2 * fi_cdiv(cout, 64);
+      const bool ws_plain = v2 == 2 && a.xf == 0 && cout >= 64 &&
+                            ((cin >= 128 && items_nf2 >= 48) || (cin >= 64 && items_nf2 >= 768));
       if (fits && (v2 == 4 || v2 == 5 || v2 == 6 || ws_auto || ws_plain)) {
         // 8 consumer + 2 x 4 producer waves where the tile is wide enough to feed them (64+ outputs, measured 3-10 % ahead
         // of 4 + 8); 32-output slabs and the statistics-only head measured ahead with 4 + 8
         const int pw = v2 == 4 ? 4 : (v2 == 6 ? 44 : (v2 == 5 ? 8 : ((cout >= 64 && y0 && !ws_plain) ? 44 : 8)));
         int n4 = cout > 32 ? 4 : 2;
-        if (ws_plain && v2 == 2) n4 = cout >= 256 ? 4 : 2;
+        if (ws_plain && v2 == 2) n4 = (cout >= 256 && items_nf4 >= 192) ? 4 : 2;
         if (v2_nf == 2 || v2_nf == 4) n4 = (int)v2_nf;
         int c4 = (a.xf != 2 && d->c0 % 16 == 0 && d->c1 % 16 == 0) ? 32 : 16;
         if (v2_ck && a.xf != 2) c4 = (int)v2_ck;
