@@ -59,12 +59,22 @@ class FiError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 2             # include/fedicra_hip.h FI_ABI_VERSION
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C fedicra_amd/csrc).  fedicra_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.fi_abi_version.restype = C.c_int
+        got = _lib.fi_abi_version()
+        if got != ABI_VERSION:
+            _lib = None
+            raise FiError(f"{LIB_PATH} reports C-ABI version {got}, this host mirror was written against {ABI_VERSION} "
+                          "(include/fedicra_hip.h FI_ABI_VERSION): rebuild with `make -C fedicra_amd/csrc`")
         _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int

@@ -56,6 +56,7 @@ class WeightedAllReduce:
         self._send = None
         self._cnt = None
         self._done = None
+        self.counter_mean = None
 
     # ---------------------------------------------------------------------------------------------
     def start(self, weights):
@@ -103,7 +104,8 @@ class WeightedAllReduce:
         """Fence the training stream behind the collective and return the global weights."""
         if self.on_gpu:
             torch.cuda.current_stream().wait_event(self._done)
-        counters = (self._cnt.double() / self.total).to(torch.int64)     # true divide, then truncate
+        self.counter_mean = self._cnt.double() / self.total              # float64, as flwr's aggregate hands it back
+        counters = self.counter_mean.to(torch.int64)                      # the clients' load truncates
         return DeviceWeights(self._send, counters)
 
     def aggregate(self, weights: DeviceWeights) -> DeviceWeights:

@@ -827,7 +827,7 @@ extern "C" int fi_probe_tr16(const short* in, const int* offs, short* out, void*
   return 0;
 }
 
-extern "C" int fi_abi_version(void) { return 1; }
+extern "C" int fi_abi_version(void) { return FI_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
 // (partial) Dice loss: pDLoss / DiceLoss of /root/reference/code/utils/losses.py:156-232.

@@ -541,22 +541,11 @@ class FedOpt(FedAvg):
         if agg is None:
             return None, {}
         if self.on_device:
-            cur = self.current.state
-            if self.m_t is None:
-                self.m_t, self.v_t = torch.zeros_like(cur), torch.zeros_like(cur)
-                self.m_c = torch.zeros(self.cnt.shape, dtype=torch.float64, device=cur.device)
-                self.v_c = torch.zeros_like(self.m_c)
-            L.fedopt_step(self.MODE, cur, agg.state, self.m_t, self.v_t, self.eta, self.beta_1, self.beta_2, self.tau)
             # the int64 counters: FedAvg hands back their float64 true-divide; the step runs in float64 (numpy's promotion)
             # and the clients truncate on load (quirk 6).  18 scalars: plain tensor arithmetic.
             total = sum(r.num_examples for _, r in results)
             avg = sum(r.parameters.counters.double() * int(r.num_examples) for _, r in results) / total
-            d = avg - self.cnt.double()
-            self.m_c = self.beta_1 * self.m_c + (1 - self.beta_1) * d
-            self.v_c = self._second_moment(self.v_c, d)
-            self.cnt = self.cnt.double() + self.eta * self.m_c / (torch.sqrt(self.v_c) + self.tau)
-            self.current = DeviceWeights(cur, self.cnt.to(torch.int64))
-            return DeviceWeights(cur.clone(), self.cnt.to(torch.int64)), metrics
+            return self.server_step(agg, avg), metrics
         fedavg_weights = fl.parameters_to_ndarrays(agg)
         delta_t = [x - y for x, y in zip(fedavg_weights, self.current_weights)]
         if not self.m_t:
@@ -568,6 +557,23 @@ class FedOpt(FedAvg):
         new_weights = [x + self.eta * y / (np.sqrt(z) + self.tau) for x, y, z in zip(self.current_weights, self.m_t, self.v_t)]
         self.current_weights = new_weights
         return fl.ndarrays_to_parameters(self.current_weights), metrics
+
+    def server_step(self, agg: "DeviceWeights", counters_mean) -> "DeviceWeights":
+        """The server optimizer on a FedAvg mean that already sits on the device -- ``aggregate_fit`` above, and the
+        rank-per-GPU round driver, where the mean comes out of the weighted all-reduce and every rank takes the same step.
+        `counters_mean`: the float64 weighted mean of the int64 counters (before truncation)."""
+        cur = self.current.state
+        if self.m_t is None:
+            self.m_t, self.v_t = torch.zeros_like(cur), torch.zeros_like(cur)
+            self.m_c = torch.zeros(self.cnt.shape, dtype=torch.float64, device=cur.device)
+            self.v_c = torch.zeros_like(self.m_c)
+        L.fedopt_step(self.MODE, cur, agg.state, self.m_t, self.v_t, self.eta, self.beta_1, self.beta_2, self.tau)
+        d = counters_mean.double() - self.cnt.double()
+        self.m_c = self.beta_1 * self.m_c + (1 - self.beta_1) * d
+        self.v_c = self._second_moment(self.v_c, d)
+        self.cnt = self.cnt.double() + self.eta * self.m_c / (torch.sqrt(self.v_c) + self.tau)
+        self.current = DeviceWeights(cur, self.cnt.to(torch.int64))
+        return DeviceWeights(cur.clone(), self.cnt.to(torch.int64))
 
     def __repr__(self):
         return f"{type(self).__name__}(accept_failures={self.accept_failures})"

@@ -67,7 +67,8 @@ class MyClient(BaseClient):
     def _ensure_optimizer(self):
         if self.optimizer is None:
             self.optimizer = FusedAdamW(self._net(), lr=self.current_lr, base_lr=self.args.base_lr,
-                                        max_iterations=self.args.max_iterations)
+                                        max_iterations=self.args.max_iterations,
+                                        frozen=getattr(self.args, "adamw_frozen", "torch2"))
             self.ctx.seed_offset = self.optimizer.iter       # ops.set_dropout_seed_offset, for this client's context
         return self.optimizer
 
@@ -178,6 +179,10 @@ class MyClient(BaseClient):
                 sampled_batch = self.sampled_batches[self.current_iter % n_b]
                 x, y = self._stage(sampled_batch)
                 pattern = self._set_freeze(i_iter)
+                if opt.frozen == "torch1":
+                    # which parameters step (and under which counters) also depends on which ones have ever held a
+                    # gradient: a step captured before that set is complete must not be replayed after it grew
+                    pattern = "{}/{}".format(pattern, len(opt._ever))
                 if self.use_graph:
                     rec = self._steps.get(pattern)
                     if rec is None:

@@ -8,6 +8,13 @@ each iteration (:154-157).  Parameters whose ``.grad`` is None are skipped entir
 FedICRA's freeze schedule (:84-101) work: the first ``iters - rep_iters`` iterations only touch
 ``decoder.out_conv``.
 
+``frozen="torch1"`` (``args.adamw_frozen``) selects the semantics of the reference's PINNED environment instead
+(fed39v2.yaml: PyTorch 1.10.2, where ``optimizer.zero_grad()`` zeroes gradients in place): once a parameter has held a
+gradient it keeps a (zero) gradient tensor for the rest of the process, and AdamW keeps stepping it while the freeze
+schedule has it switched off -- decoupled weight decay, and the decay of whatever momentum the round's fresh optimizer
+has already collected for it.  Every parameter that has ever received a gradient therefore steps at every iteration; a
+parameter's step count starts at its first step of the round.
+
 torch keeps one step counter per parameter; here parameters are grouped by *freeze pattern*
 (the set of parameters that received a gradient), each pattern owning one device-side step
 counter.  That is exact as long as the patterns seen within one round are disjoint, which holds
@@ -39,7 +46,11 @@ class FusedAdamW:
     MAX_GROUPS = 8
 
     def __init__(self, model, lr, base_lr=None, max_iterations=None, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2, bf16_shadow=False):
+                 weight_decay=1e-2, bf16_shadow=False, frozen="torch2"):
+        if frozen not in ("torch2", "torch1"):
+            raise ValueError("FusedAdamW: frozen must be 'torch2' (grad None -> skipped) or 'torch1' (zero-grad steps)")
+        self.frozen = frozen
+        self._ever = set()              # torch1: parameters that hold a gradient tensor (it outlives the per-round optimizer)
         self.model = model
         self.betas, self.eps, self.wd = betas, eps, weight_decay
         self.base_lr = lr if base_lr is None else base_lr
@@ -96,20 +107,34 @@ class FusedAdamW:
         ops.flush_wgrad()                    # no-op unless a backward's deferred wgrad reduction is still pending
         params = dict(self.model.named_parameters())
         active = [n for n in self._names if params[n].grad is not None]
-        if not active:
+        if not active and not (self.frozen == "torch1" and self._ever):
             return
         _adopt_foreign_grads(params, active)
-        gi, ranges = self._group_for(active)
+        if self.frozen == "torch1":
+            # every parameter that has ever held a gradient steps (the frozen ones on the zeros zero_grad() left in the
+            # flat gradient buffer); those stepping for the first time this round open a new step counter
+            self._ever.update(active)
+            grouped = set().union(*[set(k) for k in self._groups]) if self._groups else set()
+            fresh = tuple(n for n in self._names if n in self._ever and n not in grouped)
+            if fresh:
+                if len(self._groups) >= self.MAX_GROUPS:
+                    raise RuntimeError("FusedAdamW: too many distinct freeze patterns in one round")
+                self._groups[fresh] = (len(self._groups), self.model.param_ranges(fresh))
+            todo = list(self._groups.values())
+        else:
+            todo = [self._group_for(active)]
         P, G = self.model.flat_params, self.model.flat_grads
-        if scale is not None:
+        if scale is not None:                 # all ranges first: an overflow anywhere skips every group's step
+            for gi, ranges in todo:
+                for s, e in ranges:
+                    L.amp_unscale(G[s:e], scale, found_inf)
+        for gi, ranges in todo:
+            L.adamw_hyper(self.steps[gi:gi + 1], self.hyper[gi], self.lr_state, self.betas[0], self.betas[1], self.wd)
+            if scale is not None:
+                L.amp_guard(self.steps[gi:gi + 1], self.hyper[gi], found_inf)
             for s, e in ranges:
-                L.amp_unscale(G[s:e], scale, found_inf)
-        L.adamw_hyper(self.steps[gi:gi + 1], self.hyper[gi], self.lr_state, self.betas[0], self.betas[1], self.wd)
-        if scale is not None:
-            L.amp_guard(self.steps[gi:gi + 1], self.hyper[gi], found_inf)
-        for s, e in ranges:
-            L.adamw_step(P[s:e], G[s:e], self.m[s:e], self.v[s:e], self.hyper[gi], self.betas[0], self.betas[1],
-                         self.eps, None if self.shadow is None else self.shadow[s:e])
+                L.adamw_step(P[s:e], G[s:e], self.m[s:e], self.v[s:e], self.hyper[gi], self.betas[0], self.betas[1],
+                             self.eps, None if self.shadow is None else self.shadow[s:e])
         ops.bump_weights_epoch()            # raw-pointer write: invalidate the conv operand packs
 
     def advance_lr(self):
@@ -151,6 +176,7 @@ class FusedSGD:
         active = [n for n in self._names if params[n].grad is not None]
         if not active:
             return
+        _adopt_foreign_grads(params, active)     # the 3D ops hand autograd ordinary gradient tensors, not the flat sink
         ranges = self.model.param_ranges(tuple(active))
         P, G = self.model.flat_params, self.model.flat_grads
         skip = None

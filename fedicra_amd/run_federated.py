@@ -73,11 +73,18 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="N > 0: N synthetic training slices per client instead of HDF5")
     p.add_argument("--dtype", type=str, default=None, help="compute dtype of the HIP kernels (fp32 | bf16 | fp16)")
     p.add_argument("--graph", type=int, default=1, help="capture the training / ALA iteration into a hipGraph")
+    p.add_argument("--adamw_frozen", type=str, default="torch2", choices=["torch2", "torch1"],
+                   help="AdamW on parameters the FedICRA freeze schedule has switched off: torch2 = skipped (grad None), "
+                        "torch1 = the reference's pinned PyTorch 1.10.2 (zeroed gradients: weight decay keeps acting)")
     return p
 
 
 def check_args(args, world):
     """flower_pCE_2D.py:262-276."""
+    from .flower_common import CENTRALIZED_FL, PERSONALIZED_FL
+    # flower_common.get_strategy asserts the name (flower_common.py:431-433); a typo must not silently train FedAvg
+    assert args.strategy in CENTRALIZED_FL + PERSONALIZED_FL, \
+        "unknown --strategy {!r}: one of {}".format(args.strategy, CENTRALIZED_FL + PERSONALIZED_FL)
     assert args.iters > 0
     assert args.eval_iters > 0 and args.eval_iters % args.iters == 0
     assert args.max_iterations > 0 and args.max_iterations % args.eval_iters == 0
@@ -187,7 +194,7 @@ def run(args, log=print):
     from . import fl
     from .comm import WeightedAllReduce, init_process_group_from_env
     from .flower_common import (PERSONALIZED_FL, VAL_METRICS, DeviceWeights, fit_metrics_aggregation_fn,
-                                get_evaluate_metrics_aggregation_fn)
+                                get_evaluate_metrics_aggregation_fn, get_strategy)
     rank, local, world = init_process_group_from_env()
     sup_types = check_args(args, world)
     device = torch.device("cuda", local)
@@ -213,13 +220,23 @@ def run(args, log=print):
         dist.broadcast(glob.state, src=0)
         dist.broadcast(glob.counters, src=0)
     personalized = args.strategy in PERSONALIZED_FL
+    # FedAdagrad / FedAdam / FedYogi: the server optimizer of flwr's FedOpt family runs on the all-reduced mean -- every rank
+    # holds the same mean and the same optimizer state, so every rank takes the same step (no server process).  The
+    # reference builds these strategies without flwr's mandatory initial_parameters (flower_pCE_2D.py:353-363) and cannot
+    # run them as shipped; here they start from the broadcast initial state.
+    server_opt = None
+    if args.strategy in ("FedAdagrad", "FedAdam", "FedYogi"):
+        server_opt = get_strategy(args.strategy, initial_parameters=glob)
     best_performance, history = 0.0, []
     start = timeit.default_timer()
     for current_round in round_schedule(args):
         iter_num = current_round
         res = client.fit(fl.FitIns(parameters=glob, config=make_config(args, current_round, "fit")))
         glob = agg.aggregate(res.parameters)                     # FedAvg.aggregate_fit as one weighted all-reduce
-        glob = DeviceWeights(glob.state.clone(), glob.counters.clone())   # the reducer reuses its buffers next round
+        if server_opt is not None:
+            glob = server_opt.server_step(glob, agg.counter_mean)
+        else:
+            glob = DeviceWeights(glob.state.clone(), glob.counters.clone())   # the reducer reuses its buffers next round
         scalars = {k: v for k, v in res.metrics.items() if not isinstance(v, (bytes, bytearray))}
         fit_metrics = fit_metrics_aggregation_fn(_gather((res.num_examples, scalars), world))
         if writer is not None:

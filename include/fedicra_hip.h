@@ -43,6 +43,12 @@ extern "C" {
 #define FI_DROP_MASK_CHAN 3 /* explicit uint8 keep-mask per (n,c) [N,C] -- nn.Dropout2d (parity mode) */
 #define FI_DROP_RNG_CHAN 4  /* counter RNG keyed (seed, n*C+c) -- nn.Dropout2d                        */
 
+/* Bumped whenever the signature of an exported function or the layout of a struct below changes (additions of new entry
+ * points included): the host mirror (fedicra_amd/_lib.py) refuses a library whose version differs from the header it was
+ * written against, so a stale or foreign libfedicra_hip.so fails at load, not by passing a pointer in the wrong slot.
+ *   1: rounds 1-2 (fi_ala_update gained `skip` without a bump -- the reason for this note)
+ *   2: round 3 (fi_lc_loss_*, fi_pcs_*, consumer-side up-sampling in FiInXform, this check) */
+#define FI_ABI_VERSION 2
 int fi_abi_version(void);
 
 /* ---------------------------------------------------------------- convolution ------------

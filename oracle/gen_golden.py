@@ -641,12 +641,149 @@ def g18_ours_train():
     save("g18_ours_train.npz", **d)
 
 
+def g6_fedavg_counters():
+    """The int64 -> float64 -> truncate path of a FedAvg round, through the reference's OWN wire functions
+    (flower_common.py:488-489 ``MyModel.get_weights``, :627-633 ``set_weights`` of the non-personalised strategies) around
+    the restated flwr ``aggregate`` (third-party, absent: oracle.fed_ref.fedavg_aggregate): K in {2, 5, 8} clients with the
+    FAZ site sizes as n_k, every client a seeded UNet(1,2) whose BatchNorm counters were set to distinct values."""
+    import flower_common as fc
+    from networks.net_factory import net_factory
+    from oracle import fed_ref
+    n_all = [21, 13, 17, 59, 3, 21, 13, 17]
+    d = {"n_all": np.array(n_all)}
+    for K in (2, 5, 8):
+        args = _args(strategy="FedAvg", min_num_clients=K)
+        results = []
+        for k in range(K):
+            net = net_factory(args, net_type="unet", in_chns=1, class_num=2)
+            seeded_state(net, 100 + k)
+            j = 0
+            for name, buf in net.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    buf.fill_(7 * k + 3 * j + 1)
+                    j += 1
+            w = fc.MyModel(args, net, None, None).get_weights({})
+            results.append(([np.array(a) for a in w], n_all[k]))        # np.array: .numpy() aliases the parameters on CPU
+        keys = list(net.state_dict().keys())
+        agg = fed_ref.fedavg_aggregate(results)
+        d[f"K{K}/dtypes"] = np.array([str(a.dtype) for a in agg])
+        cidx = [i for i, k_ in enumerate(keys) if k_.endswith("num_batches_tracked")]
+        d[f"K{K}/counters_f64"] = np.array([float(agg[i]) for i in cidx])
+        recv = net_factory(args, net_type="unet", in_chns=1, class_num=2)
+        seeded_state(recv, 7)
+        fc.MyModel(args, recv, None, None).set_weights(agg, {"iter_global": 60})
+        sd = recv.state_dict()
+        d[f"K{K}/counters_loaded"] = np.array([int(sd[keys[i]]) for i in cidx], dtype=np.int64)
+        for k_ in ("encoder.in_conv.conv_conv.0.weight", "encoder.down4.maxpool_conv.1.conv_conv.5.running_var",
+                   "decoder.up1.conv.conv_conv.0.weight", "decoder.out_conv.weight", "decoder.out_conv.bias"):
+            d[f"K{K}/ck/{k_}"] = checksum(sd[k_].double())
+        d[f"K{K}/out_conv_weight"] = sd["decoder.out_conv.weight"].numpy().copy()
+    d["keys"] = np.array(keys)
+    save("g6_fedavg_counters.npz", **d)
+
+
+def g8_eval_metrics():
+    """The evaluation path above medpy: the reference's own ``calculate_metric_percase`` / ``test_single_volume``
+    (val_2D.py:9-22,25-74) and ``evaluate`` (flower_common.py:122-136) with oracle.losses_ref.medpy_binary standing in for
+    the absent ``medpy.metric.binary`` -- pins the class rule (class 1: ``== 1``; every class >= 2: ``>= 1``), the
+    empty-prediction rule, the binarisation of non-binary inputs, the arg-max of the logits and the per-dataset /
+    per-class folds.  A stateless stand-in network maps an image (its index is written into pixel [0,0]) to fixed
+    logits.  Cases with an empty ground truth under a non-empty prediction are left out: medpy raises there and the
+    reference does not catch it."""
+    import types
+    import flower_common as fc
+    import val_2D
+    from oracle import losses_ref
+    binary = types.SimpleNamespace(**{k: getattr(losses_ref.medpy_binary, k)
+                                      for k in ("dc", "hd95", "recall", "precision", "jc", "specificity", "ravd")})
+    val_2D.metric = types.SimpleNamespace(binary=binary)
+    rng = np.random.default_rng(8)
+    S = 48
+    yy, xx = np.mgrid[0:S, 0:S]
+
+    def disk(cy, cx, r):
+        return (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+
+    d = {}
+    # --- direct calls, incl. non-binary integer inputs (the function binarises with > 0, in place)
+    pairs = [(disk(20, 20, 9).astype(np.int64) * 3, disk(22, 21, 8).astype(np.int64) * 2),
+             (np.zeros((S, S), np.int64), disk(22, 21, 8).astype(np.int64)),
+             (disk(10, 10, 4) | disk(35, 30, 6), disk(12, 10, 5) | disk(35, 33, 5)),
+             (disk(24, 24, 30), disk(24, 24, 12))]                        # prediction = the whole image
+    d["direct/pred"] = np.stack([np.asarray(p).astype(np.int64) for p, _ in pairs])
+    d["direct/gt"] = np.stack([np.asarray(g).astype(np.int64) for _, g in pairs])
+    d["direct/out"] = np.array([[float(v) for v in val_2D.calculate_metric_percase(np.array(p), np.array(g))] for p, g in pairs])
+
+    def make_set(ncls, specs):
+        preds, gts = [], []
+        for pred_disks, gt_disks in specs:
+            p, g = np.zeros((S, S), np.int64), np.zeros((S, S), np.int64)
+            for (cy, cx, r, c) in pred_disks:
+                p[disk(cy, cx, r)] = c
+            for (cy, cx, r, c) in gt_disks:
+                g[disk(cy, cx, r)] = c
+            preds.append(p)
+            gts.append(g)
+        logits = []
+        for p in preds:
+            l = rng.normal(0, 0.05, size=(ncls, S, S)).astype(np.float32)
+            for c in range(ncls):
+                l[c][p == c] += 4.0
+            logits.append(l)
+        return np.stack(preds), np.stack(gts), np.stack(logits)
+
+    sets = {
+        "faz": (2, 1, [([(20, 20, 9, 1)], [(22, 21, 8, 1)]),
+                        ([], [(22, 21, 8, 1)]),                                           # empty prediction -> zeros
+                        ([(10, 10, 4, 1), (35, 30, 6, 1)], [(12, 10, 5, 1), (35, 33, 5, 1)]),
+                        ([(2, 2, 6, 1)], [(3, 3, 5, 1)]),                                # touching the image border
+                        ([(24, 24, 3, 1)], [(24, 24, 14, 1)])]),
+        "odoc": (3, 3, [([(24, 24, 14, 1), (24, 24, 6, 2)], [(25, 23, 13, 1), (25, 23, 5, 2)]),   # nested cup in disc
+                         ([(24, 24, 10, 2)], [(24, 24, 12, 1), (24, 24, 5, 2)]),          # no class-1 pixel predicted
+                         ([], [(24, 24, 12, 1), (24, 24, 5, 2)]),                         # nothing predicted
+                         ([(20, 28, 9, 1)], [(22, 26, 10, 1), (22, 26, 4, 2)])]),         # class 2 never predicted
+    }
+    for name, (ncls, chns, specs) in sets.items():
+        preds, gts, logits = make_set(ncls, specs)
+        table = torch.from_numpy(logits)
+
+        class Net:
+            def eval(self):
+                return self
+
+            def __call__(self, x):
+                idx = x.reshape(x.shape[0], -1)[:, 0].round().long()
+                return [table[idx]]
+
+        batches = []
+        for i in range(len(preds)):
+            img = rng.random((chns, S, S)).astype(np.float32)
+            img[:, 0, 0] = i
+            im = torch.from_numpy(img[0] if chns == 1 else img).unsqueeze(0)            # faz [1,H,W] / odoc [1,3,H,W]
+            batches.append({"image": im, "label": torch.from_numpy(gts[i]).unsqueeze(0)})
+
+        class Loader(list):
+            pass
+
+        loader = Loader(batches)
+        loader.dataset = list(range(len(batches)))
+        args = _args(num_classes=ncls, img_class=name)
+        per_image = [val_2D.test_single_volume(b["image"], b["label"], Net(), classes=ncls) for b in batches]
+        out = fc.evaluate(args, Net(), loader)
+        d[f"{name}/pred"], d[f"{name}/gt"], d[f"{name}/logits"] = preds, gts, logits
+        d[f"{name}/images"] = np.stack([b["image"].numpy()[0] for b in batches])
+        d[f"{name}/per_image"] = np.array(per_image, dtype=np.float64)                  # [n, classes-1, 7]
+        d[f"{name}/keys"] = np.array(list(out.keys()))
+        d[f"{name}/vals"] = np.array([float(v) for v in out.values()])
+    save("g8_eval_metrics.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g7_ala", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue", "g18_ours_train"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g6_fedavg_counters", "g7_ala", "g8_eval_metrics", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue", "g18_ours_train"]
     for w in which:
         globals()[w]()

@@ -93,3 +93,108 @@ def hd95_percase(pred: np.ndarray, gt: np.ndarray) -> float:
     d1 = distance_transform_edt(~gb)[pb]
     d2 = distance_transform_edt(~pb)[gb]
     return float(np.percentile(np.hstack((d1, d2)), 95))
+
+
+class medpy_binary:
+    """``medpy.metric.binary`` (medpy==0.4.0, fed39v2.yaml:88; call sites /root/reference/code/val_2D.py:13-19) restated
+    from the published 0.4.0 definitions -- third-party, absent from /root/reference and from this image: PARITY
+    UNPINNED for these seven formulas.  Everything ABOVE them (the class rule ``== 1`` / ``>= 1``, the empty-prediction
+    rule, the per-dataset and per-class folds of val_2D.py:9-22,66-74 and flower_common.py:122-136) is pinned by golden g8:
+    the reference's own functions run with this namespace standing in for the missing module."""
+
+    @staticmethod
+    def _b(result, reference):
+        return np.atleast_1d(np.asarray(result).astype(bool)), np.atleast_1d(np.asarray(reference).astype(bool))
+
+    @staticmethod
+    def dc(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        inter = np.count_nonzero(r & g)
+        try:
+            return 2.0 * inter / float(np.count_nonzero(r) + np.count_nonzero(g))
+        except ZeroDivisionError:
+            return 0.0
+
+    @staticmethod
+    def jc(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        return float(np.count_nonzero(r & g)) / float(np.count_nonzero(r | g))
+
+    @staticmethod
+    def precision(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        tp, fp = np.count_nonzero(r & g), np.count_nonzero(r & ~g)
+        try:
+            return tp / float(tp + fp)
+        except ZeroDivisionError:
+            return 0.0
+
+    @staticmethod
+    def recall(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        tp, fn = np.count_nonzero(r & g), np.count_nonzero(~r & g)
+        try:
+            return tp / float(tp + fn)
+        except ZeroDivisionError:
+            return 0.0
+
+    @staticmethod
+    def specificity(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        tn, fp = np.count_nonzero(~r & ~g), np.count_nonzero(r & ~g)
+        try:
+            return tn / float(tn + fp)
+        except ZeroDivisionError:
+            return 0.0
+
+    @staticmethod
+    def ravd(result, reference):
+        r, g = medpy_binary._b(result, reference)
+        v1, v2 = np.count_nonzero(r), np.count_nonzero(g)
+        if v2 == 0:
+            raise RuntimeError("The second supplied array does not contain any binary object.")
+        return (v1 - v2) / float(v2)
+
+    @staticmethod
+    def hd95(result, reference, voxelspacing=None, connectivity=1):
+        r, g = medpy_binary._b(result, reference)
+        if not r.any():
+            raise RuntimeError("The first supplied array does not contain any binary object.")
+        if not g.any():
+            raise RuntimeError("The second supplied array does not contain any binary object.")
+        return hd95_percase(r, g)
+
+
+VAL_METRICS = ["dice", "hd95", "recall", "precision", "jc", "specificity", "ravd"]     # flower_common.py:121
+
+
+def metric_percase(pred: np.ndarray, gt: np.ndarray) -> tuple:
+    """val_2D.py:9-22: all seven metrics of one binary (prediction, ground truth) pair; zeros for an empty prediction."""
+    pred, gt = np.asarray(pred) > 0, np.asarray(gt) > 0
+    if pred.sum() > 0:
+        b = medpy_binary
+        return (b.dc(pred, gt), b.hd95(pred, gt), b.recall(pred, gt), b.precision(pred, gt), b.jc(pred, gt),
+                b.specificity(pred, gt), b.ravd(pred, gt))
+    return (0, 0, 0, 0, 0, 0, 0)
+
+
+def eval_case_all(pred_lbl: np.ndarray, gt_lbl: np.ndarray, classes: int) -> list:
+    """val_2D.py:66-74 with all seven columns: class 1 is ``== 1``, every class >= 2 is ``>= 1``."""
+    return [metric_percase(pred_lbl == 1, gt_lbl == 1) if i == 1 else metric_percase(pred_lbl >= 1, gt_lbl >= 1)
+            for i in range(1, classes)]
+
+
+def evaluate_labels(preds, gts, classes: int, n_dataset: int = None) -> dict:
+    """flower_common.py:122-136 on arg-max label maps: per-image metric rows summed, divided by len(dataset); per-class
+    and class-mean entries under the reference's keys."""
+    total = 0.0
+    for p, g in zip(preds, gts):
+        total = total + np.array(eval_case_all(p, g, classes), dtype=np.float64)
+    total = total / (len(preds) if n_dataset is None else n_dataset)
+    out = {}
+    for ci in range(classes - 1):
+        for mi, name in enumerate(VAL_METRICS):
+            out["val_{}_{}".format(ci + 1, name)] = total[ci, mi]
+    for mi, name in enumerate(VAL_METRICS):
+        out["val_mean_{}".format(name)] = np.mean(total, axis=0)[mi]
+    return out

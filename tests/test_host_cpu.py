@@ -26,7 +26,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fedicra_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared
     lib.fi_abi_version.restype = ctypes.c_int
-    assert lib.fi_abi_version() == 1                  # host-only call: no GPU needed
+    from fedicra_amd import _lib as L
+    header = open(os.path.join(ROOT, "include", "fedicra_hip.h")).read()
+    assert int(re.search(r"#define FI_ABI_VERSION (\d+)", header).group(1)) == L.ABI_VERSION
+    assert lib.fi_abi_version() == L.ABI_VERSION      # host-only call: no GPU needed
 
 
 def test_product_has_no_cpu_fallback_and_no_oracle_import():
@@ -355,6 +358,12 @@ def test_run_federated_host_logic_follows_the_launcher_and_server_loop(tmp_path)
         rf.check_args(icra, 2)                                   # FedICRA needs the LC model
     odoc = p.parse_args(["--exp", "e", "--img_class", "odoc"])
     assert rf.check_args(odoc, 5)[3] == "keypoint" and (odoc.num_classes, odoc.in_chns) == (3, 3)
+    typo = p.parse_args(["--exp", "e", "--strategy", "Fedicra"])
+    with pytest.raises(AssertionError, match="unknown --strategy"):
+        rf.check_args(typo, 2)                                   # get_strategy asserts the name (flower_common.py:431-433)
+    for name in ("FedAdagrad", "FedAdam", "FedYogi"):
+        rf.check_args(p.parse_args(["--exp", "e", "--strategy", name]), 2)
+    assert p.parse_args(["--exp", "e"]).adamw_frozen == "torch2"
 
 
 def _const_term_worker(rank, world, port, q):
@@ -394,3 +403,49 @@ def test_weighted_allreduce_constant_term_counts_the_clients_no_rank_hosts():
     want_c = ((torch.tensor([1, 7]) * 3 + torch.tensor([2, 7]) * 5 + torch.tensor([4, 4]) * 2).double() / 10).to(torch.int64)
     for rank, st, cn, total in res:
         assert total == 10 and torch.allclose(st, want) and torch.equal(cn, want_c), (rank, st, cn)
+
+
+def test_g8_metrics_from_counts_reproduce_the_references_rows(golden):
+    """The product's count-based metric rows (flower_common.metrics_from_counts) against golden g8 = the reference's own
+    calculate_metric_percase / test_single_volume rows: class rule, empty-prediction rule, all seven columns."""
+    from fedicra_amd.flower_common import metrics_from_counts
+    from oracle.losses_ref import hd95_percase
+    g = golden("g8_eval_metrics.npz")
+    for name, ncls in (("faz", 2), ("odoc", 3)):
+        for p, q, want in zip(g[f"{name}/pred"], g[f"{name}/gt"], g[f"{name}/per_image"]):
+            for k in range(1, ncls):
+                P = (p == 1) if k == 1 else (p >= 1)
+                G = (q == 1) if k == 1 else (q >= 1)
+                row = metrics_from_counts(int((P & G).sum()), int(P.sum()), int(G.sum()), P.size, hd95_percase(P, G))
+                np.testing.assert_allclose(np.array(row), want[k - 1], rtol=0, atol=1e-15, err_msg=f"{name} class {k}")
+
+
+def test_g6_host_aggregate_and_set_weights_follow_the_references_round_trip(golden):
+    """The Flower-compatible host path of the product (get_weights -> aggregate -> set_weights on lists of numpy arrays)
+    against golden g6: aggregate dtypes, float64 counters, truncating load, loaded tensors."""
+    import argparse
+    from fedicra_amd.flower_common import MyModel, aggregate
+    from fedicra_amd.networks.unet import UNet
+    from oracle.unet_ref import seeded_state
+    g = golden("g6_fedavg_counters.npz")
+    n_all = [int(v) for v in g["n_all"]]
+    keys = [str(k) for k in g["keys"]]
+    args = argparse.Namespace(strategy="FedAvg", amp=0, cid=0, num_classes=2, img_class="faz")
+    for K in (2, 5):
+        results = []
+        for k in range(K):
+            net = UNet(1, 2)
+            seeded_state(net, 100 + k)
+            for j in range(net.flat_counters.numel()):
+                net.flat_counters[j] = 7 * k + 3 * j + 1
+            results.append(([a.copy() for a in MyModel(args, net, [], []).get_weights(None)], n_all[k]))
+        assert list(net.state_dict().keys()) == keys
+        agg = aggregate(results)
+        assert [str(a.dtype) for a in agg] == [str(s) for s in g[f"K{K}/dtypes"]]
+        cidx = [i for i, k_ in enumerate(keys) if k_.endswith("num_batches_tracked")]
+        np.testing.assert_array_equal(np.array([float(agg[i]) for i in cidx]), g[f"K{K}/counters_f64"])
+        recv = UNet(1, 2)
+        seeded_state(recv, 7)
+        MyModel(args, recv, [], []).set_weights(agg, {"iter_global": 60})
+        np.testing.assert_array_equal(recv.flat_counters.numpy(), g[f"K{K}/counters_loaded"])
+        np.testing.assert_array_equal(recv.state_dict()["decoder.out_conv.weight"].numpy(), g[f"K{K}/out_conv_weight"])

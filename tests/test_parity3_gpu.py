@@ -1,0 +1,186 @@
+"""Round-3 parity tests: the evaluation path and the FedAvg counter path on the device against the reference's own
+functions (golden g8 / g6), AdamW's torch-1 frozen-parameter semantics, FusedSGD on a 3D model."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_g8_device_evaluate_matches_the_references_evaluate(golden):
+    """fedicra_amd.flower_common.evaluate (device arg-max + integer counts + device hd95, chunked forward) on the logits
+    and label maps of golden g8 = the reference's own flower_common.evaluate / val_2D.test_single_volume with the restated
+    medpy formulas: every key, every value."""
+    from fedicra_amd.flower_common import evaluate
+    g = golden("g8_eval_metrics.npz")
+    for name, ncls in (("faz", 2), ("odoc", 3)):
+        table = torch.from_numpy(g[f"{name}/logits"]).to(DEV)
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.dummy = torch.nn.Parameter(torch.zeros(1, device=DEV))
+
+            def forward(self, x):
+                idx = x.reshape(x.shape[0], -1)[:, 0].round().long()
+                return [table[idx].contiguous(memory_format=torch.channels_last)]
+
+        images = g[f"{name}/images"]
+        batches = [{"image": torch.from_numpy(images[i:i + 1]), "label": torch.from_numpy(g[f"{name}/gt"][i:i + 1])}
+                   for i in range(images.shape[0])]
+
+        class Loader(list):
+            pass
+
+        loader = Loader(batches)
+        loader.dataset = list(range(len(batches)))
+        args = argparse.Namespace(num_classes=ncls, img_class=name)
+        out = evaluate(args, Net(), loader)
+        assert list(out.keys()) == [str(k) for k in g[f"{name}/keys"]]
+        np.testing.assert_allclose(np.array([float(v) for v in out.values()]), g[f"{name}/vals"], rtol=0, atol=1e-14)
+
+
+def test_g6_device_aggregate_reproduces_the_references_counter_path(golden):
+    """aggregate_device + WeightedAllReduce (one process, K co-located clients) on the K client states of golden g6: the
+    counters after the int64 sum -> float64 divide -> truncation are the ones the reference's set_weights loaded; the fp32
+    state is the numpy aggregate bit for bit."""
+    from fedicra_amd.comm import WeightedAllReduce
+    from fedicra_amd.flower_common import DeviceWeights, aggregate_device
+    from fedicra_amd.networks.unet import UNet
+    from oracle.unet_ref import seeded_state
+    g = golden("g6_fedavg_counters.npz")
+    n_all = [int(v) for v in g["n_all"]]
+    for K in (2, 5, 8):
+        nets = []
+        for k in range(K):
+            net = UNet(1, 2)
+            seeded_state(net, 100 + k)
+            net = net.to(DEV)
+            net.flat_counters.copy_(torch.tensor([7 * k + 3 * j + 1 for j in range(net.flat_counters.numel())]))
+            nets.append(net)
+        dws = [DeviceWeights(n.flat_state, n.flat_counters) for n in nets]
+        got = aggregate_device([(dw, n_all[k]) for k, dw in enumerate(dws)])
+        np.testing.assert_array_equal(got.counters.cpu().numpy(), g[f"K{K}/counters_loaded"])
+        recv = UNet(1, 2).to(DEV)
+        recv.flat_state.copy_(got.state)
+        np.testing.assert_array_equal(recv.state_dict()["decoder.out_conv.weight"].cpu().numpy(), g[f"K{K}/out_conv_weight"])
+        red = WeightedAllReduce(n_all[:K], device=torch.device(DEV))
+        got2 = red.aggregate(dws)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got2.counters.cpu().numpy(), g[f"K{K}/counters_loaded"])
+        assert torch.equal(got2.state, got.state)
+
+
+@pytest.mark.parametrize("frozen", ["torch1", "torch2"])
+def test_fused_adamw_frozen_parameter_semantics_against_torch_adamw(frozen):
+    """FedICRA's freeze schedule under the two zero_grad semantics ('a stated deviation'): FusedAdamW against
+    torch.optim.AdamW on the CPU fed the same gradients for two rounds of 3 head-phase + 2 body-phase iterations, a fresh
+    optimizer per round (flower_pCE_2D.py:55).  torch1 = PyTorch 1.10.2 of the reference's environment: a parameter that has
+    held a gradient keeps a zero gradient while frozen, so AdamW keeps decaying it; torch2 = gradients set to None: skipped."""
+    from fedicra_amd.networks.unet import UNet
+    from fedicra_amd.optim import FusedAdamW
+    from oracle.unet_ref import seeded_state
+    torch.manual_seed(5)
+    net = UNet(1, 2)
+    seeded_state(net, 11)
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    net = net.to(DEV)
+    names = [n for n, _ in net.named_parameters()]
+    head = {"decoder.out_conv.weight", "decoder.out_conv.bias"}
+    opt = FusedAdamW(net, lr=0.01, base_lr=0.01, max_iterations=1000, frozen=frozen)
+    params = dict(net.named_parameters())
+    gen = torch.Generator().manual_seed(9)
+    for rnd in range(2):
+        opt.reset_round()
+        opt.set_lr(0.01, 0)
+        topt = torch.optim.AdamW(list(ref.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        for it in range(5):
+            active = head if it < 3 else set(names) - head
+            opt.zero_grad()
+            for n in names:
+                if n in active:
+                    g = torch.randn(ref[n].shape, generator=gen) * 1e-2
+                    ref[n].grad = g.clone()
+                    params[n].grad = g.to(DEV)
+                elif frozen == "torch1" and ref[n].grad is not None:
+                    ref[n].grad = torch.zeros_like(ref[n])          # zero_grad() of torch 1.x: zeroed in place, never None
+                else:
+                    ref[n].grad = None
+            opt.step()
+            topt.step()
+            torch.cuda.synchronize()
+            worst = max(float((params[n].detach().cpu() - ref[n].detach()).abs().max()) for n in names)
+            assert worst < 2e-7, (frozen, rnd, it, worst)
+    if frozen == "torch1":
+        # the two semantics really differ on this schedule: the body decayed during the head phase of round 2
+        assert len(opt._ever) == len(names)
+
+
+def test_fused_sgd_steps_a_3d_model_whose_gradients_arrive_outside_the_flat_sink():
+    """unet_3D hands autograd ordinary gradient tensors; FusedSGD must move them into the flat gradient buffer
+    before the fused step (the reference's 3D trainers use SGD).  One step against torch.optim.SGD on the CPU."""
+    from fedicra_amd.networks.net_factory_3d import net_factory_3d
+    from fedicra_amd.optim import FusedSGD
+    torch.manual_seed(3)
+    net = net_factory_3d("unet_3D", in_chns=1, class_num=2)
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    net = net.to(DEV)
+    opt = FusedSGD(net, lr=0.01, base_lr=0.01, max_iterations=100)
+    topt = torch.optim.SGD(list(ref.values()), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(4)
+    for _ in range(2):
+        opt.zero_grad()
+        for n, p in net.named_parameters():
+            g = torch.randn(ref[n].shape, generator=gen) * 1e-2
+            ref[n].grad = g.clone()
+            p.grad = g.to(DEV)                                        # an ordinary tensor, not the parameter's sink view
+        opt.step()
+        topt.step()
+    torch.cuda.synchronize()
+    for n, p in net.named_parameters():
+        assert float((p.detach().cpu() - ref[n].detach()).abs().max()) < 1e-6, n
+
+
+@pytest.mark.parametrize("name", ["FedAdagrad", "FedAdam", "FedYogi"])
+def test_round_driver_applies_the_fedopt_server_step_to_the_all_reduced_mean(name, tmp_path):
+    """``--strategy FedAdam`` must not silently train FedAvg.  (a) ``FedOpt.server_step`` on the mean coming
+    out of the weighted all-reduce == ``aggregate_fit`` of the same strategy on the clients' results, two rounds;
+    (b) the round driver accepts the strategy and runs it; an unknown name is rejected before any work."""
+    import os
+    import subprocess
+    import sys
+    from fedicra_amd import fl
+    from fedicra_amd.comm import WeightedAllReduce
+    from fedicra_amd.flower_common import DeviceWeights, get_strategy
+    g = torch.Generator().manual_seed(21)
+    n = 50001
+    init = DeviceWeights(torch.randn(n, generator=g).to(DEV), torch.tensor([3, 9], dtype=torch.int64, device=DEV))
+    a = get_strategy(name, initial_parameters=DeviceWeights(init.state.clone(), init.counters.clone()))
+    b = get_strategy(name, initial_parameters=DeviceWeights(init.state.clone(), init.counters.clone()))
+    n_k = [21, 13, 17]
+    red = WeightedAllReduce(n_k, device=torch.device(DEV))
+    for rnd in range(2):
+        ws = [DeviceWeights((init.state + 0.1 * torch.randn(n, generator=g).to(DEV)), init.counters + 5 * (k + rnd + 1))
+              for k in range(3)]
+        results = [(None, fl.FitRes(status=fl.Status("OK", "Success"), parameters=w, num_examples=n_k[k], metrics={}))
+                   for k, w in enumerate(ws)]
+        want, _ = a.aggregate_fit(rnd + 1, results, [])
+        mean = red.aggregate(ws)
+        got = b.server_step(mean, red.counter_mean)
+        torch.cuda.synchronize()
+        assert torch.equal(got.state, want.state) and torch.equal(got.counters, want.counters), (name, rnd)
+        assert not torch.equal(got.state, mean.state)               # it is not the plain mean
+    if name != "FedAdam":
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "fedicra_amd.run_federated", "--exp", "t_opt", "--model", "unet", "--img_class", "faz",
+            "--iters", "2", "--eval_iters", "4", "--max_iterations", "4", "--batch_size", "4", "--img_size", "64",
+            "--synthetic", "8", "--snapshot_dir", str(tmp_path), "--graph", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(base + ["--strategy", "FedAdam"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FL finished" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    bad = subprocess.run(base + ["--strategy", "Fedicra"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "unknown --strategy" in bad.stderr
