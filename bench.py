@@ -23,6 +23,10 @@ global state + FedICRA's adaptive local aggregation: one ALA epoch of forward / 
 the client's ``--loader-batches`` training batches (flower_common.py:566-618).  ``config.ms_per_aggregation_round`` is
 that interval (HIP events on the training stream).
 
+Batches live in PINNED HOST memory (the reference's DataLoader, flower_pCE_2D.py:303-304) and cross PCIe inside the timed
+region: fedicra_amd.staging.BatchStager copies batch i+1 on a side stream while iteration i computes (``--data resident``
+keeps them in HBM instead; that rate is reported beside the headline as config.resident_images_per_sec).
+
 value = images/s over ALL hosted clients (= images/s/client at N = 1; per-client figure in config), timed over the K
 steps including their aggregation rounds, barrier + synchronize on both sides, max over ranks.  Rank 0 prints ONE JSON
 line.  Extra objects on it (DESIGN.md "measurement"):
@@ -59,19 +63,23 @@ def make_args(a, cid):
                               use_graph=not a.no_graph)
 
 
-def device_loader(n_batches, a, cid, device):
+def make_loader(n_batches, a, cid, device, where):
+    """The client's training batches: `host` = pinned host memory (every use crosses PCIe, staged on a side stream),
+    `resident` = already in HBM."""
     from fedicra_amd.synth import phantom_batch
     out = []
     for i in range(n_batches):
         img, weak, _ = phantom_batch(a.batch, a.size, a.in_chns, a.classes, cid=cid, index=i)
-        out.append({"image": torch.from_numpy(img).to(device), "label": torch.from_numpy(weak).to(device)})
+        x, y = torch.from_numpy(img), torch.from_numpy(weak)
+        out.append({"image": x.to(device), "label": y.to(device)} if where == "resident"
+                   else {"image": x.pin_memory(), "label": y.pin_memory()})
     return out
 
 
 class Federation:
     """The hosted client of this rank plus the round loop (fit -> aggregate -> set_weights) around it."""
 
-    def __init__(self, a, rank, world, dev, dtype):
+    def __init__(self, a, rank, world, dev, dtype, data=None):
         from fedicra_amd.comm import WeightedAllReduce
         from fedicra_amd.flower_common import DeviceWeights, MyModel
         from fedicra_amd.flower_pCE_2D import MyClient
@@ -84,7 +92,7 @@ class Federation:
         torch.manual_seed(2022)                          # the reference seeds every client process with 2022
         net = net_factory(args, net_type="unet_lc", in_chns=a.in_chns, class_num=a.classes)
         set_compute_dtype(net, dtype)
-        self.loader = device_loader(a.loader_batches, a, cid, dev)      # resident in HBM before timing starts
+        self.loader = make_loader(a.loader_batches, a, cid, dev, data or a.data)
         self.model = MyModel(args, net, self.loader, self.loader)
         # steady-state rounds: the one-off convergence loop of a client's FIRST personalised round (>= 11 ALA epochs,
         # flower_common.py:604-618) is not what "ms per aggregation round" means; every timed round runs exactly one epoch
@@ -97,14 +105,26 @@ class Federation:
             # clients 'world'..7 are hosted by nobody: their term of the weighted sum is n_k x (initial state), a constant
             n_abs = sum(all_n[world:])
             absent = (DeviceWeights(net.flat_state.clone(), net.flat_counters.clone()), n_abs)
-        self.agg = WeightedAllReduce(all_n[cid], device=dev, constant_term=absent)
+        self.agg = WeightedAllReduce(all_n[cid], device=dev, constant_term=absent, timing=True)
+        self.backend = None
         if world > 1:
             # communicator creation (seconds, once) must not land inside a timed region, whatever --warmup is
             import torch.distributed as dist
-            dist.all_reduce(torch.zeros(1, device=dev if dist.get_backend() == "nccl" else "cpu"))
+            self.backend = dist.get_backend()
+            if not os.environ.get("FEDICRA_DIST_BACKEND"):          # (test hook: several ranks on one GPU through gloo)
+                assert self.backend == "nccl", f"multi-GPU bench must exchange over RCCL, got backend {self.backend!r}"
+            dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
             torch.cuda.synchronize()
         self.iter_global = 60                            # > 50: the ALA branch runs (flower_common.py:524-526)
         self.agg_events = []
+        self.train_events = []
+        self._loaded = None
+        self.model.__dict__["_timing_mark"] = self._mark
+
+    def _mark(self, what):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._loaded = e
 
     def run_steps(self, nsteps):
         a, c = self.a, self.client
@@ -112,6 +132,8 @@ class Federation:
         while done < nsteps:
             it = min(a.round_iters, nsteps - done)
             c.args.iters = it
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
             c._train({"iter_global": self.iter_global, "iters": it, "eval_iters": 10 * it, "batch_size": a.batch,
                       "stage": "fit"})
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -119,9 +141,11 @@ class Federation:
             self.agg.start(self.model.get_device_weights())      # side stream: pre-scale, all-reduce, divide
             c.sampled_batches = list(c.trainloader)              # overlapped: next round's batch staging (epoch list)
             glob = self.agg.finish()
+            self._loaded = None
             self.model.set_weights(glob, {"iter_global": self.iter_global})    # global load + ALA epoch
             e1.record()
-            self.agg_events.append((e0, e1))
+            self.agg_events.append((e0, e1, self._loaded))
+            self.train_events.append((t0, e0, it))
             self.iter_global += 1
             done += it
 
@@ -130,7 +154,7 @@ class Federation:
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
-        self.agg_events = []
+        self.agg_events, self.train_events, self.agg.splits = [], [], []
         t0 = time.perf_counter()
         self.run_steps(steps)
         torch.cuda.synchronize()
@@ -141,46 +165,89 @@ class Federation:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.model.model.flat_state.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        agg_ms = [e0.elapsed_time(e1) for e0, e1 in self.agg_events]
+        agg_ms = [e0.elapsed_time(e1) for e0, e1, _ in self.agg_events]
         return elapsed, sum(agg_ms) / max(len(agg_ms), 1)
+
+    def round_split(self):
+        """Mean ms per round of the last timed() call: local training (round_iters steps), then the aggregation round cut
+        into pack (pre-scale on the side stream) / collective (all-reduce) / unpack (divide + the load of the global state
+        into the model, up to the event after it) / ala (the rest of set_weights: one ALA epoch)."""
+        n = float(max(len(self.agg_events), 1))
+        sp = self.agg.split_ms() or {"pack": 0.0, "collective": 0.0, "divide": 0.0, "exposed": 0.0, "hidden": 0.0}
+        train = sum(t0.elapsed_time(t1) for t0, t1, _ in self.train_events) / n
+        steps = sum(it for _, _, it in self.train_events) / n
+        to_loaded = sum(e0.elapsed_time(l) for e0, _, l in self.agg_events if l is not None) / n
+        total = sum(e0.elapsed_time(e1) for e0, e1, _ in self.agg_events) / n
+        out = {"train": train, "train_steps_per_round": steps, "pack": sp["pack"], "collective": sp["collective"],
+               "unpack": max(0.0, to_loaded - sp["pack"] - sp["collective"]), "ala": total - to_loaded,
+               "aggregation_total": total, "side_stream_exposed": sp["exposed"], "overlap_hidden": sp["hidden"]}
+        return {k: round(v, 3) for k, v in out.items()}
 
 
 def cpu_baseline(a):
-    """The oracle's FedICRA local_train (LC forwards included) on the host cores: bounded sample of the same workload."""
+    """The CPU oracle (oracle/, kind "port") on this box's host cores, on a bounded sample of the same workload:
+    the FedICRA local-training iteration (LC forwards included) in the timed run's head : body mix, then one aggregation
+    round (numpy FedAvg over 8 client states + one ALA epoch), on a THIRD of a batch (4 images) so that a warm-up plus
+    three timed iterations stay within about a minute; per-image cost on the CPU does not depend on the batch size at 512^2."""
+    import numpy as np
     from oracle import fed_ref
     from oracle.unet_ref import RefUNetLC
-    from fedicra_amd.synth import phantom_batch
+    from fedicra_amd.synth import client_num_batches, phantom_batch
     # torch's CPU conv path stops scaling (and collapses from oversubscription) far below the 256 hardware
     # threads of the GPU box's host: use at most 32 threads and report that number as `cores`.
     cores = min(os.cpu_count() or 1, int(os.environ.get("FEDICRA_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
     torch.manual_seed(2022)
+    B = max(1, min(a.batch, int(os.environ.get("FEDICRA_CPU_BATCH", "4"))))
     m = RefUNetLC(a.in_chns, a.classes, 1, FEDERATION, FEDERATION, 0, heads=1)
-    img, weak, _ = phantom_batch(a.batch, a.size, a.in_chns, a.classes, cid=0, index=0)
-    batches = [{"image": torch.from_numpy(img), "label": torch.from_numpy(weak)}]
+    batches = []
+    for i in range(2):
+        img, weak, _ = phantom_batch(B, a.size, a.in_chns, a.classes, cid=0, index=i)
+        batches.append({"image": torch.from_numpy(img), "label": torch.from_numpy(weak)})
     st = fed_ref.TrainState(0.01)
     kw = dict(num_classes=a.classes, base_lr=0.01, max_iterations=30000, img_class="faz" if a.in_chns == 1 else "odoc",
-              strategy="FedICRA", rep_iters=0, alpha=1.0, cid=0, num_clients=FEDERATION)
-    n, t0 = 0, time.perf_counter()
-    while n < 1 or (time.perf_counter() - t0 < 15.0 and n < 20):
-        fed_ref.local_train(m, st, batches, iters=1, **kw)       # head-phase iteration: forward, 7 LC forwards, out_conv step
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n * a.batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} head-phase FedICRA training iteration(s) of {a.batch}x{a.in_chns}x{a.size}x{a.size} incl. the 7 "
-                      f"LC forwards (oracle.fed_ref.local_train on RefUNetLC, torch {torch.__version__} CPU fp32), no warm-up"}
+              strategy="FedICRA", alpha=1.0, cid=0, num_clients=FEDERATION)
+    fed_ref.local_train(m, st, batches, iters=1, rep_iters=0, **kw)          # warm-up: thread pool, allocator, primitives
+    t_head, t_body = [], []
+    for rep in (0, 0, 1):                                                      # two head-phase + one body-phase iteration
+        t0 = time.perf_counter()
+        fed_ref.local_train(m, st, batches, iters=1, rep_iters=rep, **kw)
+        (t_body if rep else t_head).append(time.perf_counter() - t0)
+    head_frac = (a.round_iters - 3) / float(a.round_iters)
+    s_iter = head_frac * float(np.median(t_head)) + (1.0 - head_frac) * float(np.median(t_body))
+    # aggregation round: flwr's aggregate restated in numpy over the 8 clients' wire payloads + one ALA epoch
+    w = fed_ref.get_weights(m)
+    n_k = client_num_batches(FEDERATION, a.batch)
+    t0 = time.perf_counter()
+    glob = fed_ref.fedavg_aggregate([([x + np.float32(0.001 * k) if x.dtype == np.float32 else x for x in w], n_k[k])
+                                     for k in range(FEDERATION)])
+    t_agg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fed_ref.set_weights_ala(m, glob, batches[:1], num_classes=a.classes, iter_global=60, start_phase=False,
+                            img_class="faz" if a.in_chns == 1 else "odoc")
+    t_ala_batch = (time.perf_counter() - t0) * (a.batch / float(B))           # one ALA batch of the full size
+    return {"value": round(B / s_iter, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_aggregation_round": round((t_agg + t_ala_batch * a.loader_batches) * 1e3, 1),
+            "ms_fedavg_numpy_k8": round(t_agg * 1e3, 2),
+            "sec_per_head_iteration": round(float(np.median(t_head)), 3), "sec_per_body_iteration": round(float(np.median(t_body)), 3),
+            "sample": f"oracle.fed_ref.local_train on RefUNetLC (torch {torch.__version__} CPU fp32, {cores} threads): 1 warm-up + 2 "
+                      f"head-phase + 1 body-phase FedICRA iterations of {B}x{a.in_chns}x{a.size}x{a.size} (a third of the batch) incl. "
+                      f"the 7 LC forwards, weighted {a.round_iters - 3}:3 like the timed rounds; aggregation = numpy FedAvg K=8 + one "
+                      f"ALA batch of {B} images scaled to {a.loader_batches} batches of {a.batch}"}
 
 
 def roofline_pass(client, a, dtype_name):
     """Eager, instrumented iterations: HIP events around every C-ABI launch on the launch stream."""
     from fedicra_amd import _lib as L
     client.use_graph = False
-    iters = 4
+    iters = a.round_iters                                # the timed mix: round_iters - 3 head-phase + 3 body-phase iterations
     client.args.iters = iters
-    cfg = {"iter_global": 60, "iters": iters, "eval_iters": 10, "batch_size": a.batch, "stage": "fit"}
-    client._train(cfg)                                   # warm the eager path
+    cfg = {"iter_global": 60, "iters": iters, "eval_iters": 10 * iters, "batch_size": a.batch, "stage": "fit"}
+    client.args.iters = 4
+    client._train(dict(cfg, iters=4))                    # warm the eager path (both phases)
+    client.args.iters = iters
     L.profile_begin(subtract_overhead=False)
-    client._train(cfg)                                   # 1 head-phase + 3 body-phase iterations
+    client._train(cfg)
     kp = L.profile_end()
     prof = kp.summary()
     total_ms = sum(v["ms"] for v in prof.values())
@@ -194,6 +261,17 @@ def roofline_pass(client, a, dtype_name):
         for q in ("calls", "ms", "flops", "bytes"):
             f[q] += v[q]
     fname, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    # per-launch min-roofline: each (kind, shape) is priced against whichever of MFMA peak / HBM peak bounds it;
+    # frac = sum of those ideal times / sum of measured times (SURVEY section 8d "per-layer min(MFMA, HBM)")
+    pk_f, pk_b = MFMA_PEAK[dtype_name] * 1e12, HBM_PEAK_GBS * 1e9
+
+    def ideal_ms(v):
+        return max(v["flops"] / pk_f, v["bytes"] / pk_b) * 1e3
+
+    fam_keys = [k for k in prof if (("conv_fwd" if k[0] == "conv_dgrad" else k[0]) == fname)]
+    conv_keys = [k for k in prof if k[0].startswith("conv")]
+    min_roof_fam = sum(ideal_ms(prof[k]) for k in fam_keys) / max(sum(prof[k]["ms"] for k in fam_keys), 1e-9)
+    min_roof_conv = sum(ideal_ms(prof[k]) for k in conv_keys) / max(sum(prof[k]["ms"] for k in conv_keys), 1e-9)
     calls = dom["calls"]
     avg_ms = dom["ms"] / calls
     flops, nbytes = dom["flops"] / calls, dom["bytes"] / calls
@@ -216,6 +294,11 @@ def roofline_pass(client, a, dtype_name):
             "frac_of_mfma_peak": round(flops / (avg_ms * 1e-3) / 1e12 / mf_peak, 4),
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
             "share_of_gpu_time": round(dom["ms"] / total_ms, 4),
+            "min_roofline_frac": round(min_roof_fam, 4), "min_roofline_frac_all_conv": round(min_roof_conv, 4),
+            "min_roofline_note": "sum over launches of max(flops / MFMA peak, bytes / HBM peak) / sum of measured durations; "
+                                 "per-shape table: profiles/*_per_layer_roofline.txt",
+            "instrumented_iterations": f"{iters - 3} head-phase + 3 body-phase (the timed mix)",
+            "hip_launches_per_step": round(sum(v["calls"] for v in prof.values()) / float(iters), 1),
             "conv_flops_per_step": conv_flops / float(iters),
             "kernel_time_breakdown_ms_per_step": {k: round(v / float(iters), 4) for k, v in sorted(breakdown.items())}}
     # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 PMC run of this same
@@ -234,6 +317,19 @@ def roofline_pass(client, a, dtype_name):
                 break
         except (OSError, ValueError, KeyError):
             continue
+    table = os.environ.get("FEDICRA_BENCH_TABLE")
+    if table:
+        with open(table, "w") as f:
+            f.write("# per-launch-shape roofline of one FedICRA round's local training (bench.py eager instrumented pass, HIP events, "
+                    f"{iters - 3} head + 3 body iterations, {dtype_name}); ideal = max(flops / {MFMA_PEAK[dtype_name]} TF/s, bytes / 8 TB/s)\n")
+            f.write(f"# {'kind/shape (dtype,N,H,W,Cin,Cout,k)':58s} {'calls':>5s} {'avg_us':>9s} {'ideal_us':>9s} {'frac':>6s} {'TF/s':>8s} {'GB/s':>8s} bound\n")
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                us = v["ms"] / v["calls"] * 1e3
+                idl = ideal_ms(v) / v["calls"] * 1e3
+                bound = "mfma" if v["flops"] / pk_f >= v["bytes"] / pk_b else "hbm"
+                f.write(f"{'/'.join(map(str, k)):60s} {v['calls']:5d} {us:9.1f} {idl:9.1f} {idl / max(us, 1e-9):6.3f} "
+                        f"{v['flops'] / v['calls'] / (us * 1e-6) / 1e12:8.1f} {v['bytes'] / v['calls'] / (us * 1e-6) / 1e9:8.1f} {bound}\n")
+            f.write(f"# family {fname}: min-roofline frac {min_roof_fam:.4f}; all conv launches: {min_roof_conv:.4f}\n")
     if os.environ.get("FEDICRA_BENCH_VERBOSE"):
         top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:60]
         for k, v in top:
@@ -273,6 +369,10 @@ def main():
     ap.add_argument("--round-iters", type=int, default=10)
     ap.add_argument("--loader-batches", type=int, default=8,
                     help="training batches resident per client = len(trainloader) = batches of one ALA epoch")
+    ap.add_argument("--data", default="host", choices=["host", "resident"],
+                    help="where the training batches live: pinned host memory, staged over PCIe beside the compute stream "
+                         "inside the timed region (default; the reference's DataLoader), or resident in HBM")
+    ap.add_argument("--no-resident", action="store_true", help="skip the resident-data rate reported beside the headline")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -305,6 +405,19 @@ def main():
         return
     elapsed, agg_ms = fed.timed(a.warmup, a.steps, dist)
     value = a.steps * a.batch * world / elapsed
+    split = fed.round_split()
+    h2d_bytes_per_step = None
+    if a.data == "host":
+        h2d_bytes_per_step = a.batch * (a.in_chns * 4 + 1) * a.size * a.size
+
+    resident = None
+    if a.data == "host" and not a.no_resident:
+        fedr = Federation(a, rank, world, dev, a.dtype, data="resident")
+        kr = min(a.steps, a.round_iters)
+        elr, aggr = fedr.timed(a.warmup, kr, dist)
+        resident = {"images_per_sec": round(kr * a.batch * world / elr, 2), "steps": kr, "ms_per_aggregation_round": round(aggr, 3)}
+        del fedr
+        torch.cuda.empty_cache()
 
     fp32 = None
     if a.dtype != "fp32" and not a.no_fp32:
@@ -332,16 +445,26 @@ def main():
                        "clients_hosted": world, "federation": FEDERATION, "global_batch": a.batch * world,
                        "images_per_sec_per_client": round(value / world, 2),
                        "ms_per_aggregation_round": round(agg_ms, 3),
+                       "round_split_ms": split,
                        "ala_batches_per_round": a.loader_batches,
+                       "data_location": ("pinned host memory; batch i+1 crosses PCIe on a side stream while iteration i computes "
+                                         "(inside the timed region)") if a.data == "host" else "resident in HBM",
+                       "h2d_bytes_per_step": h2d_bytes_per_step,
+                       "resident_images_per_sec": None if resident is None else resident["images_per_sec"],
+                       "resident": resident,
                        "fp32_images_per_sec": None if fp32 is None else fp32["images_per_sec"],
                        "fp32": fp32, "hipgraph": not a.no_graph, "parallelism": f"fed-dp{world}"},
         }
+        if world > 1:
+            line["config"].update({"rccl_ranks": world if fed.backend == "nccl" else 0, "dist_backend": fed.backend,
+                                   "allreduce_us_per_round": round(split["collective"] * 1e3, 1),
+                                   "overlap_hidden_ms": split["overlap_hidden"]})
         if not a.no_roofline:
             try:
                 roof = roofline_pass(fed.client, a, a.dtype)
                 line["roofline"] = roof
                 step_s = (elapsed - agg_ms * 1e-3 * len(fed.agg_events)) / a.steps      # training part of a step
-                tf = roof["conv_flops_per_step"] / step_s / 1e12
+                tf = roof["conv_flops_per_step"] / step_s / 1e12          # same head : body mix on both sides of the ratio
                 line["config"]["conv_tflops_per_gpu"] = round(tf, 2)
                 line["config"]["frac_of_mfma_peak"] = round(tf / MFMA_PEAK[a.dtype], 4)
             except Exception as e:  # noqa: BLE001  (never lose the headline number to the instrumented pass)

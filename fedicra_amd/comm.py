@@ -27,10 +27,15 @@ from .flower_common import DeviceWeights
 
 
 class WeightedAllReduce:
-    def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None, constant_term=None):
+    def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None, constant_term=None,
+                 timing: bool = False):
         """`constant_term` = (DeviceWeights, n): a fixed contribution n * state to the weighted sum, added by rank 0 --
-        clients of the federation that no rank hosts (bench.py with fewer GPUs than clients)."""
+        clients of the federation that no rank hosts (bench.py with fewer GPUs than clients).  `timing`: HIP events on the
+        side stream around pre-scale / all-reduce / divide and on the training stream around the fence (bench.py's round
+        split; `splits` collects one dict of event pairs per round)."""
         self.group = group
+        self.timing = bool(timing)
+        self.splits = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device
@@ -71,7 +76,10 @@ class WeightedAllReduce:
         if self.on_gpu:
             from . import _lib as L
             self.side.wait_stream(torch.cuda.current_stream())
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.timing else None
             with torch.cuda.stream(self.side):
+                if ev:
+                    ev[0].record(self.side)
                 L.scale(weights.state, self._send, float(self.n_local[0]))
                 torch.mul(weights.counters, self.n_local[0], out=self._cnt)
                 for w, n in zip(many[1:], self.n_local[1:]):          # acc + w_k * n_k, left to right (numpy's order)
@@ -80,10 +88,17 @@ class WeightedAllReduce:
                 if self.constant is not None:
                     L.axpy(self._send, self.constant[0].state, float(self.constant[1]))
                     self._cnt.add_(self.constant[0].counters, alpha=self.constant[1])
+                if ev:
+                    ev[1].record(self.side)
                 if self.world > 1:
                     dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                     dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
+                if ev:
+                    ev[2].record(self.side)
                 L.scale(self._send, self._send, float(self.total), divide=True)
+                if ev:
+                    ev[3].record(self.side)
+                    self.splits.append({"side": ev})
                 self._done = torch.cuda.Event()
                 self._done.record(self.side)
         else:   # gloo / CPU test path
@@ -103,10 +118,31 @@ class WeightedAllReduce:
     def finish(self) -> DeviceWeights:
         """Fence the training stream behind the collective and return the global weights."""
         if self.on_gpu:
-            torch.cuda.current_stream().wait_event(self._done)
+            if self.timing and self.splits:
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record()
+                torch.cuda.current_stream().wait_event(self._done)
+                w1.record()
+                self.splits[-1]["fence"] = (w0, w1)
+            else:
+                torch.cuda.current_stream().wait_event(self._done)
         self.counter_mean = self._cnt.double() / self.total              # float64, as flwr's aggregate hands it back
         counters = self.counter_mean.to(torch.int64)                      # the clients' load truncates
         return DeviceWeights(self._send, counters)
+
+    def split_ms(self):
+        """Mean milliseconds per round of the recorded rounds (call after a device synchronize): pack = pre-scale (+ the
+        co-located / absent clients' terms), collective = the two all-reduces (0 when one rank holds everything), divide, and
+        `exposed` = how long the training stream actually stood at the fence; hidden = side-stream span - exposed."""
+        if not self.splits:
+            return None
+        n = float(len(self.splits))
+        pack = sum(s["side"][0].elapsed_time(s["side"][1]) for s in self.splits) / n
+        coll = sum(s["side"][1].elapsed_time(s["side"][2]) for s in self.splits) / n
+        div = sum(s["side"][2].elapsed_time(s["side"][3]) for s in self.splits) / n
+        exposed = sum(s["fence"][0].elapsed_time(s["fence"][1]) for s in self.splits if "fence" in s) / n
+        return {"pack": pack, "collective": coll, "divide": div, "exposed": exposed,
+                "hidden": max(0.0, pack + coll + div - exposed)}
 
     def aggregate(self, weights: DeviceWeights) -> DeviceWeights:
         self.start(weights)

@@ -235,13 +235,26 @@ class MyModel(nn.Module):
             net.flat_counters.copy_(cnt)
             ops.bump_weights_epoch()
 
+    def batch_stager(self):
+        """Host -> device staging beside the compute stream (staging.py), shared by local training and the ALA loop."""
+        st = self.__dict__.get("_stager")
+        if st is None:
+            from .staging import BatchStager
+            st = self.__dict__["_stager"] = BatchStager(self.model.flat_state.device)
+        return st
+
     def _batch(self, sampled_batch):
+        """(image, label, staged) on the device.  flower_common.py:568-573.  A host batch comes out of the staging pair
+        (prefetched on the side stream when the caller looked ahead); `staged` tells the caller to release() it."""
         dev = self.model.flat_state.device
-        if self.args.img_class == "faz":
-            x = sampled_batch["image"].unsqueeze(1)
+        staged = dev.type == "cuda" and sampled_batch["image"].device.type == "cpu"
+        if staged:
+            x, y = self.batch_stager().fetch(sampled_batch)
         else:
-            x = sampled_batch["image"]
-        return x.to(dev), sampled_batch["label"].to(dev)
+            x, y = sampled_batch["image"].to(dev), sampled_batch["label"].to(dev)
+        if self.args.img_class == "faz":
+            x = x.unsqueeze(1)
+        return x, y, staged
 
     def _ala_model(self, net, local_keys):
         """The reference deep-copies the model on every set_weights (:498,503); here ONE copy is kept and its flat state
@@ -275,6 +288,9 @@ class MyModel(nn.Module):
         net = self.model
         old_local = net.flat_params.clone()                   # "server_model" deepcopy = OLD LOCAL weights (quirk 4)
         self._load_global(weights)                            # self.model now holds the GLOBAL weights
+        mark = self.__dict__.get("_timing_mark")              # bench.py's round split: an event after the global load
+        if mark is not None:
+            mark("loaded")
         glob = net.flat_params
         first = next(iter(net.parameters()))
         n0, o0 = first._fi_off, first.numel()
@@ -325,9 +341,16 @@ class MyModel(nn.Module):
         with ops.use_context(st["ctx"]):
             while True:
                 loss = None
-                for sampled_batch in self.trainloader:        # :566-602
-                    x, y = self._batch(sampled_batch)
+                batches = iter(self.trainloader)              # :566-602, one batch of look-ahead for the H2D staging
+                upcoming = next(batches, None)
+                while upcoming is not None:
+                    sampled_batch, upcoming = upcoming, next(batches, None)
+                    x, y, staged = self._batch(sampled_batch)
                     if not use_graph:
+                        if staged:                            # eager path: take a private copy, free the staging pair
+                            x, y = x.clone(), y.clone()
+                            self.batch_stager().release()
+                            self.batch_stager().prefetch(upcoming)
                         loss = iteration(x, y)
                         ops.bump_weights_epoch()              # temp's weights were rewritten through raw pointers
                         continue
@@ -343,6 +366,9 @@ class MyModel(nn.Module):
                             st["graph"], st["warm"] = None, False
                     st["x"].copy_(x, non_blocking=True)
                     st["y"].copy_(y, non_blocking=True)
+                    if staged:
+                        self.batch_stager().release()
+                        self.batch_stager().prefetch(upcoming)         # lands while this batch computes
                     if not st["warm"]:                        # first batch ever: eager (allocations, operand packs)
                         st["loss"] = iteration(st["x"], st["y"])
                         st["warm"] = True

@@ -75,7 +75,9 @@ class MyClient(BaseClient):
     def _stage(self, sampled_batch):
         """Copy one batch into the static device buffers (graph inputs)."""
         dev = self._net().flat_state.device
-        x, y = sampled_batch["image"], sampled_batch["label"]
+        stager = self._stager()
+        staged = stager is not None and stager.on_host(sampled_batch)
+        x, y = stager.fetch(sampled_batch) if staged else (sampled_batch["image"], sampled_batch["label"])
         if self.args.img_class == "faz":
             x = x.unsqueeze(1)                               # flower_pCE_2D.py:77
         if self._xbuf is None or self._xbuf.shape != x.shape:
@@ -88,7 +90,24 @@ class MyClient(BaseClient):
             self._xbuf, self._ybuf, self._steps = self._shapes[key]
         self._xbuf.copy_(x, non_blocking=True)
         self._ybuf.copy_(y, non_blocking=True)
+        if staged:
+            stager.release()
         return self._xbuf, self._ybuf
+
+    def _stager(self):
+        """Host-resident batches (a DataLoader-like trainloader) are staged beside the compute stream (staging.py); the
+        stager belongs to the model wrapper so that the ALA loop of set_weights shares it."""
+        get = getattr(self.model, "batch_stager", None)
+        return get() if callable(get) and self._net().flat_state.is_cuda else None
+
+    def _prefetch_next(self):
+        """Start the host -> device copy of the batch the NEXT iteration will take (flower_pCE_2D.py:66-73: same epoch
+        list) while this one runs.  At an epoch boundary the list is rebuilt first: no prefetch, the copy is serial."""
+        stager = self._stager()
+        n_b = len(self.trainloader)
+        if stager is None or not self.sampled_batches or self.current_iter % n_b == 0:
+            return
+        stager.prefetch(self.sampled_batches[self.current_iter % n_b])
 
     def _set_freeze(self, i_iter):
         """flower_pCE_2D.py:84-101.  Returns a hashable pattern id."""
@@ -216,6 +235,8 @@ class MyClient(BaseClient):
                 self.current_iter += 1
                 lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
                 self.current_lr = lr_
+                if i_iter + 1 < iters:
+                    self._prefetch_next()
             yield i_iter
         with self._scope():
             return self._round_result(hist, x, y, rec)

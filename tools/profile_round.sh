@@ -3,7 +3,7 @@
 # iterations alone (bench.py --roofline-only: the launch mix the roofline object prices).  Run on the GPU box from the
 # repo root: bash tools/profile_round.sh r02_a ; results land in gpurun_out/<tag>_*
 TAG=${1:-r02_a}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
-FEDICRA_BENCH_VERBOSE=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+FEDICRA_BENCH_TABLE=$OUT/${TAG}_per_layer_roofline.txt FEDICRA_BENCH_VERBOSE=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_k /tmp/prof_r
 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline \
