@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -34,7 +34,7 @@ EXPORTS = [
 class FiConv(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ksize", C.c_int),
                 ("c0", C.c_int), ("c1", C.c_int), ("co0", C.c_int), ("co1", C.c_int), ("accumulate0", C.c_int),
-                ("accumulate1", C.c_int), ("y_f32", C.c_int)]
+                ("accumulate1", C.c_int), ("y_f32", C.c_int), ("w16", C.c_void_p), ("w16_rows", C.c_int)]
 
 
 class FiInXform(C.Structure):
@@ -237,6 +237,21 @@ def _esz(t):
 
 
 # ------------------------------------------------------------------ thin wrappers
+def conv_weight_chunk16(dtype, ksize, cin, cout):
+    """True when a filter of this shape gets the chunk-major second operand (fi_pack_weights mode 2 / 3; for the dgrad
+    operand pass the conv's cout as cin and vice versa)."""
+    return bool(lib().fi_conv_weight_chunk16(dt(dtype), int(ksize), int(cin), int(cout)))
+
+
+def _attach_w16(d, w):
+    """The chunk-major sibling of a packed operand travels as a python attribute of the operand tensor (ops._packed,
+    flat.FlatStoreMixin._fi_refresh_packs set it): FiConv.w16 / w16_rows."""
+    w16 = getattr(w, "_fi_w16", None)
+    if w16 is not None:
+        d.w16 = w16.data_ptr()
+        d.w16_rows = int(getattr(w, "_fi_w16_rows", 0))
+
+
 def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False, y_f32=False, tag="conv_fwd", cout=None):
     """x*: [N,H,W,C] dense NHWC; w: packed [Cout][k*k][Cin] (any shape, dense) in x0.dtype.  y0 = None with `cout` and
     `stats` given: statistics-only launch (nothing stored)."""
@@ -246,6 +261,7 @@ def conv2d_fwd(x0, x1, w, bias, y0, y1, stats, *, ksize, acc0=False, acc1=False,
     co0 = int(cout) if y0 is None else y0.shape[3]
     co1 = 0 if y1 is None else y1.shape[3]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, co0, co1, int(acc0), int(acc1), int(y_f32))
+    _attach_w16(d, w)
     cin, cout, px = c0 + c1, co0 + co1, N * H * W
     with _timed(tag, (str(x0.dtype)[6:], N, H, W, cin, cout, ksize), 2.0 * px * cin * cout * ksize * ksize,
                 px * cin * _esz(x0) + (0 if y0 is None else px * cout * _esz(y0)) + cin * cout * ksize * ksize * _esz(x0)):
@@ -285,6 +301,7 @@ def conv2d_fwd_fused(x0, t0, x1, t1, w, bias, y, stats, *, ksize, groups, cout=N
     c1 = 0 if x1 is None else x1.shape[3]
     co = int(cout) if y is None else y.shape[3]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, co, 0, 0, 0, 0)
+    _attach_w16(d, w)
     cin, px = c0 + c1, N * H * W
     gi = N // groups
     with _timed(tag, (str(x0.dtype)[6:], N, H, W, cin, co, ksize, "fused"), 2.0 * px * cin * co * ksize * ksize,

@@ -25,6 +25,8 @@ int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStre
 int fi_conv_thin_f16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws2_bf16(int tr, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws2_f16(int tr, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -51,7 +53,8 @@ static long wgrad_blocks() {
 }
 
 // which forward kernel: [0] -1 = FI_V2 from the environment (default 2: per-layer choice), 0 = one-tile kernel, 1 = persistent
-// kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 / 6 = wave-specialised kernel with 4 / 8 / 2 x 4 producer waves; [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
+// kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 / 6 = wave-specialised kernel with 4 / 8 / 2 x 4 producer waves, 7 = the
+// 64 x 64-wave-tile form wherever it applies (needs FiConv.w16; forcing any OTHER form also keeps launches off it); [1] slab width in 16-channel fragments, [2] channel chunk, [3] workgroups per CU (0 = default)
 static long g_tune[4] = {-1, 0, 0, 0};
 static long env_v2() {
   static long v = env_long("FI_V2", 2);      // 2 = the measured per-layer rule
@@ -59,11 +62,23 @@ static long env_v2() {
 }
 extern "C" int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu) {
   if ((nf && nf != 1 && nf != 2 && nf != 4) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 16) return FI_ERR_SHAPE;
+  if (v2 > 7) return FI_ERR_SHAPE;
   g_tune[0] = v2;
   g_tune[1] = nf;
   g_tune[2] = ck;
   g_tune[3] = wgs_per_cu;
   return 0;
+}
+
+// The 64 x 64-wave-tile form (conv_fwd_ws2_kernel) and its chunk-major operand: FI_WS2 = 0 switches both off, 1 (default)
+// = the measured per-launch rule below, 2 = wherever the kernel applies.
+static long env_ws2() {
+  static long v = env_long("FI_WS2", 1);
+  return v;
+}
+extern "C" int fi_conv_weight_chunk16(int dtype, int ksize, int cin, int cout) {
+  if (env_ws2() == 0) return 0;
+  return (dtype == FI_BF16 || dtype == FI_F16) && ksize == 3 && cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0;
 }
 
 static int pick_th(int N, int H, int W, long per_tile_mult) {
@@ -209,6 +224,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
   a.tilesY = fi_cdiv(d->H, th);
   a.nct = nct;
   a.depth = 0;
+  a.wrows = 0;
 #ifdef FI_TRACE
   a.trace = g_trace;
 #endif
@@ -217,6 +233,35 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
     const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
     const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
+    // 64 x 64-wave-tile form (conv_fwd_ws2_kernel; conv_ws2.h): needs the chunk-major second operand (FiConv.w16), 16-channel
+    // chunks that do not straddle the two sources, whole 64-channel slabs, a plain epilogue and 32-bit byte offsets
+    if (d->w16 && depth == 0 && !f32 && d->ksize == 3 && (a.xf == 0 || a.xf == 1) && plain && env_ws2() != 0 &&
+        (g_tune[0] < 0 || g_tune[0] == 2 || g_tune[0] == 7)) {
+      const long big = (long)d->N * d->H * d->W * 2;
+      const int rows = d->w16_rows > 0 ? d->w16_rows : cout;
+      const bool ok = d->c0 % 16 == 0 && d->c1 % 16 == 0 && cin >= 32 && cout % 64 == 0 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&
+                      big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
+                      big * d->co1 < (1L << 32) && (long)rows * 9 * cin * 2 < (1L << 32);
+      // measured rule (FI_WS2 = 1): the batched fused launches and the plain launches the 32-pixel-tile form had
+      const long tiles16 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
+      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || a.xf == 1 || cin >= 64;
+      if (ok && wanted) {
+        // 16-row tiles x 128 channels where the slab exists and the launch still has >= 2 items per CU, else 32 rows x 64
+        int tr = (cout % 128 == 0 && tiles16 * (cout / 128) >= 512) ? 16 : 32;
+        if (tr == 32 && d->H <= 16 && cout % 128 == 0) tr = 16;           // a 32-row tile would be half empty
+        static const long force_tr = env_long("FI_WS2_TR", 0);
+        if (force_tr == 16 && cout % 128 == 0) tr = 16;
+        if (force_tr == 32) tr = 32;
+        if (g_tune[0] == 7 && g_tune[1] == 1 && cout % 128 == 0) tr = 16;   // fi_conv_tuning(7, 1 | 2, ...): 16- / 32-row tiles
+        if (g_tune[0] == 7 && g_tune[1] == 2) tr = 32;
+        a.w = d->w16;
+        a.wrows = rows;
+        a.tilesY = fi_cdiv(d->H, tr);
+        a.nct = cout / (tr == 16 ? 128 : 64);
+        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(tr, (int)g_tune[3], a, st) : fi_conv_fwd_ws2_bf16(tr, (int)g_tune[3], a, st);
+        return rc;
+      }
+    }
     // wave-specialised form (conv_fwd_ws_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 32-bit
     // byte offsets into every tensor
     {

@@ -52,6 +52,7 @@ struct ConvArgs {
   int c0, c1, co0, co1;
   int acc0, acc1, y_f32;
   int tilesX, tilesY, nct;
+  int wrows;                 // conv_fwd_ws2_kernel: output rows per 16-channel chunk of the chunk-major operand `w` then points to
   int depth;                 // > 0 (wave-specialised form only): 3x3x3 convolution over volumes of `depth` consecutive slices --
                              // an "image" is a slice, the depth taps are three channel groups of the contraction (K =
                              // 9 taps x 3 depth taps x (c0 + c1) channels, filter [Cout][9][3][c0 + c1]); slices outside the

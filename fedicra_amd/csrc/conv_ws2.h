@@ -1,0 +1,509 @@
+// Forward / dgrad kernel, fifth form: wave-specialised, 64 x 64 WAVE tiles on v_mfma_f32_32x32x16 (channel-rich 3x3 layers).
+//
+// Why (round 3; profiles/r02_q_ws_kprobe_pmc.txt, MI355X_MICROARCH.md "LDS"): conv_fwd_ws_kernel gives each consumer wave a
+// 32-pixel x 64-channel tile: per contraction step 6 ds_read_b128 feed 8 MFMAs, i.e. 0.75 LDS-array cycles per MFMA cycle
+// for the fragment reads alone, plus the producers' writes -- the LDS pipe, not the matrix pipe, is what a bare consumer
+// saturates (51 % of the bf16 peak).  LDS bytes per FLOP fall with the wave tile: here a consumer wave owns 4 image rows
+// (64 pixels) x 64 output channels = 2 x 2 accumulator blocks of v_mfma_f32_32x32x16, so a filter tap is 4 fragment reads
+// for 4 MFMAs of 32 cycles each: 0.5 LDS cycles per MFMA cycle (reads + writes: 0.66 against 0.99), and half the MFMA
+// instructions.  K = 16 per MFMA also makes a 16-channel chunk exactly one MFMA per tap (9 per stage, no K padding), which
+// halves a stage's footprint: a 256-pixel x 128-channel (or 512 x 64) workgroup tile double-buffers in 94 KB (76 KB).
+//
+//   workgroup = 8 consumer waves + 2 teams of 4 producer waves (1024 threads, 128 registers), persistent over a run of items
+//   tile      = TR x 16 pixels x BN channels: (TR, BN) = (16, 128) -> consumers 4 row groups x 2 channel halves,
+//                                                        (32,  64) -> consumers 8 row groups x 1
+//   stage     = one 16-channel chunk: halo tile [TR+2][18][16 ch] + weight slab [BN][9 taps][16 ch]
+//   weights   = CHUNK-MAJOR packed operand [Cin/16][Cout][9][16] (fi_pack_weights modes 2 / 3): a stage's slab is one
+//               contiguous BN x 288-byte block -- with the tap-major layout a 16-channel chunk touches 32 of every 128-byte
+//               line, four times the L2 -> L1 traffic, which at 128 output channels is the whole 64 B/clk of the vector L1.
+// LDS layouts (bank = (byte / 4) mod 64; a ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32):
+//   pixels : 32 bytes each, no padding; the two 16-byte channel halves of a pixel are SWAPPED on odd halo rows.  A pixel
+//            fragment is two image rows x 16 pixels with lane = half * 32 + row * 16 + column, so a 16-lane group reads 8
+//            pixels of an even and 8 of an odd row, all of the same half: the swap puts them on disjoint banks.
+//   weights: rows of 304 bytes (288 + 16): 19 is odd, so the 16 rows of a lane group start 16 distinct 16-byte units apart.
+// Epilogue: D[channel][pixel] with lane = pixel (32 lanes) and 4 x 4 consecutive channels per lane and block; a
+// v_permlane32_swap per word pairs the two half-waves' 4-channel groups into 16-byte stores (8 consecutive channels of one
+// pixel); BatchNorm statistics of the values as stored: DPP sum over the 16 lanes of a row, one v_permlane16_swap + add per
+// PAIR of values over the two rows, then a wave-private LDS strip that is flushed to the fp64 accumulators every 8 tiles.
+// Same transforms (XF 0 / 1), rounding, statistics slots and group semantics as the other forms.
+#pragma once
+#include "conv_impl.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+#ifndef FI_WS2_DEBUG
+#define FI_WS2_DEBUG 0         // A/B builds: 1 no MFMAs, 2 no loads, 4 no LDS commit, 8 no transform, 16 no epilogue, 32 no statistics
+#endif
+#define FI_WS2_FLUSH_TILES 8   // tiles between two flushes of the fp32 statistics strip into the fp64 accumulators
+
+template <typename T, int TR, int BN, int XF>
+__global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  static_assert((TR == 16 && BN == 128) || (TR == 32 && BN == 64), "8 consumer waves of 4 rows x 64 channels");
+  static_assert(XF == 0 || XF == 1, "plain or transforming loader");
+  constexpr int CW = 8, PT = 256;                                // consumer waves; threads of one producer team
+  constexpr int RG = TR / 4;                                     // row groups (the rest of the 8 waves split the channels)
+  constexpr int XH = TR + 2, XW = 18, KK = 9, CK = 16, VG = 8;
+  constexpr int PXB = 32;                                        // bytes of a staged pixel (16 channels)
+  constexpr int WROW = KK * CK * 2 + 16;                         // bytes of a staged weight row: 288 + 16 (odd 16-byte units)
+  constexpr int XT = XH * XW * PXB, WT = BN * WROW, STAGE = XT + WT;      // bytes
+  typedef typename DT<T>::vec_t vec_t;
+  typedef typename DT<T>::frag_t frag_t;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];    // [2]{ pixels[XH][XW][32 B], weights[BN][304 B] }, [8] strip[3 x 64] floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= CW;
+  const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
+  const int H = a.H, W = a.W;
+
+  // ---- this workgroup's run of items; item = slab * ntile + tile (slab-major: a run keeps its slab and statistics group)
+  const int ntile = a.N * a.tilesY * a.tilesX, tpi = a.tilesY * a.tilesX;
+  const int nitem = ntile * a.nct;
+  const int per = (nitem + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int i_begin = (int)blockIdx.x * per, i_end = min(nitem, i_begin + per);
+  if (i_begin >= i_end) return;
+  const int nchunk = cin / CK;
+  const int nstage = (i_end - i_begin) * nchunk;
+
+  constexpr unsigned esz = 2;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned hw = (unsigned)H * (unsigned)W;
+
+  struct Item {
+    int tx, ty, n, ct;
+  };
+  auto item_at = [&](int item) {
+    Item c;
+    c.ct = item / ntile;
+    const int tile = item - c.ct * ntile;
+    c.n = tile / tpi;
+    const int r = tile - c.n * tpi;
+    c.ty = r / a.tilesX;
+    c.tx = r - c.ty * a.tilesX;
+    return c;
+  };
+  auto item_next = [&](Item c) {
+    if (++c.tx == a.tilesX) {
+      c.tx = 0;
+      if (++c.ty == a.tilesY) {
+        c.ty = 0;
+        if (++c.n == a.N) {
+          c.n = 0;
+          ++c.ct;
+        }
+      }
+    }
+    return c;
+  };
+
+  if (producer) {
+    // =============================================================================================== producers
+    // Two teams of 4 waves; team g owns the stages of parity g and always writes LDS buffer g: while stage s is consumed, team
+    // (s & 1) issues the loads of stage s + 2 and the other team transforms / commits stage s + 1, so a load has a whole stage
+    // to land and the commit's vmcnt(0) is exact.  Loads are branch-free and fixed in number per stage (conv_fwd_ws_kernel).
+    const int team = (wave - CW) >> 2;
+    const int ptid = tid - CW * 64 - team * PT;
+    // pixels: a thread owns one 16-byte half of one pixel column, 7 halo rows apart (252 of the 256 threads)
+    constexpr int XCOLS = XW * 2, XRPP = PT / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
+    static_assert(XRPP == 7, "7 halo rows per pass");
+    const int xcol = ptid % XCOLS, xrow0 = ptid / XCOLS;
+    const int xpx = xcol >> 1, xh = xcol & 1;
+    const bool xact = xrow0 < XRPP;
+    // LDS byte offset of pass p: rows alternate parity from pass to pass (7 is odd), and so does the half swap
+    const unsigned xl_base = (unsigned)((xrow0 * XW + xpx) * PXB);
+    const unsigned xl_even = xl_base + (unsigned)(((xh ^ (xrow0 & 1)) & 1) << 4);
+    const unsigned xl_odd = xl_base + (unsigned)(((xh ^ (xrow0 & 1) ^ 1) & 1) << 4);
+    // weights: the slab of a stage is one contiguous block of BN rows x 18 vectors; a thread owns one vector column of a row,
+    // 14 rows apart (252 threads)
+    constexpr int WCOLS = KK * 2, WRPP = PT / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
+    static_assert(WRPP == 14, "14 weight rows per pass");
+    const int wcol = ptid % WCOLS, wrow0 = ptid / WCOLS;
+    const bool wact = wrow0 < WRPP;
+    const unsigned wl0 = (unsigned)(XT + wrow0 * WROW + wcol * 16);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w), 0, (unsigned)nchunk * (unsigned)a.wrows * (KK * CK * esz), 0x00020000);
+
+    struct Set {
+      vec_t x[XPASS];
+      vec_t w[WPASS];
+      unsigned cofs;            // element offset of this thread's coefficients, fetched at commit
+      unsigned flags;           // bit p: pass p is inside the image; bit 16: source 0; bit 17: transform active
+      unsigned vix0;            // dropout element-vector index of pass 0
+    };
+    Set S;
+    const bool drop0 = XF == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM;
+    uint64_t seed_base = 0;
+    if (drop0) {
+      seed_base = a.t0.seed;
+      if (a.t0.seed_offset) seed_base += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
+    }
+    const T* const x0p = reinterpret_cast<const T*>(a.x0);
+    const T* const x1p = reinterpret_cast<const T*>(a.x1);
+    const float* const dummy = reinterpret_cast<const float*>(a.w);        // >= 32 readable bytes for inactive lanes
+
+    auto issue = [&](const Item& it, int chunk, bool live) __attribute__((always_inline)) {
+#if FI_WS2_DEBUG & 2
+      return;
+#endif
+      const int ci = chunk * CK + xh * VG;                       // first channel of this thread's vector
+      const bool chok = live && xact;
+      const bool first = ci < a.c0;
+      const unsigned cs = (unsigned)(first ? a.c0 : a.c1), co = (unsigned)(first ? ci : ci - a.c0);
+      const T* const xb = first ? x0p : x1p;
+      const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+      const int nl = it.n - grp * a.gimages;
+      const int ns = (XF != 0 && first && a.bcast0) ? nl : it.n;
+      const int gx = it.tx * 16 + xpx - 1;
+      const int gy0 = it.ty * TR + xrow0 - 1;
+      const bool colok = chok && (unsigned)gx < (unsigned)W;
+      unsigned flags = first ? 0x10000u : 0u;
+      const unsigned o0 = (unsigned)((ns * H + gy0) * W + gx) * cs + co;
+      const unsigned step = (unsigned)(XRPP * W) * cs;
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const bool ok = colok && (unsigned)(gy0 + p * XRPP) < (unsigned)H && xrow0 + p * XRPP < XH;
+        flags |= ok ? (1u << p) : 0u;
+        S.x[p] = *reinterpret_cast<const vec_t*>(xb + (ok ? o0 + (unsigned)p * step : 0u));
+      }
+      {
+        // chunk-major operand: [chunk][wrows][9][16]; this slab starts at row it.ct * BN
+        const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(it.ct * BN + wrow0)) * (KK * 2) + (unsigned)wcol) * 16u;
+        const bool wok = live && wact;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) {
+          const bool ok = wok && wrow0 + p * WRPP < BN;
+          S.w[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? o0w + (unsigned)(p * WRPP * KK * 2 * 16) : OOB, 0, 0));
+        }
+      }
+      if constexpr (XF != 0) {
+        const float* scp = first ? a.t0.scale : a.t1.scale;
+        const bool act = chok && scp != nullptr;
+        flags |= act ? 0x20000u : 0u;
+        S.cofs = act ? (unsigned)grp * cs + co : 0u;
+        S.vix0 = (unsigned)((nl * H + gy0) * W + gx) * (cs / VG) + co / VG;
+      }
+      S.flags = flags;
+    };
+
+    auto commit = [&](const Item& it, int buf) __attribute__((always_inline)) {
+#if FI_WS2_DEBUG & 4
+      return;
+#endif
+      char* const sb = smem + buf * STAGE;
+      const bool first = (S.flags & 0x10000u) != 0;
+      float slope = 1.f;
+      bool xf = false, drop = false;
+      uint64_t seed = 0;
+      unsigned vstep = 0;
+      float csc[VG], csh[VG];                                   // this thread's 8 scale / shift values
+      if constexpr (XF != 0) {
+        slope = first ? a.t0.slope : a.t1.slope;
+        xf = (S.flags & 0x20000u) != 0;
+        const float* const scp = xf ? (first ? a.t0.scale : a.t1.scale) : dummy;
+        const float* const shp = xf ? (first ? a.t0.shift : a.t1.shift) : dummy;
+#pragma unroll
+        for (int j = 0; j < VG; j += 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(scp + S.cofs + j);
+          const float4 h4 = *reinterpret_cast<const float4*>(shp + S.cofs + j);
+          csc[j] = s4.x, csc[j + 1] = s4.y, csc[j + 2] = s4.z, csc[j + 3] = s4.w;
+          csh[j] = h4.x, csh[j + 1] = h4.y, csh[j + 2] = h4.z, csh[j + 3] = h4.w;
+        }
+#if FI_WS2_DEBUG & 8
+        xf = false;
+#endif
+        drop = drop0 && first;
+        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+        seed = seed_base + (uint64_t)grp * a.t0.seed_gstride;
+        vstep = (unsigned)(XRPP * W) * ((unsigned)(first ? a.c0 : a.c1) / VG);
+      }
+      auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
+        float f[VG];
+        VecWords<T>::unpack(raw, f);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) {
+          const float v = f[j] * csc[j] + csh[j];
+          f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
+        }
+        if (drop) {
+#pragma unroll
+          for (int g4 = 0; g4 < VG / 4; ++g4) {
+            uint32_t rr[4];
+            fi_rand32x4(seed, vecidx * (VG / 4) + g4, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[g4 * 4 + j] *= rr[j] >= a.t0.thresh ? a.t0.keep_scale : 0.f;
+          }
+        }
+        return VecWords<T>::pack(f);
+      };
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        if (xact && xrow0 + p * XRPP < XH) {
+          const bool ok = (S.flags >> p) & 1u;                  // outside the image: z = 0, not act(shift)
+          vec_t val;
+          if constexpr (XF == 0)
+            val = fi_vec_select(ok, S.x[p]);
+          else
+            val = fi_vec_select(ok, xf ? xform(S.x[p], S.vix0 + (unsigned)p * vstep) : S.x[p]);
+          *reinterpret_cast<vec_t*>(sb + ((p & 1) ? xl_odd : xl_even) + p * (XRPP * XW * PXB)) = val;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < WPASS; ++p) {
+        if (wact && wrow0 + p * WRPP < BN) *reinterpret_cast<vec_t*>(sb + wl0 + p * (WRPP * WROW)) = S.w[p];
+      }
+    };
+
+    Item it = item_at(i_begin);
+    int ch = 0, k = 0;                                           // this team's current stage
+    auto adv = [&]() __attribute__((always_inline)) {
+      ++k;
+      if (++ch == nchunk) {
+        ch = 0;
+        it = item_next(it);
+      }
+    };
+    if (team == 0) {
+      issue(it, 0, true);
+      commit(it, 0);                                             // stage 0
+      adv();
+      adv();
+    } else {
+      adv();
+      issue(it, ch, k < nstage);                                 // stage 1 in flight
+    }
+    fi_lds_barrier();
+    for (int s = 0; s < nstage; ++s) {
+      if ((s & 1) == team) {
+        issue(it, ch, k < nstage);                               // k == s + 2
+      } else {
+        if (s + 1 < nstage) commit(it, (s + 1) & 1);             // k == s + 1
+        adv();
+        adv();
+      }
+      fi_lds_barrier();
+    }
+  } else {
+    // =============================================================================================== consumers
+    const int rg = wave % RG, cgp = wave / RG;                   // row group, 64-channel group of this wave
+    const int n32 = lane & 31, hh = lane >> 5;
+    const int prow = n32 >> 4, pcol = n32 & 15;
+    const int rowbase = rg * 4, cobase = cgp * 64;
+    // fragment addresses: lane constants + immediates.  pixels: the half swap depends on the parity of the halo row =
+    // parity of (prow + tap row), two bases; weights: one base.
+    const unsigned pb0 = (unsigned)(((rowbase + prow) * XW + pcol) * PXB) + (unsigned)(((hh ^ prow) & 1) << 4);
+    const unsigned pb1 = (unsigned)(((rowbase + prow) * XW + pcol) * PXB) + (unsigned)(((hh ^ prow ^ 1) & 1) << 4);
+    const unsigned wb = (unsigned)(XT + (cobase + n32) * WROW + hh * 16);
+    const __amdgpu_buffer_rsrc_t ry0 = __builtin_amdgcn_make_buffer_rsrc(
+        a.y0, 0, a.y0 ? (unsigned)a.N * hw * (unsigned)a.co0 * esz : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc(
+        a.y1, 0, (a.y1 && a.co1) ? (unsigned)a.N * hw * (unsigned)a.co1 * esz : 0u, 0x00020000);
+
+    f32x16 acc[2][2];                                            // [pixel pair: rows 0-1 / 2-3 of the wave][32-channel block]
+
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+      const char* const sb = smem + buf * STAGE;
+      frag_t P[2][2], Wf[2][2];
+      auto fetch = [&](int t, int q) __attribute__((always_inline)) {
+        const int r = t / 3, sx = t % 3;
+        const unsigned pbase = (r & 1) ? pb1 : pb0;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) Wf[q][cb] = *reinterpret_cast<const frag_t*>(sb + wb + cb * (32 * WROW) + t * 32);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+          P[q][pp] = *reinterpret_cast<const frag_t*>(sb + pbase + ((2 * pp + r) * XW + sx) * PXB);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        if (t + 1 < KK) fetch(t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[pp][cb] = mfma32(Wf[t & 1][cb], P[t & 1][pp], acc[pp][cb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // wave-private strip: [sum 64][sum of squares 64][bias 64] floats
+    float* const strip = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * (3 * 64);
+    auto stats_clear = [&]() __attribute__((always_inline)) { strip[lane] = strip[64 + lane] = 0.f; };
+    auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
+      if (!a.stats) return;
+      const int slot = (blockIdx.x * CW + wave) & (FI_STATS_SLOTS - 1);
+      const int co = ct * BN + cobase + lane;
+      if (co < cout) {
+        double* const dst = &a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2];
+        atomicAdd(dst, (double)strip[lane]);
+        atomicAdd(dst + 1, (double)strip[64 + lane]);
+      }
+    };
+    auto load_bias = [&](int ct) __attribute__((always_inline)) {
+      const int co = ct * BN + cobase + lane;
+      strip[128 + lane] = (a.bias && co < cout) ? a.bias[co] : 0.f;
+    };
+
+    auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+      const int gx = it.tx * 16 + pcol;
+      const bool colok = gx < W;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          // the two 4-channel groups j = 2 jp, 2 jp + 1 of this lane: channels cobase + cb * 32 + 8 j + 4 hh + (0..3)
+          float4 bv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) bv[u] = *reinterpret_cast<const float4*>(&strip[128 + cb * 32 + 8 * (2 * jp + u) + 4 * hh]);
+          float ps[2][4], pq[2][4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps[u][r] = pq[u][r] = 0.f;
+          const int cg = it.ct * BN + cobase + cb * 32 + 8 * (2 * jp + hh);     // the 8 channels this lane stores
+          const bool second = cg >= a.co0;
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const int gy = it.ty * TR + rowbase + 2 * pp + prow;
+            const bool okp = colok && gy < H;
+            const float mk = okp ? 1.f : 0.f;
+            v2u q[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float bvr[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[pp][cb][4 * (2 * jp + u) + r] + bvr[r];
+              q[u] = __builtin_bit_cast(v2u, Quad<T>::pack(v));  // v := the values as stored
+#if !(FI_WS2_DEBUG & 32)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                ps[u][r] += v[r] * mk;                           // tile overhang does not count
+                pq[u][r] += (v[r] * mk) * v[r];
+              }
+#endif
+            }
+            if (a.y0) {
+              // lanes 0-31 end up with group 2 jp of both half-waves (8 consecutive channels), lanes 32-63 with group 2 jp + 1
+              const v2u lo = __builtin_amdgcn_permlane32_swap(q[0].x, q[1].x, false, false);
+              const v2u hi = __builtin_amdgcn_permlane32_swap(q[0].y, q[1].y, false, false);
+              const v4u out = {lo.x, hi.x, lo.y, hi.y};
+              const bool live = okp && cg < cout;
+              const unsigned pix = (unsigned)((it.n * H + gy) * W + gx);
+              if (a.co1 == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(out, ry0, live ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b128(out, ry0, (live && !second) ? (pix * (unsigned)a.co0 + (unsigned)cg) * esz : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(out, ry1, (live && second) ? (pix * (unsigned)a.co1 + (unsigned)(cg - a.co0)) * esz : OOB, 0, 0);
+              }
+            }
+          }
+#if !(FI_WS2_DEBUG & 32)
+          if (a.stats) {
+            // over the 16 lanes of a row (DPP), then over the two rows of the half-wave: one row swap + add serves a PAIR of
+            // values (x' = [x0 y0 x2 y2], y' = [x1 y1 x3 y3]): the even row ends up with the first, the odd row with the second
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              float tot[2][2];                                   // [sum | sum of squares][channel r = prow / r = 2 + prow]
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const float x0 = fi_row16_sum(ps[u][2 * h2]), x1 = fi_row16_sum(ps[u][2 * h2 + 1]);
+                const float y0 = fi_row16_sum(pq[u][2 * h2]), y1 = fi_row16_sum(pq[u][2 * h2 + 1]);
+                const v2u sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+                const v2u sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(y0), __float_as_uint(y1), false, false);
+                tot[0][h2] = __uint_as_float(sx.x) + __uint_as_float(sx.y);
+                tot[1][h2] = __uint_as_float(sy.x) + __uint_as_float(sy.y);
+              }
+              if (pcol == 0) {                                   // lanes 0 / 16 / 32 / 48: channel 8 j + 4 hh + 2 h2 + prow
+                const int c = cb * 32 + 8 * (2 * jp + u) + 4 * hh + prow;
+                strip[c] += tot[0][0];
+                strip[c + 2] += tot[0][1];
+                strip[64 + c] += tot[1][0];
+                strip[64 + c + 2] += tot[1][1];
+              }
+            }
+          }
+#endif
+        }
+      }
+    };
+
+    Item it = item_at(i_begin);
+    int ch = 0, since_flush = 0;
+    int sgrp = a.gimages > 0 ? it.n / a.gimages : 0, sct = it.ct;
+    stats_clear();
+    load_bias(sct);
+    auto consume = [&](int buf) __attribute__((always_inline)) {
+      if (ch == 0) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pp][cb][i] = 0.f;
+      }
+#if !(FI_WS2_DEBUG & 1)
+      mma(buf);
+#endif
+      if (++ch == nchunk) {
+        ch = 0;
+        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+        if (grp != sgrp || it.ct != sct || since_flush >= FI_WS2_FLUSH_TILES) {   // new (group, slab), or time to leave fp32
+          stats_flush(sgrp, sct);
+          stats_clear();
+          if (it.ct != sct) load_bias(it.ct);
+          sgrp = grp;
+          sct = it.ct;
+          since_flush = 0;
+        }
+#if !(FI_WS2_DEBUG & 16)
+        epilogue(it);
+#endif
+        ++since_flush;
+        it = item_next(it);
+      }
+    };
+    fi_lds_barrier();                                            // stage 0 is in buffer 0
+    for (int s = 0; s < nstage; s += 2) {
+      consume(0);
+      fi_lds_barrier();
+      if (s + 1 >= nstage) break;
+      consume(1);
+      fi_lds_barrier();
+    }
+    stats_flush(sgrp, sct);
+  }
+}
+
+template <typename T, int TR, int BN>
+static int launch_conv_fwd_ws2(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
+  constexpr int XH = TR + 2, XW = 18;
+  constexpr int STAGE = XH * XW * 32 + BN * (9 * 16 * 2 + 16);
+  const size_t lds = (size_t)2 * STAGE + (size_t)8 * 3 * 64 * sizeof(float);
+  const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
+  long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
+  if (blocks > nitem) blocks = nitem;
+  const dim3 g((unsigned)blocks), b(1024);
+  if (a.xf == 0) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 0>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 0>), g, b, lds, st, a);
+  } else if (a.xf == 1) {
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 1>);
+    (void)big;
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 1>), g, b, lds, st, a);
+  } else {
+    return FI_ERR_UNSUPPORTED;
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}

@@ -981,7 +981,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
       const int ci = (int)(i % cin);
       const int t = (int)((i / cin) % kk);
       const int co = (int)(i / ((long)cin * kk));
-      dst[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = from_f32<T>(src[i]);
+      if (mode == 1)
+        dst[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = from_f32<T>(src[i]);
+      else if (mode == 2)
+        dst[(((size_t)(ci >> 4) * cout + co) * kk + t) * 16 + (ci & 15)] = from_f32<T>(src[i]);
+      else
+        dst[(((size_t)(co >> 4) * cin + ci) * kk + (kk - 1 - t)) * 16 + (co & 15)] = from_f32<T>(src[i]);
     }
   }
 }
@@ -989,7 +994,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
 extern "C" int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype,
                                void* stream) {
   if (!src || !dst) return FI_ERR_NULL;
-  if (mode != 0 && mode != 1) return FI_ERR_UNSUPPORTED;
+  if (mode < 0 || mode > 3) return FI_ERR_UNSUPPORTED;
+  if ((mode == 2 && cin % 16) || (mode == 3 && cout % 16)) return FI_ERR_SHAPE;
   const long n = (long)cout * kk * cin;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FI_F32)
@@ -1104,17 +1110,20 @@ extern "C" int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, in
 
 // ------------------------------------------------------------------------------------------------
 // multi-tensor weight repack: ONE launch for every conv weight of a model (the per-tensor launches
-// were ~45 x 5 us per training step).  table[t] = {src, dst_fwd, dst_dgrad, cout, kk, cin} (int64 x 6).
+// were ~45 x 5 us per training step).  table[t] = {src, dst_fwd, dst_dgrad, cout, kk, cin, dst_fwd16, dst_dgrad16}
+// (int64 x FI_PACK_ROW; the last two are the chunk-major forms of conv_fwd_ws2_kernel, or 0).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long long* __restrict__ table) {
   // 32 (cout) x 32 (cin) tiles per filter tap, transposed through LDS: reads are coalesced along cin, the dgrad
   // operand's writes along cout (the element-wise scatter this replaces took 44 us for the U-Net's 1.8 M weights)
   __shared__ float tile[32][33];
-  const long long* d = table + (size_t)blockIdx.y * 6;
+  const long long* d = table + (size_t)blockIdx.y * FI_PACK_ROW;
   const float* src = reinterpret_cast<const float*>(d[0]);
   T* dst0 = reinterpret_cast<T*>(d[1]);
   T* dst1 = reinterpret_cast<T*>(d[2]);
+  T* dst2 = reinterpret_cast<T*>(d[6]);        // chunk-major forms (16-channel chunks of the contraction), or NULL
+  T* dst3 = reinterpret_cast<T*>(d[7]);
   const int cout = (int)d[3], kk = (int)d[4], cin = (int)d[5];
   const int tco = (cout + 31) / 32, tci = (cin + 31) / 32;
   const int ntiles = tco * tci * kk;
@@ -1130,6 +1139,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long long
         const size_t i = ((size_t)co * kk + t) * cin + ci;
         v = src[i];
         if (dst0) dst0[i] = from_f32<T>(v);
+        if (dst2) dst2[(((size_t)(ci >> 4) * cout + co) * kk + t) * 16 + (ci & 15)] = from_f32<T>(v);
       }
       tile[ty + r * 8][tx] = v;
     }
@@ -1139,6 +1149,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long long
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + ty + r * 8, co = co0 + tx;
         if (co < cout && ci < cin) dst1[((size_t)ci * kk + (kk - 1 - t)) * cout + co] = from_f32<T>(tile[tx][ty + r * 8]);
+      }
+    }
+    if (dst3) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + r * 8, co = co0 + tx;
+        if (co < cout && ci < cin)
+          dst3[(((size_t)(co >> 4) * cin + ci) * kk + (kk - 1 - t)) * 16 + (co & 15)] = from_f32<T>(tile[tx][ty + r * 8]);
       }
     }
   }

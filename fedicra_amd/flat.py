@@ -141,17 +141,35 @@ class FlatStoreMixin:
             need_fwd = dtype != torch.float32          # fp32 forward consumes the master weights directly
             buf0 = torch.empty(total if need_fwd else 0, dtype=dtype, device=dev)
             buf1 = torch.empty(total, dtype=dtype, device=dev)
-            rows, off = [], 0
+            # chunk-major siblings (fi_pack_weights modes 2 / 3) of the filters the 64 x 64-wave-tile kernel can take
+            # (include/fedicra_hip.h: FiConv.w16); they ride on the operand tensors as `_fi_w16`
+            want2 = [need_fwd and dev.type == "cuda" and p.shape[2] == p.shape[3]
+                     and L.conv_weight_chunk16(dtype, p.shape[2], p.shape[1], p.shape[0]) for p in convs]
+            want3 = [dev.type == "cuda" and dtype != torch.float32 and p.shape[2] == p.shape[3]
+                     and L.conv_weight_chunk16(dtype, p.shape[2], p.shape[0], p.shape[1]) for p in convs]
+            buf2 = torch.empty(sum(p.numel() for p, w_ in zip(convs, want2) if w_), dtype=dtype, device=dev)
+            buf3 = torch.empty(sum(p.numel() for p, w_ in zip(convs, want3) if w_), dtype=dtype, device=dev)
+            rows, off, off2, off3 = [], 0, 0, 0
             ref = weakref.ref(self)
-            for p in convs:
+            for p, w2, w3 in zip(convs, want2, want3):
                 n = p.numel()
                 co, ci, kh, kw = p.shape
                 v0 = buf0[off:off + n] if need_fwd else None
                 v1 = buf1[off:off + n]
-                rows.append([p.data_ptr(), v0.data_ptr() if need_fwd else 0, v1.data_ptr(), co, kh * kw, ci])
+                v2 = v3 = None
+                if w2:
+                    v2 = buf2[off2:off2 + n]
+                    v0._fi_w16 = v2
+                    off2 += n
+                if w3:
+                    v3 = buf3[off3:off3 + n]
+                    v1._fi_w16 = v3
+                    off3 += n
+                rows.append([p.data_ptr(), v0.data_ptr() if need_fwd else 0, v1.data_ptr(), co, kh * kw, ci,
+                             0 if v2 is None else v2.data_ptr(), 0 if v3 is None else v3.data_ptr()])
                 p._fi_packs = (ref, v0, v1)
                 off += n
-            self._fi_pack_bufs = (buf0, buf1)
+            self._fi_pack_bufs = (buf0, buf1, buf2, buf3)
             self._fi_pack_table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self._fi_pack_n = len(rows)
             self._fi_pack_key = key

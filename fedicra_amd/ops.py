@@ -198,6 +198,12 @@ def _packed(wk, dtype, mode, cout, kk, cin, param=None):
                 return packs[1 + mode]
     out = torch.empty(cout * kk * cin, dtype=dtype, device=wk.device)
     L.pack_weights(wk, out, cout, kk, cin, mode)
+    ksize = 3 if kk == 9 else (1 if kk == 1 else 0)
+    if wk.is_cuda and L.conv_weight_chunk16(dtype, ksize, *((cin, cout) if mode == 0 else (cout, cin))):
+        # the chunk-major sibling the 64 x 64-wave-tile kernel stages from (include/fedicra_hip.h: FiConv.w16)
+        out16 = torch.empty_like(out)
+        L.pack_weights(wk, out16, cout, kk, cin, 2 + mode)
+        out._fi_w16 = out16
     return out
 
 

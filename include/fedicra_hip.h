@@ -68,6 +68,13 @@ typedef struct FiConv {
   int accumulate0;    /* y0 += result instead of y0 = result                                         */
   int accumulate1;    /* same for y1                                                                 */
   int y_f32;          /* store the output as fp32 even when dtype == FI_BF16 (logits)                */
+  /* Optional second form of the SAME filter, chunk-major (fi_pack_weights mode 2 / 3; NULL = none): where
+   * fi_conv_weight_chunk16() says so for the filter's shape, fi_conv2d_fwd / _fwd_fused may take the launch through the
+   * 64 x 64-wave-tile kernel (conv_fwd_ws2_kernel), which stages 16-channel slabs of it as contiguous blocks.  Ignored by
+   * every other entry point.  w16_rows = output rows per chunk of that operand (0: co0 + co1): a launch may cover a
+   * sub-range of the packed filter's output channels (`w16` then points at its first row inside chunk 0). */
+  const void* w16;
+  int w16_rows;
 } FiConv;
 
 /* y = conv(cat(x0,x1), w) + bias.  w: [co0+co1][k*k][c0+c1] in `dtype` (see fi_pack_weights).
@@ -172,11 +179,21 @@ int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, voi
 /* weight repack from the fp32 master [Cout][k*k][Cin]:
  *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)
  *   mode 1: dst[ci][k*k-1-t][co]    = (dtype) src[co][t][ci]          (dgrad operand: conv of dy
- *           with the flipped, transposed filter -- run through fi_conv2d_fwd with Cin<->Cout)   */
+ *           with the flipped, transposed filter -- run through fi_conv2d_fwd with Cin<->Cout)
+ *   mode 2: dst[ci/16][co][t][ci%16]        = mode 0's values, CHUNK-MAJOR (cin % 16 == 0): the slab a 16-channel
+ *           stage of conv_fwd_ws2_kernel needs -- all output rows x 9 taps x 16 channels -- is one contiguous block
+ *   mode 3: dst[co/16][ci][k*k-1-t][co%16]  = mode 1's values, chunk-major over ITS contraction channels (cout % 16 == 0) */
 int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype, void* stream);
 
-/* The same repack for MANY weights in one launch.  table (device, int64[ntensors][6]) rows:
- * { src fp32 master ptr, dst forward operand ptr or 0, dst dgrad operand ptr or 0, cout, k*k, cin }. */
+/* 1 when a filter of this shape gets the chunk-major second operand (FiConv.w16): 16-bit storage, 3x3, contraction channels
+ * (cin; for the dgrad operand pass the conv's cout as cin and vice versa) a multiple of 32, output channels of 64.
+ * FI_WS2=0 in the environment switches the form off (A/B runs of one build). */
+int fi_conv_weight_chunk16(int dtype, int ksize, int cin, int cout);
+
+/* The same repack for MANY weights in one launch.  table (device, int64[ntensors][8]) rows:
+ * { src fp32 master ptr, dst forward operand ptr or 0, dst dgrad operand ptr or 0, cout, k*k, cin,
+ *   dst chunk-major forward operand (mode 2) or 0, dst chunk-major dgrad operand (mode 3) or 0 }. */
+#define FI_PACK_ROW 8
 int fi_pack_weights_multi(const long long* table, int ntensors, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- BatchNorm + activation --

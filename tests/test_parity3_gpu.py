@@ -113,7 +113,7 @@ def test_fused_adamw_frozen_parameter_semantics_against_torch_adamw(frozen):
             topt.step()
             torch.cuda.synchronize()
             worst = max(float((params[n].detach().cpu() - ref[n].detach()).abs().max()) for n in names)
-            assert worst < 2e-7, (frozen, rnd, it, worst)
+            assert worst < 1e-6, (frozen, rnd, it, worst)                     # fp32 round-off of 10 steps; the two semantics differ by ~1e-4
     if frozen == "torch1":
         # the two semantics really differ on this schedule: the body decayed during the head phase of round 2
         assert len(opt._ever) == len(names)
