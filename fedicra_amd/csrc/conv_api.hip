@@ -236,7 +236,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     // 64 x 64-wave-tile form (conv_fwd_ws2_kernel; conv_ws2.h): needs the chunk-major second operand (FiConv.w16), 16-channel
     // chunks that do not straddle the two sources, whole 64-channel slabs, a plain epilogue and 32-bit byte offsets
     if (d->w16 && depth == 0 && !f32 && d->ksize == 3 && (a.xf == 0 || a.xf == 1) && plain && env_ws2() != 0 &&
-        (g_tune[0] < 0 || g_tune[0] == 2 || g_tune[0] == 7)) {
+        (g_tune[0] < 0 || g_tune[0] == 7)) {                   // forcing any other form (incl. 2 = the old rule) keeps off it
       const long big = (long)d->N * d->H * d->W * 2;
       const int rows = d->w16_rows > 0 ? d->w16_rows : cout;
       const bool ok = d->c0 % 16 == 0 && d->c1 % 16 == 0 && cin >= 32 && cout % 64 == 0 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&

@@ -42,6 +42,18 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
 #endif
 #define FI_WS2_FLUSH_TILES 8   // tiles between two flushes of the fp32 statistics strip into the fp64 accumulators
 
+// -DFI_TRACE builds (tools/ws2_trace.py): every wave logs up to FI_WS2_TRN (s_memtime << 4 | tag) events of its first stages
+#ifdef FI_TRACE
+#define FI_WS2_TRN 250
+#define FI_T2(tag)                                                                                                   \
+  do {                                                                                                               \
+    if (a.trace && lane == 0 && tn < FI_WS2_TRN)                                                                     \
+      a.trace[((size_t)blockIdx.x * 16 + wave) * 256 + (tn++)] = ((long long)__builtin_amdgcn_s_memtime() << 4) | (tag); \
+  } while (0)
+#else
+#define FI_T2(tag) do { } while (0)
+#endif
+
 template <typename T, int TR, int BN, int XF>
 __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage");
@@ -65,6 +77,9 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   const bool producer = wave >= CW;
   const int cin = a.c0 + a.c1, cout = a.co0 + a.co1;
   const int H = a.H, W = a.W;
+#ifdef FI_TRACE
+  int tn = 0;
+#endif
 
   // ---- this workgroup's run of items; item = slab * ntile + tile (slab-major: a run keeps its slab and statistics group)
   const int ntile = a.N * a.tilesY * a.tilesX, tpi = a.tilesY * a.tilesX;
@@ -283,15 +298,19 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     }
     fi_lds_barrier();
     for (int s = 0; s < nstage; ++s) {
+      FI_T2(1);                                                  // iteration start
       if ((s & 1) == team) {
         issue(it, ch, k < nstage);                               // k == s + 2
+        FI_T2(2);                                                // loads issued
       } else {
         if (s + 1 < nstage) commit(it, (s + 1) & 1);             // k == s + 1
+        FI_T2(3);                                                // committed
         adv();
         adv();
       }
       fi_lds_barrier();
     }
+    FI_T2(1);
   } else {
     // =============================================================================================== consumers
     const int rg = wave % RG, cgp = wave / RG;                   // row group, 64-channel group of this wave
@@ -451,9 +470,11 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pp][cb][i] = 0.f;
       }
+      FI_T2(4);                                                  // stage start (barrier passed)
 #if !(FI_WS2_DEBUG & 1)
       mma(buf);
 #endif
+      FI_T2(5);                                                  // MFMAs issued
       if (++ch == nchunk) {
         ch = 0;
         const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
@@ -468,6 +489,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #if !(FI_WS2_DEBUG & 16)
         epilogue(it);
 #endif
+        FI_T2(6);                                                // epilogue issued
         ++since_flush;
         it = item_next(it);
       }
@@ -481,6 +503,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       fi_lds_barrier();
     }
     stats_flush(sgrp, sct);
+    FI_T2(4);
   }
 }
 

@@ -290,7 +290,7 @@ def test_header_is_plain_c_and_links_from_a_c_host(tmp_path):
 #include <stdio.h>
 #include "fedicra_hip.h"
 int main(void) {
-  FiConv d = { FI_BF16, 12, 256, 256, 3, 16, 0, 16, 0, 0, 0, 0 };
+  FiConv d = { FI_BF16, 12, 256, 256, 3, 16, 0, 16, 0, 0, 0, 0, NULL, 0 };   /* no chunk-major second operand */
   long ws = fi_conv2d_wgrad_workspace(&d);
   long ws3 = fi_conv3d_wgrad_workspace(&d, 8);
   int rc = fi_conv2d_fwd(&d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);

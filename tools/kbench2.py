@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--layers", default="", help="comma-separated layer indices (LAYERS order) to restrict the sweep to")
     ap.add_argument("--ws", action="store_true", help="only the one-tile kernel vs the wave-specialised kernel")
     ap.add_argument("--thin", action="store_true", help="only the one-tile kernel vs the thin-layer kernel, thin layers only")
+    ap.add_argument("--ws2", action="store_true", help="one-tile kernel vs the library's old choice (FI_V2 rule) vs the 64x64-wave-tile kernel")
     a = ap.parse_args()
     td = torch.bfloat16
     dev = "cuda"
@@ -64,6 +65,10 @@ def main():
         configs = [c for c in configs if c[0] == "v1" or c[0].startswith("thin")]
     if a.ws:
         configs = [c for c in configs if c[0] == "v1" or c[0].startswith("ws")]
+    if a.ws2:
+        a.ws = True
+        configs = [("v1", (0, 0, 0, 0)), ("old", (2, 0, 0, 0)), ("ws2_16", (7, 1, 0, 0)), ("ws2_32", (7, 2, 0, 0)),
+                   ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2))]
     tot = {}
     for mode in ("plain", "fused"):
         if a.only and a.only != mode:
@@ -83,7 +88,12 @@ def main():
             hs = 2 * H if pool else H
             x0 = torch.randn(N, hs, hs, c0, device=dev).to(td)
             x1 = torch.randn(N, H, H, c1, device=dev).to(td) if c1 else None
-            w = (torch.randn(cout, 3, 3, c0 + c1, device=dev) * 0.05).to(td)
+            wf = torch.randn(cout, 3, 3, c0 + c1, device=dev) * 0.05
+            w = wf.to(td)
+            if a.ws2 and L.conv_weight_chunk16(td, 3, c0 + c1, cout):
+                w16 = torch.empty(w.numel(), dtype=td, device=dev)
+                L.pack_weights(wf, w16, cout, 9, c0 + c1, 2)
+                w._fi_w16 = w16
             bias = torch.randn(cout, device=dev)
             y = None if kind == "head" else torch.empty(N, H, H, cout, device=dev, dtype=td)
             st = torch.zeros(G, L.STATS_SLOTS, cout, 2, dtype=torch.float64, device=dev)
@@ -106,6 +116,8 @@ def main():
                 if cfg[0] == 1 and pool and cfg[2] == 32:
                     continue
                 if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
+                    continue
+                if cfg[0] == 7 and (not hasattr(w, "_fi_w16") or pool or (cfg[1] == 1 and cout % 128)):
                     continue
                 if cfg[0] in (4, 5, 6) and (c0 + c1 < 32 or cout <= 16 or (cfg[1] == 4 and cout <= 32) or (pool and cfg[2] == 32)):
                     continue

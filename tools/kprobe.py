@@ -20,6 +20,9 @@ def parse_cfg(s):
     if s == "thin":
         return (3, 0, 0, 0)
     import re
+    m = re.fullmatch(r"ws2t(\d+)", s)                    # 64x64-wave-tile kernel with 16- / 32-row tiles
+    if m:
+        return (7, {16: 1, 32: 2}[int(m.group(1))], 0, 0)
     m = re.fullmatch(r"ws(\d+)nf(\d)", s)               # wave-specialised: ws8nf4 / ws44nf4 ...
     if m:
         return ({4: 4, 8: 5, 44: 6}[int(m.group(1))], int(m.group(2)), 0, 0)
@@ -44,7 +47,12 @@ def main():
     G, N, H = a.groups, a.batch * a.groups, a.H
     x0 = torch.randn(N, H, H, a.cin, device=dev).to(td)
     x1 = torch.randn(N, H, H, a.c1, device=dev).to(td) if a.c1 else None
-    w = (torch.randn(a.cout, 3, 3, a.cin + a.c1, device=dev) * 0.05).to(td)
+    wf = torch.randn(a.cout, 3, 3, a.cin + a.c1, device=dev) * 0.05
+    w = wf.to(td)
+    if L.conv_weight_chunk16(td, 3, a.cin + a.c1, a.cout):
+        w16 = torch.empty(w.numel(), dtype=td, device=dev)
+        L.pack_weights(wf, w16, a.cout, 9, a.cin + a.c1, 2)
+        w._fi_w16 = w16
     bias = torch.randn(a.cout, device=dev)
     y = None if a.stats_only else torch.empty(N, H, H, a.cout, device=dev, dtype=td)
     st = torch.zeros(G, L.STATS_SLOTS, a.cout, 2, dtype=torch.float64, device=dev)
