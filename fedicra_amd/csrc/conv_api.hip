@@ -239,20 +239,23 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
         (g_tune[0] < 0 || g_tune[0] == 7)) {                   // forcing any other form (incl. 2 = the old rule) keeps off it
       const long big = (long)d->N * d->H * d->W * 2;
       const int rows = d->w16_rows > 0 ? d->w16_rows : cout;
-      const bool ok = d->c0 % 16 == 0 && d->c1 % 16 == 0 && cin >= 32 && cout % 64 == 0 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&
-                      big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
-                      big * d->co1 < (1L << 32) && (long)rows * 9 * cin * 2 < (1L << 32);
-      // measured rule (FI_WS2 = 1): the batched fused launches and the plain launches the 32-pixel-tile form had
+      // pixel groups of 64 (16-row tiles) / 32 (32-row tiles) channels must not straddle the two sources
+      const bool ok32 = d->c0 % 32 == 0 && d->c1 % 32 == 0 && cin >= 32 && cout % 64 == 0 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&
+                        big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
+                        big * d->co1 < (1L << 32) && (long)rows * 9 * cin * 2 < (1L << 32);
+      const bool ok16 = ok32 && d->c0 % 64 == 0 && d->c1 % 64 == 0 && cout % 128 == 0;
+      // measured rule (FI_WS2 = 1; profiles/r03_*_kbench2_ws2*.txt): the batched fused launches that fill the persistent grid,
+      // 128-channel slabs with 64-channel pixel groups -- 1.05-1.16x the 32-pixel-tile form there (64^2 128->128 160 -> 145 us,
+      // 32^2 256->256 159 -> 137, head 887 -> 841); the 32-row x 64-channel shape and the 12-image launches measured level
+      // or behind and stay where they were
       const long tiles16 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
-      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || a.xf == 1 || cin >= 64;
-      if (ok && wanted) {
-        // 16-row tiles x 128 channels where the slab exists and the launch still has >= 2 items per CU, else 32 rows x 64
-        int tr = (cout % 128 == 0 && tiles16 * (cout / 128) >= 512) ? 16 : 32;
-        if (tr == 32 && d->H <= 16 && cout % 128 == 0) tr = 16;           // a 32-row tile would be half empty
+      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (a.xf == 1 && ok16 && tiles16 * (cout / 128) >= 1024);
+      if (ok32 && wanted) {
+        int tr = ok16 ? 16 : 32;
         static const long force_tr = env_long("FI_WS2_TR", 0);
-        if (force_tr == 16 && cout % 128 == 0) tr = 16;
+        if (force_tr == 16 && ok16) tr = 16;
         if (force_tr == 32) tr = 32;
-        if (g_tune[0] == 7 && g_tune[1] == 1 && cout % 128 == 0) tr = 16;   // fi_conv_tuning(7, 1 | 2, ...): 16- / 32-row tiles
+        if (g_tune[0] == 7 && g_tune[1] == 1 && ok16) tr = 16;             // fi_conv_tuning(7, 1 | 2, ...): 16- / 32-row tiles
         if (g_tune[0] == 7 && g_tune[1] == 2) tr = 32;
         a.w = d->w16;
         a.wrows = rows;

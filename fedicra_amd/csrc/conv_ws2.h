@@ -60,17 +60,20 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   static_assert((TR == 16 && BN == 128) || (TR == 32 && BN == 64), "8 consumer waves of 4 rows x 64 channels");
   static_assert(XF == 0 || XF == 1, "plain or transforming loader");
   constexpr int CW = 8, PT = 256;                                // consumer waves; threads of one producer team
-  constexpr int RG = TR / 4;                                     // row groups (the rest of the 8 waves split the channels)
+  constexpr int RG = TR / 4, CG = BN / 64;                       // consumer grid: row groups x 64-channel groups
   constexpr int XH = TR + 2, XW = 18, KK = 9, CK = 16, VG = 8;
-  constexpr int PXB = 32;                                        // bytes of a staged pixel (16 channels)
-  constexpr int WROW = KK * CK * 2 + 16;                         // bytes of a staged weight row: 288 + 16 (odd 16-byte units)
-  constexpr int XT = XH * XW * PXB, WT = BN * WROW, STAGE = XT + WT;      // bytes
+  constexpr int GC = TR == 16 ? 64 : 32;                         // channels of a pixel GROUP (what the loader fetches per pixel)
+  constexpr int NQ = GC / CK, NP = GC / VG;                      // stages per group; 16-byte pieces per staged pixel
+  constexpr int XG = XH * XW * NP * 16;                          // bytes of a group's halo tile
+  constexpr int WROW = KK * CK * 2, WT = BN * WROW;              // bytes of a staged weight row (288, unpadded) / slab
+  constexpr int O_W = 2 * XG, O_STRIP = 2 * XG + 2 * WT;         // LDS map: [2] pixel groups, [2] weight slabs, [CG] strips
+  static_assert(O_STRIP + CG * 192 * 4 <= 160 * 1024, "LDS");
   typedef typename DT<T>::vec_t vec_t;
   typedef typename DT<T>::frag_t frag_t;
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];    // [2]{ pixels[XH][XW][32 B], weights[BN][304 B] }, [8] strip[3 x 64] floats
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   const int per = (nitem + (int)gridDim.x - 1) / (int)gridDim.x;
   const int i_begin = (int)blockIdx.x * per, i_end = min(nitem, i_begin + per);
   if (i_begin >= i_end) return;
-  const int nchunk = cin / CK;
-  const int nstage = (i_end - i_begin) * nchunk;
+  const int nchunk = cin / CK, ngrp = cin / GC;
+  const int nstage = (i_end - i_begin) * nchunk, ngroups = (i_end - i_begin) * ngrp;
 
   constexpr unsigned esz = 2;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -121,39 +124,51 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     return c;
   };
 
+  // Every workgroup streams the SAME weight slabs at about the same time.  Rotating the order in which a tile walks its chunks
+  // by the tile's position (-DFI_WS2_ROT: groups by rot / NQ, the chunks inside a group by rot % NQ), so that workgroups on
+  // different tiles are on different slabs, was measured and is NOT a gain (tools/ws2_trace.py: plain 64^2 128->128 stage
+  // 3 484 -> 3 884 cycles, fused 4 960 -> 5 032): the L2 likes the lock step.  Left in as an A/B switch.
+#ifdef FI_WS2_ROT
+  auto rot_of = [&](const Item& c) { return (c.tx + 3 * c.ty) % nchunk; };
+#else
+  auto rot_of = [&](const Item&) { return 0; };
+#endif
+
   if (producer) {
     // =============================================================================================== producers
-    // Two teams of 4 waves; team g owns the stages of parity g and always writes LDS buffer g: while stage s is consumed, team
-    // (s & 1) issues the loads of stage s + 2 and the other team transforms / commits stage s + 1, so a load has a whole stage
-    // to land and the commit's vmcnt(0) is exact.  Loads are branch-free and fixed in number per stage (conv_fwd_ws_kernel).
+    // Two teams of 4 waves.  PACKAGE k = the weight slab of stage k + one of the NQ parts of the pixel group that stage
+    // k + NQ - 1 falls into (so that a group is complete one stage before its first use); team g owns the packages of parity
+    // g: while stage s is consumed, team (s & 1) issues the loads of package s + 2 and the other team transforms / commits
+    // package s + 1 -- a load has a whole stage to land and the commit's vmcnt(0) is exact.  Loads are branch-free and fixed
+    // in number per package (conv_fwd_ws_kernel).
     const int team = (wave - CW) >> 2;
     const int ptid = tid - CW * 64 - team * PT;
-    // pixels: a thread owns one 16-byte half of one pixel column, 7 halo rows apart (252 of the 256 threads)
-    constexpr int XCOLS = XW * 2, XRPP = PT / XCOLS, XPASS = (XH + XRPP - 1) / XRPP;
-    static_assert(XRPP == 7, "7 halo rows per pass");
-    const int xcol = ptid % XCOLS, xrow0 = ptid / XCOLS;
-    const int xpx = xcol >> 1, xh = xcol & 1;
-    const bool xact = xrow0 < XRPP;
-    // LDS byte offset of pass p: rows alternate parity from pass to pass (7 is odd), and so does the half swap
-    const unsigned xl_base = (unsigned)((xrow0 * XW + xpx) * PXB);
-    const unsigned xl_even = xl_base + (unsigned)(((xh ^ (xrow0 & 1)) & 1) << 4);
-    const unsigned xl_odd = xl_base + (unsigned)(((xh ^ (xrow0 & 1) ^ 1) & 1) << 4);
-    // weights: the slab of a stage is one contiguous block of BN rows x 18 vectors; a thread owns one vector column of a row,
-    // 14 rows apart (252 threads)
-    constexpr int WCOLS = KK * 2, WRPP = PT / WCOLS, WPASS = (BN + WRPP - 1) / WRPP;
-    static_assert(WRPP == 14, "14 weight rows per pass");
-    const int wcol = ptid % WCOLS, wrow0 = ptid / WCOLS;
-    const bool wact = wrow0 < WRPP;
-    const unsigned wl0 = (unsigned)(XT + wrow0 * WROW + wcol * 16);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.w), 0, (unsigned)nchunk * (unsigned)a.wrows * (KK * CK * esz), 0x00020000);
+#ifdef FI_WS2_PRIO
+    __builtin_amdgcn_s_setprio(FI_WS2_PRIO);                    // A/B: producers ahead of the (older) consumer waves at the issue port
+#endif
+    // pixels of a part: PLQ consecutive halo pixels x NP pieces; thread j takes vectors j, j + 256, ...: a wave covers whole
+    // 128-byte lines of the source, and a thread's piece (= its 8 channels within the group) never changes
+    constexpr int PLQ = XH * XW / NQ, XV = PLQ * NP, XPASS = (XV + PT - 1) / PT;
+    static_assert(PLQ * NQ == XH * XW && PT % NP == 0, "whole parts");
+    const int piece = ptid % NP;
+    constexpr int WV = BN * KK * 2, WPASS = (WV + PT - 1) / PT;    // weight slab: WV consecutive 16-byte vectors
+    // Every load goes through a buffer resource built from SCALARS: which source a group comes from and whether the package
+    // is live at all are uniform, and a uniform condition inside a per-lane select is what hipcc turns into a BRANCH around
+    // the load -- its (path-insensitive) wait-count bookkeeping then puts s_waitcnt vmcnt(0) between the loads of one package
+    // and they go out one memory round trip at a time (tools/ws2_trace.py: 4 300 cycles to issue 12 loads).  A dead package
+    // loads through a zero-length resource (the hardware returns zeros); only the per-lane conditions select the offset.
+    auto rsrc = [&](const void* ptr, unsigned bytes) __attribute__((always_inline)) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+    };
+    const unsigned wbytes = (unsigned)nchunk * (unsigned)a.wrows * (KK * CK * esz);
+    const unsigned xbytes0 = (unsigned)((XF != 0 && a.bcast0) ? a.gimages : a.N) * hw * (unsigned)a.c0 * esz;
+    const unsigned xbytes1 = (unsigned)a.N * hw * (unsigned)a.c1 * esz;
 
     struct Set {
       vec_t x[XPASS];
       vec_t w[WPASS];
-      unsigned cofs;            // element offset of this thread's coefficients, fetched at commit
+      float sc[XF != 0 ? VG : 1], sh[XF != 0 ? VG : 1];         // this thread's 8 scale / shift values (its piece of the group)
       unsigned flags;           // bit p: pass p is inside the image; bit 16: source 0; bit 17: transform active
-      unsigned vix0;            // dropout element-vector index of pass 0
     };
     Set S;
     const bool drop0 = XF == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM;
@@ -162,91 +177,110 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       seed_base = a.t0.seed;
       if (a.t0.seed_offset) seed_base += 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)a.t0.seed_offset[0];
     }
-    const T* const x0p = reinterpret_cast<const T*>(a.x0);
-    const T* const x1p = reinterpret_cast<const T*>(a.x1);
-    const float* const dummy = reinterpret_cast<const float*>(a.w);        // >= 32 readable bytes for inactive lanes
 
-    auto issue = [&](const Item& it, int chunk, bool live) __attribute__((always_inline)) {
+    // ---- pixel part q of the group `cg` of item `it`.  A thread's vectors are DPL halo pixels apart from pass to pass: (row,
+    // col) and the source offset advance by one of two per-part constants (no multiply, no division per vector).
+    constexpr int DPL = PT / NP, DR = DPL / XW, DC = DPL % XW;   // pixel-list step of a pass = DR rows + DC columns
+    auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+    auto issue_x = [&](const Item& it, int cg_, int q_, bool live_) __attribute__((always_inline)) {
 #if FI_WS2_DEBUG & 2
       return;
 #endif
-      const int ci = chunk * CK + xh * VG;                       // first channel of this thread's vector
-      const bool chok = live && xact;
-      const bool first = ci < a.c0;
-      const unsigned cs = (unsigned)(first ? a.c0 : a.c1), co = (unsigned)(first ? ci : ci - a.c0);
-      const T* const xb = first ? x0p : x1p;
-      const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
-      const int nl = it.n - grp * a.gimages;
-      const int ns = (XF != 0 && first && a.bcast0) ? nl : it.n;
-      const int gx = it.tx * 16 + xpx - 1;
-      const int gy0 = it.ty * TR + xrow0 - 1;
-      const bool colok = chok && (unsigned)gx < (unsigned)W;
+      // everything the buffer resource is made of is UNIFORM; say so, or hipcc wraps every load in a waterfall loop
+      const int cg = uni(cg_), q = uni(q_);
+      const bool live = uni(live_ ? 1 : 0) != 0;
+      const bool first = cg * GC < a.c0;                         // a group never straddles the two sources (host)
+      const unsigned cs = (unsigned)(first ? a.c0 : a.c1);
+      const unsigned co = (unsigned)(cg * GC - (first ? 0 : a.c0)) + (unsigned)(piece * VG);
+      const unsigned long long xptr = (unsigned long long)(first ? a.x0 : a.x1);
+      const __amdgpu_buffer_rsrc_t rx = rsrc(
+          reinterpret_cast<const void*>((unsigned long long)(unsigned)uni((int)(unsigned)xptr) |
+                                        ((unsigned long long)(unsigned)uni((int)(unsigned)(xptr >> 32)) << 32)),
+          (unsigned)uni((int)(live ? (first ? xbytes0 : xbytes1) : 0u)));
+      const int n = uni(it.n), ty = uni(it.ty), tx = uni(it.tx);
+      const int grp = a.gimages > 0 ? n / a.gimages : 0;
+      const int nl = n - grp * a.gimages;
+      const int ns = (XF != 0 && first && a.bcast0) ? nl : n;
       unsigned flags = first ? 0x10000u : 0u;
-      const unsigned o0 = (unsigned)((ns * H + gy0) * W + gx) * cs + co;
-      const unsigned step = (unsigned)(XRPP * W) * cs;
+      const int pl0 = q * PLQ + ptid / NP;
+      int row = pl0 / XW, col = pl0 - (pl0 / XW) * XW;
+      const unsigned pxb = cs * esz;                             // bytes of a source pixel
+      // byte offset of (row, col): ((ns H + ty TR - 1 + row) W + tx 16 - 1 + col) * pxb + co * 2
+      unsigned off = ((unsigned)((ns * H + ty * TR - 1 + row) * W + tx * 16 - 1 + col)) * pxb + co * esz;
+      const unsigned inc_a = (unsigned)(DR * W + DC) * pxb, inc_b = (unsigned)((DR + 1) * W + DC - XW) * pxb;
 #pragma unroll
       for (int p = 0; p < XPASS; ++p) {
-        const bool ok = colok && (unsigned)(gy0 + p * XRPP) < (unsigned)H && xrow0 + p * XRPP < XH;
+        const int gy = ty * TR + row - 1, gx = tx * 16 + col - 1;
+        const bool ok = ptid + p * PT < XV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;      // per lane
         flags |= ok ? (1u << p) : 0u;
-        S.x[p] = *reinterpret_cast<const vec_t*>(xb + (ok ? o0 + (unsigned)p * step : 0u));
-      }
-      {
-        // chunk-major operand: [chunk][wrows][9][16]; this slab starts at row it.ct * BN
-        const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(it.ct * BN + wrow0)) * (KK * 2) + (unsigned)wcol) * 16u;
-        const bool wok = live && wact;
-#pragma unroll
-        for (int p = 0; p < WPASS; ++p) {
-          const bool ok = wok && wrow0 + p * WRPP < BN;
-          S.w[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? o0w + (unsigned)(p * WRPP * KK * 2 * 16) : OOB, 0, 0));
-        }
+        S.x[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : OOB, 0, 0));
+        const bool wrap = col + DC >= XW;
+        row += wrap ? DR + 1 : DR;
+        col += wrap ? DC - XW : DC;
+        off += wrap ? inc_b : inc_a;
       }
       if constexpr (XF != 0) {
-        const float* scp = first ? a.t0.scale : a.t1.scale;
-        const bool act = chok && scp != nullptr;
+        const float* const scp = first ? a.t0.scale : a.t1.scale;
+        const float* const shp = first ? a.t0.shift : a.t1.shift;
+        const bool act = live && scp != nullptr;
         flags |= act ? 0x20000u : 0u;
-        S.cofs = act ? (unsigned)grp * cs + co : 0u;
-        S.vix0 = (unsigned)((nl * H + gy0) * W + gx) * (cs / VG) + co / VG;
+        const unsigned long long sp = (unsigned long long)scp, hp = (unsigned long long)shp;
+        const unsigned nrec = (unsigned)uni((int)(act ? 0x7FFFFFF0u : 0u));
+        const __amdgpu_buffer_rsrc_t rs = rsrc(reinterpret_cast<const void*>((unsigned long long)(unsigned)uni((int)(unsigned)sp) |
+                                                                             ((unsigned long long)(unsigned)uni((int)(unsigned)(sp >> 32)) << 32)), nrec);
+        const __amdgpu_buffer_rsrc_t rh = rsrc(reinterpret_cast<const void*>((unsigned long long)(unsigned)uni((int)(unsigned)hp) |
+                                                                             ((unsigned long long)(unsigned)uni((int)(unsigned)(hp >> 32)) << 32)), nrec);
+        const unsigned cofs = ((unsigned)grp * cs + co) * 4u;
+#pragma unroll
+        for (int j = 0; j < VG; j += 4) {
+          const float4 s4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, cofs + j * 4, 0, 0));
+          const float4 h4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, cofs + j * 4, 0, 0));
+          S.sc[j] = s4.x, S.sc[j + 1] = s4.y, S.sc[j + 2] = s4.z, S.sc[j + 3] = s4.w;
+          S.sh[j] = h4.x, S.sh[j + 1] = h4.y, S.sh[j + 2] = h4.z, S.sh[j + 3] = h4.w;
+        }
       }
       S.flags = flags;
     };
-
-    auto commit = [&](const Item& it, int buf) __attribute__((always_inline)) {
+    auto commit_x = [&](const Item& it, int cg_, int q_, int gbuf) __attribute__((always_inline)) {
 #if FI_WS2_DEBUG & 4
       return;
 #endif
-      char* const sb = smem + buf * STAGE;
+      const int cg = uni(cg_), q = uni(q_);
+      char* const xb = smem + gbuf * XG;
       const bool first = (S.flags & 0x10000u) != 0;
       float slope = 1.f;
       bool xf = false, drop = false;
       uint64_t seed = 0;
-      unsigned vstep = 0;
-      float csc[VG], csh[VG];                                   // this thread's 8 scale / shift values
+      unsigned cs8 = 0;
+      unsigned vix = 0;
+      const int pl0 = q * PLQ + ptid / NP;
+      int pl = pl0, col = pl0 - (pl0 / XW) * XW;
+      unsigned vinc_a = 0, vinc_b = 0;
       if constexpr (XF != 0) {
         slope = first ? a.t0.slope : a.t1.slope;
         xf = (S.flags & 0x20000u) != 0;
-        const float* const scp = xf ? (first ? a.t0.scale : a.t1.scale) : dummy;
-        const float* const shp = xf ? (first ? a.t0.shift : a.t1.shift) : dummy;
-#pragma unroll
-        for (int j = 0; j < VG; j += 4) {
-          const float4 s4 = *reinterpret_cast<const float4*>(scp + S.cofs + j);
-          const float4 h4 = *reinterpret_cast<const float4*>(shp + S.cofs + j);
-          csc[j] = s4.x, csc[j + 1] = s4.y, csc[j + 2] = s4.z, csc[j + 3] = s4.w;
-          csh[j] = h4.x, csh[j + 1] = h4.y, csh[j + 2] = h4.z, csh[j + 3] = h4.w;
-        }
 #if FI_WS2_DEBUG & 8
         xf = false;
 #endif
         drop = drop0 && first;
-        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+        const int n = uni(it.n), ty = uni(it.ty), tx = uni(it.tx);
+        const int grp = a.gimages > 0 ? n / a.gimages : 0;
+        const int nl = n - grp * a.gimages;
         seed = seed_base + (uint64_t)grp * a.t0.seed_gstride;
-        vstep = (unsigned)(XRPP * W) * ((unsigned)(first ? a.c0 : a.c1) / VG);
+        cs8 = (unsigned)(first ? a.c0 : a.c1) / VG;
+        const unsigned co8 = (unsigned)(cg * GC - (first ? 0 : a.c0)) / VG + (unsigned)piece;
+        const int row = pl0 / XW;
+        // dropout element-vector index of (row, col) inside the group's tensor, stepped like the source offset
+        vix = (unsigned)((nl * H + ty * TR - 1 + row) * W + tx * 16 - 1 + col) * cs8 + co8;
+        vinc_a = (unsigned)(DR * W + DC) * cs8;
+        vinc_b = (unsigned)((DR + 1) * W + DC - XW) * cs8;
       }
       auto xform = [&](const vec_t& raw, size_t vecidx) __attribute__((always_inline)) -> vec_t {
         float f[VG];
         VecWords<T>::unpack(raw, f);
 #pragma unroll
         for (int j = 0; j < VG; ++j) {
-          const float v = f[j] * csc[j] + csh[j];
+          const float v = f[j] * S.sc[j] + S.sh[j];
           f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
         }
         if (drop) {
@@ -262,48 +296,111 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       };
 #pragma unroll
       for (int p = 0; p < XPASS; ++p) {
-        if (xact && xrow0 + p * XRPP < XH) {
+        if (ptid + p * PT < XV) {
           const bool ok = (S.flags >> p) & 1u;                  // outside the image: z = 0, not act(shift)
           vec_t val;
           if constexpr (XF == 0)
             val = fi_vec_select(ok, S.x[p]);
           else
-            val = fi_vec_select(ok, xf ? xform(S.x[p], S.vix0 + (unsigned)p * vstep) : S.x[p]);
-          *reinterpret_cast<vec_t*>(sb + ((p & 1) ? xl_odd : xl_even) + p * (XRPP * XW * PXB)) = val;
+            val = fi_vec_select(ok, xf ? xform(S.x[p], vix) : S.x[p]);
+          // piece slot within the pixel: xor by the column pair -> the consumers' fragment reads are conflict-free
+          *reinterpret_cast<vec_t*>(xb + (pl * NP + (piece ^ ((col >> 1) & (NP - 1)))) * 16) = val;
         }
+        const bool wrap = col + DC >= XW;
+        pl += DPL;
+        col += wrap ? DC - XW : DC;
+        vix += wrap ? vinc_b : vinc_a;
       }
+    };
+    // ---- weight slab of chunk `chunk` (of the whole contraction) for the slab it.ct
+    auto issue_w = [&](const Item& it, int chunk, bool live) __attribute__((always_inline)) {
+#if FI_WS2_DEBUG & 2
+      return;
+#endif
+      // chunk-major operand: [chunk][wrows][9][16]: the slab is one contiguous block starting at row it.ct * BN
+      const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(it.ct * BN)) * (KK * 2) + (unsigned)ptid) * 16u;
+      const __amdgpu_buffer_rsrc_t rw = rsrc(a.w, (unsigned)__builtin_amdgcn_readfirstlane((int)(live ? wbytes : 0u)));
 #pragma unroll
       for (int p = 0; p < WPASS; ++p) {
-        if (wact && wrow0 + p * WRPP < BN) *reinterpret_cast<vec_t*>(sb + wl0 + p * (WRPP * WROW)) = S.w[p];
+        const bool ok = (p + 1) * PT <= WV || ptid + p * PT < WV;          // compile-time true except in a ragged last pass
+        S.w[p] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? o0w + (unsigned)(p * PT * 16) : OOB, 0, 0));
+      }
+    };
+    auto commit_w = [&](int buf) __attribute__((always_inline)) {
+#if FI_WS2_DEBUG & 4
+      return;
+#endif
+      char* const wb = smem + O_W + buf * WT;
+#pragma unroll
+      for (int p = 0; p < WPASS; ++p) {
+        const int v = ptid + p * PT;
+        if (v < WV) {
+          const int co = v / (KK * 2), q18 = v - co * (KK * 2);
+          // row of 288 bytes, no padding; the two 16-byte halves of a tap swap on rows 8..15 mod 16 (conflict-free reads)
+          *reinterpret_cast<vec_t*>(wb + co * WROW + (q18 >> 1) * 32 + ((((q18 & 1) ^ (co >> 3)) & 1) << 4)) = S.w[p];
+        }
       }
     };
 
-    Item it = item_at(i_begin);
-    int ch = 0, k = 0;                                           // this team's current stage
+    // package cursor: k = stage whose weights it carries; (gi, cgx, qx, itx) = pixel part of flat index k + NQ - 1
+    Item itw = item_at(i_begin), itx = itw;
+    int ch = 0, k = 0, gi = 0, cgx = 0, qx = NQ - 1;
     auto adv = [&]() __attribute__((always_inline)) {
       ++k;
       if (++ch == nchunk) {
         ch = 0;
-        it = item_next(it);
+        itw = item_next(itw);
+      }
+      if (++qx == NQ) {
+        qx = 0;
+        ++gi;
+        if (++cgx == ngrp) {
+          cgx = 0;
+          itx = item_next(itx);
+        }
       }
     };
+    // position -> rotated index: group position gp of item it is group (gp + rot / NQ) % ngrp; stage position j is chunk
+    // group(j / NQ) * NQ + (j % NQ + rot % NQ) % NQ
+    auto grp_of = [&](const Item& it, int gp) __attribute__((always_inline)) {
+      const int g = gp + rot_of(it) / NQ;
+      return g >= ngrp ? g - ngrp : g;
+    };
+    auto chunk_of = [&](const Item& it, int j) __attribute__((always_inline)) {
+      const int r = rot_of(it);
+      int i = j % NQ + r % NQ;
+      i = i >= NQ ? i - NQ : i;
+      return grp_of(it, j / NQ) * NQ + i;
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+      issue_x(itx, grp_of(itx, cgx), qx, gi < ngroups);
+      issue_w(itw, chunk_of(itw, ch), k < nstage);
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+      commit_x(itx, grp_of(itx, cgx), qx, gi & 1);
+      commit_w(k & 1);
+    };
     if (team == 0) {
-      issue(it, 0, true);
-      commit(it, 0);                                             // stage 0
+      issue();
+      commit();                                                  // package 0: slab 0 + the LAST part of group 0
       adv();
       adv();
     } else {
+      for (int q = 0; q < NQ - 1; ++q) {                         // the other parts of group 0 (once per run)
+        issue_x(itx, grp_of(itx, 0), q, true);
+        commit_x(itx, grp_of(itx, 0), q, 0);
+      }
       adv();
-      issue(it, ch, k < nstage);                                 // stage 1 in flight
+      issue();                                                   // package 1 in flight
     }
     fi_lds_barrier();
     for (int s = 0; s < nstage; ++s) {
       FI_T2(1);                                                  // iteration start
       if ((s & 1) == team) {
-        issue(it, ch, k < nstage);                               // k == s + 2
+        issue();                                                 // k == s + 2
         FI_T2(2);                                                // loads issued
       } else {
-        if (s + 1 < nstage) commit(it, (s + 1) & 1);             // k == s + 1
+        if (s + 1 < nstage) commit();                            // k == s + 1
         FI_T2(3);                                                // committed
         adv();
         adv();
@@ -317,11 +414,14 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     const int n32 = lane & 31, hh = lane >> 5;
     const int prow = n32 >> 4, pcol = n32 & 15;
     const int rowbase = rg * 4, cobase = cgp * 64;
-    // fragment addresses: lane constants + immediates.  pixels: the half swap depends on the parity of the halo row =
-    // parity of (prow + tap row), two bases; weights: one base.
-    const unsigned pb0 = (unsigned)(((rowbase + prow) * XW + pcol) * PXB) + (unsigned)(((hh ^ prow) & 1) << 4);
-    const unsigned pb1 = (unsigned)(((rowbase + prow) * XW + pcol) * PXB) + (unsigned)(((hh ^ prow ^ 1) & 1) << 4);
-    const unsigned wb = (unsigned)(XT + (cobase + n32) * WROW + hh * 16);
+    // fragment addresses: lane constants (+ the chunk's xor, + the group buffer) + immediates.
+    //   pixel (row, col), piece k = 2 * chunk + half:  ((row * 18 + col) * NP + (k ^ ((col >> 1) & (NP - 1)))) * 16
+    //   weight row co, tap t, half h:                  co * 288 + t * 32 + ((h ^ (co >> 3)) & 1) * 16
+    unsigned pre[3];
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx)
+      pre[sx] = (unsigned)((((rowbase + prow) * XW + pcol + sx) * NP + (hh ^ (((pcol + sx) >> 1) & (NP - 1)))) * 16);
+    const unsigned wb = (unsigned)(O_W + (cobase + n32) * WROW + (((hh ^ (n32 >> 3)) & 1) << 4));
     const __amdgpu_buffer_rsrc_t ry0 = __builtin_amdgcn_make_buffer_rsrc(
         a.y0, 0, a.y0 ? (unsigned)a.N * hw * (unsigned)a.co0 * esz : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -329,17 +429,19 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 
     f32x16 acc[2][2];                                            // [pixel pair: rows 0-1 / 2-3 of the wave][32-channel block]
 
-    auto mma = [&](int buf) __attribute__((always_inline)) {
-      const char* const sb = smem + buf * STAGE;
+    auto mma = [&](int wbuf, int gbuf, int cq) __attribute__((always_inline)) {
+      const char* const sw = smem + wbuf * WT;
+      unsigned px[3];
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) px[sx] = (pre[sx] ^ (unsigned)(cq << 5)) + (unsigned)(gbuf * XG);
       frag_t P[2][2], Wf[2][2];
       auto fetch = [&](int t, int q) __attribute__((always_inline)) {
         const int r = t / 3, sx = t % 3;
-        const unsigned pbase = (r & 1) ? pb1 : pb0;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) Wf[q][cb] = *reinterpret_cast<const frag_t*>(sb + wb + cb * (32 * WROW) + t * 32);
+        for (int cb = 0; cb < 2; ++cb) Wf[q][cb] = *reinterpret_cast<const frag_t*>(sw + wb + cb * (32 * WROW) + t * 32);
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
-          P[q][pp] = *reinterpret_cast<const frag_t*>(sb + pbase + ((2 * pp + r) * XW + sx) * PXB);
+          P[q][pp] = *reinterpret_cast<const frag_t*>(smem + px[sx] + (2 * pp + r) * (XW * NP * 16));
       };
       fetch(0, 0);
 #pragma unroll
@@ -354,12 +456,14 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       }
     };
 
-    // wave-private strip: [sum 64][sum of squares 64][bias 64] floats
-    float* const strip = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * (3 * 64);
+    // one strip per 64-channel group, shared by its row-group waves: [sum 64][sum of squares 64][bias 64] floats.  The waves
+    // ADD their per-tile totals (ds_add_f32); the row-group-0 wave clears / flushes it and loads the bias at the START of a
+    // tile -- at least one stage barrier away from the adds on either side (a tile has >= 2 stages).
+    float* const strip = reinterpret_cast<float*>(smem + O_STRIP) + cgp * 192;
     auto stats_clear = [&]() __attribute__((always_inline)) { strip[lane] = strip[64 + lane] = 0.f; };
     auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
       if (!a.stats) return;
-      const int slot = (blockIdx.x * CW + wave) & (FI_STATS_SLOTS - 1);
+      const int slot = (blockIdx.x * CG + cgp) & (FI_STATS_SLOTS - 1);
       const int co = ct * BN + cobase + lane;
       if (co < cout) {
         double* const dst = &a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2];
@@ -444,10 +548,10 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
               }
               if (pcol == 0) {                                   // lanes 0 / 16 / 32 / 48: channel 8 j + 4 hh + 2 h2 + prow
                 const int c = cb * 32 + 8 * (2 * jp + u) + 4 * hh + prow;
-                strip[c] += tot[0][0];
-                strip[c + 2] += tot[0][1];
-                strip[64 + c] += tot[1][0];
-                strip[64 + c + 2] += tot[1][1];
+                atomicAdd(&strip[c], tot[0][0]);
+                atomicAdd(&strip[c + 2], tot[0][1]);
+                atomicAdd(&strip[64 + c], tot[1][0]);
+                atomicAdd(&strip[64 + c + 2], tot[1][1]);
               }
             }
           }
@@ -457,11 +561,10 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     };
 
     Item it = item_at(i_begin);
-    int ch = 0, since_flush = 0;
-    int sgrp = a.gimages > 0 ? it.n / a.gimages : 0, sct = it.ct;
-    stats_clear();
-    load_bias(sct);
-    auto consume = [&](int buf) __attribute__((always_inline)) {
+    int ch = 0, cq = 0, gpar = 0, since_flush = 0;
+    int sgrp = -1, sct = -1;
+    auto consume = [&](int wbuf) __attribute__((always_inline)) {
+      FI_T2(4);                                                  // stage start (barrier passed)
       if (ch == 0) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
@@ -469,32 +572,41 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
           for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pp][cb][i] = 0.f;
+        if (rg == 0) {                                           // strip housekeeping for this 64-channel group
+          const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+          if (grp != sgrp || it.ct != sct || since_flush >= FI_WS2_FLUSH_TILES) {   // new (group, slab), or time to leave fp32
+            if (sct >= 0) stats_flush(sgrp, sct);
+            stats_clear();
+            if (it.ct != sct) load_bias(it.ct);
+            sgrp = grp;
+            sct = it.ct;
+            since_flush = 0;
+          }
+          ++since_flush;
+        }
       }
-      FI_T2(4);                                                  // stage start (barrier passed)
 #if !(FI_WS2_DEBUG & 1)
-      mma(buf);
+      {
+        int cr = cq + rot_of(it) % NQ;                           // the chunk of its group this stage holds (producers: chunk_of)
+        cr = cr >= NQ ? cr - NQ : cr;
+        mma(wbuf, gpar, cr);
+      }
 #endif
       FI_T2(5);                                                  // MFMAs issued
+      if (++cq == NQ) {
+        cq = 0;
+        gpar ^= 1;
+      }
       if (++ch == nchunk) {
         ch = 0;
-        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
-        if (grp != sgrp || it.ct != sct || since_flush >= FI_WS2_FLUSH_TILES) {   // new (group, slab), or time to leave fp32
-          stats_flush(sgrp, sct);
-          stats_clear();
-          if (it.ct != sct) load_bias(it.ct);
-          sgrp = grp;
-          sct = it.ct;
-          since_flush = 0;
-        }
 #if !(FI_WS2_DEBUG & 16)
         epilogue(it);
 #endif
         FI_T2(6);                                                // epilogue issued
-        ++since_flush;
         it = item_next(it);
       }
     };
-    fi_lds_barrier();                                            // stage 0 is in buffer 0
+    fi_lds_barrier();                                            // package 0 and group 0 are in LDS
     for (int s = 0; s < nstage; s += 2) {
       consume(0);
       fi_lds_barrier();
@@ -502,16 +614,15 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       consume(1);
       fi_lds_barrier();
     }
-    stats_flush(sgrp, sct);
+    if (rg == 0 && sct >= 0) stats_flush(sgrp, sct);
     FI_T2(4);
   }
 }
 
 template <typename T, int TR, int BN>
 static int launch_conv_fwd_ws2(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
-  constexpr int XH = TR + 2, XW = 18;
-  constexpr int STAGE = XH * XW * 32 + BN * (9 * 16 * 2 + 16);
-  const size_t lds = (size_t)2 * STAGE + (size_t)8 * 3 * 64 * sizeof(float);
+  constexpr int XH = TR + 2, XW = 18, GC = TR == 16 ? 64 : 32;
+  const size_t lds = (size_t)2 * (XH * XW * GC * 2) + (size_t)2 * (BN * 9 * 16 * 2) + (size_t)(BN / 64) * 192 * sizeof(float);
   const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
   long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
   if (blocks > nitem) blocks = nitem;
