@@ -140,6 +140,7 @@ class Federation:
             e0.record()
             self.agg.start(self.model.get_device_weights())      # side stream: pre-scale, all-reduce, divide
             c.sampled_batches = list(c.trainloader)              # overlapped: next round's batch staging (epoch list)
+            self.model.stage_ahead(self.loader[0])               # ... and the first batch of the ALA epoch on its way over PCIe
             glob = self.agg.finish()
             self._loaded = None
             self.model.set_weights(glob, {"iter_global": self.iter_global})    # global load + ALA epoch
@@ -415,7 +416,8 @@ def main():
         fedr = Federation(a, rank, world, dev, a.dtype, data="resident")
         kr = min(a.steps, a.round_iters)
         elr, aggr = fedr.timed(a.warmup, kr, dist)
-        resident = {"images_per_sec": round(kr * a.batch * world / elr, 2), "steps": kr, "ms_per_aggregation_round": round(aggr, 3)}
+        resident = {"images_per_sec": round(kr * a.batch * world / elr, 2), "steps": kr, "ms_per_aggregation_round": round(aggr, 3),
+                    "round_split_ms": fedr.round_split()}
         del fedr
         torch.cuda.empty_cache()
 

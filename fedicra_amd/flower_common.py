@@ -243,6 +243,12 @@ class MyModel(nn.Module):
             st = self.__dict__["_stager"] = BatchStager(self.model.flat_state.device)
         return st
 
+    def stage_ahead(self, sampled_batch):
+        """Start the host -> device copy of a batch that set_weights / _train will ask for next (round drivers call this while
+        the aggregation collective runs: 'the next round's data staging' it is overlapped with)."""
+        if self.model.flat_state.is_cuda and sampled_batch is not None and sampled_batch["image"].device.type == "cpu":
+            self.batch_stager().prefetch(sampled_batch)
+
     def _batch(self, sampled_batch):
         """(image, label, staged) on the device.  flower_common.py:568-573.  A host batch comes out of the staging pair
         (prefetched on the side stream when the caller looked ahead); `staged` tells the caller to release() it."""

@@ -102,10 +102,15 @@ class MyClient(BaseClient):
 
     def _prefetch_next(self):
         """Start the host -> device copy of the batch the NEXT iteration will take (flower_pCE_2D.py:66-73: same epoch
-        list) while this one runs.  At an epoch boundary the list is rebuilt first: no prefetch, the copy is serial."""
+        list) while this one runs -- the next round's first iteration included.  At an epoch boundary the list is rebuilt
+        first: only a list-like trainloader (whose next epoch is known) is looked into, otherwise that copy is serial."""
         stager = self._stager()
         n_b = len(self.trainloader)
-        if stager is None or not self.sampled_batches or self.current_iter % n_b == 0:
+        if stager is None or not self.sampled_batches:
+            return
+        if self.current_iter % n_b == 0:
+            if isinstance(self.trainloader, (list, tuple)):
+                stager.prefetch(self.trainloader[0])
             return
         stager.prefetch(self.sampled_batches[self.current_iter % n_b])
 
@@ -235,8 +240,7 @@ class MyClient(BaseClient):
                 self.current_iter += 1
                 lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
                 self.current_lr = lr_
-                if i_iter + 1 < iters:
-                    self._prefetch_next()
+                self._prefetch_next()
             yield i_iter
         with self._scope():
             return self._round_result(hist, x, y, rec)

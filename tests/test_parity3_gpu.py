@@ -125,8 +125,8 @@ def test_fused_sgd_steps_a_3d_model_whose_gradients_arrive_outside_the_flat_sink
     from fedicra_amd.networks.net_factory_3d import net_factory_3d
     from fedicra_amd.optim import FusedSGD
     torch.manual_seed(3)
-    net = net_factory_3d("unet_3D", in_chns=1, class_num=2)
-    ref = {n: p.detach().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    net = net_factory_3d("unet_3D", in_chns=1, class_num=2)     # (the reference's factory moves the model to the GPU itself)
+    ref = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in net.named_parameters()}
     net = net.to(DEV)
     opt = FusedSGD(net, lr=0.01, base_lr=0.01, max_iterations=100)
     topt = torch.optim.SGD(list(ref.values()), lr=0.01, momentum=0.9, weight_decay=1e-4)
