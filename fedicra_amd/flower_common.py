@@ -326,7 +326,11 @@ class MyModel(nn.Module):
             """One ALA batch (:566-602): device work only, hipGraph-capturable."""
             ops.begin_iteration(x.device)
             temp.zero_grad()
-            out = temp(x)[0]
+            # the copy's auxiliary heads feed nothing the loop reads (only [0]) and its BatchNorm statistics are discarded with
+            # it (:623-624 copies the 42 decoder tensors back, nothing else): skip them -- unless masks come from the host
+            # generator (parity runs), where the skipped Dropout2d would shift every later draw of the run
+            lean = getattr(self, "ala_skip_aux", True) and ops._mask_provider is None and "aux" in getattr(temp.forward, "__code__", type("c", (), {"co_varnames": ()})).co_varnames
+            out = (temp(x, aux=False) if lean else temp(x))[0]
             loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, ncls)
             skip = None
             if self.amp:                                      # :576-584: scaled backward, unscale (the lr = 0 step), update

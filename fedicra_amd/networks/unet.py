@@ -316,7 +316,7 @@ class _DecoderBase(_FiModule):
         output = None if probe else ops.conv2d(x_4, None, self.out_conv, y_f32=True)    # logits always fp32
         return [output, x_1, x_2, x_3, x_4]
 
-    def _run(self, f, probe=False):
+    def _run(self, f, probe=False, aux=True):
         return self._trunk(f, probe)
 
     def _heads(self):
@@ -356,9 +356,9 @@ class Decoder_Head(_DecoderBase):
     def _heads(self):
         return [(self.dsn_head, 2)]
 
-    def _run(self, f, probe=False):
+    def _run(self, f, probe=False, aux=True):
         o = self._trunk(f, probe)
-        return o + [_run_head(self.dsn_head, o[2], probe)]
+        return o + [_run_head(self.dsn_head, o[2], probe) if aux else None]
 
 
 class Decoder_MultiHead(_DecoderBase):
@@ -373,8 +373,10 @@ class Decoder_MultiHead(_DecoderBase):
     def _heads(self):
         return [(self.dsn_head1, 2), (self.dsn_head2, 3), (self.dsn_head3, 4)]
 
-    def _run(self, f, probe=False):
+    def _run(self, f, probe=False, aux=True):
         o = self._trunk(f, probe)
+        if not aux:
+            return o + [None, None, None]
         return o + [_run_head(self.dsn_head1, o[2], probe), _run_head(self.dsn_head2, o[3], probe),
                     _run_head(self.dsn_head3, o[4], probe)]
 
@@ -428,8 +430,11 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         self.decoder = self._decoder_cls(params)
         self._fi_finish_init()
 
-    def forward(self, x, emb_idx=None, heatmap_only=False):
-        """``heatmap_only`` (train mode, no autograd): the caller reads nothing but the heat-map ``[6]`` -- the LC loss's
+    def forward(self, x, emb_idx=None, heatmap_only=False, aux=True):
+        """``aux=False``: the auxiliary heads are not run and their entries of the returned list are None -- for a caller that
+        reads only ``[0]`` on a model whose state is thrown away afterwards (the ALA loop's deep copy, flower_common.py:503,
+        566-602: nothing but the heads' BatchNorm statistics of that copy would differ).
+        ``heatmap_only`` (train mode, no autograd): the caller reads nothing but the heat-map ``[6]`` -- the LC loss's
         forwards with the other clients' embeddings (flower_pCE_2D.py:128-139).  Every state change of the full forward
         still happens (all BatchNorm running statistics and counters, decoder and heads included), but tensors nobody
         reads are not produced: the heads run their convolution for its statistics only and store nothing (the full-
@@ -438,7 +443,7 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         self._fi_refresh_packs(self.compute_dtype())     # all conv operands in one launch, only if weights changed
         probe = bool(heatmap_only) and self.training and not torch.is_grad_enabled()
         f, h = self.encoder._run(self._in(x), emb_idx)
-        o = self.decoder._run(f, probe)
+        o = self.decoder._run(f, probe, aux)
         hm = [None if t is None else self._out(t) for t in h]
         out = lambda t: None if t is None else self._out(t)
         return [out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + [out(t) for t in o[5:]]

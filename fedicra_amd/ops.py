@@ -338,12 +338,22 @@ def _conv_backward(ctx, dy, x0, x1, wk, mod):
     if need_x0 or need_x1:
         wt = _packed(wk, dy.dtype, 1, cout, kk, cin, param=mod.weight)
         N, H, W, _ = dy.shape
-        # dgrad = conv of dy with the flipped/transposed filter; two destinations for a concat input
-        d0 = torch.empty((N, H, W, x0.shape[3]), dtype=dy.dtype, device=dy.device)
-        d1 = None if x1 is None else torch.empty((N, H, W, x1.shape[3]), dtype=dy.dtype, device=dy.device)
-        L.conv2d_fwd(dy, None, wt, None, d0, d1, None, ksize=ksize, tag="conv_dgrad")
-        dx0 = d0 if need_x0 else None
-        dx1 = d1 if need_x1 else None
+        c0 = x0.shape[3]
+        if x1 is not None and need_x0 != need_x1:
+            # only ONE half of a concatenated input wants its gradient (FedICRA's ALA: the skip connection comes from the
+            # frozen encoder, flower_common.py:542-546): the dgrad operand's rows are input channels, so that half is a
+            # contiguous row range of it -- half the GEMM instead of computing a tensor nobody reads
+            rows = slice(0, c0) if need_x0 else slice(c0, cin)
+            dh = torch.empty((N, H, W, rows.stop - rows.start), dtype=dy.dtype, device=dy.device)
+            L.conv2d_fwd(dy, None, wt.view(cin, kk * cout)[rows].reshape(-1), None, dh, None, None, ksize=ksize, tag="conv_dgrad")
+            dx0, dx1 = (dh, None) if need_x0 else (None, dh)
+        else:
+            # dgrad = conv of dy with the flipped/transposed filter; two destinations for a concat input
+            d0 = torch.empty((N, H, W, c0), dtype=dy.dtype, device=dy.device)
+            d1 = None if x1 is None else torch.empty((N, H, W, x1.shape[3]), dtype=dy.dtype, device=dy.device)
+            L.conv2d_fwd(dy, None, wt, None, d0, d1, None, ksize=ksize, tag="conv_dgrad")
+            dx0 = d0 if need_x0 else None
+            dx1 = d1 if need_x1 else None
     return dx0, dx1, gw, gb
 
 

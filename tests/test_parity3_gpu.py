@@ -184,3 +184,58 @@ def test_round_driver_applies_the_fedopt_server_step_to_the_all_reduced_mean(nam
     assert out.returncode == 0 and "FL finished" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     bad = subprocess.run(base + ["--strategy", "Fedicra"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "unknown --strategy" in bad.stderr
+
+
+def test_ala_epoch_without_the_auxiliary_heads_and_with_half_dgrads_gives_the_same_weights():
+    """FedICRA's ALA loop (flower_common.py:566-602) on the device: (a) the copy's auxiliary head is skipped (nothing of it is
+    read, its BatchNorm statistics are discarded with the copy) and (b) the first convolution of every UpBlock computes only
+    the gradient half that is asked for (the skip half comes from the frozen encoder).  Both must leave the mixing weights
+    and the decoder exactly as the full computation does."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import DeviceWeights, MyModel
+    from fedicra_amd.networks import net_factory
+    from helpers import loader
+    outs = []
+    for skip_aux in (True, False):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=3, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=4, rep_iters=1, alpha=1.0,
+                                  snapshot_path=None, use_graph=False)
+        torch.manual_seed(2022)
+        ops.manual_seed(7)
+        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
+        batches = loader(2, 4, 64, cid=1, device=DEV)
+        model = MyModel(args, net, batches, batches)
+        model.train()
+        model.start_phase = False
+        model.verbose = False
+        model.ala_skip_aux = skip_aux
+        g = torch.Generator().manual_seed(5)
+        glob = DeviceWeights(net.flat_state + 0.02 * torch.randn(net.flat_state.shape, generator=g).to(DEV), net.flat_counters.clone())
+        model.set_weights(glob, {"iter_global": 60})
+        torch.cuda.synchronize()
+        outs.append((model.fedaa_weights.clone(), net.flat_params.clone(), list(model.ala_epoch_losses)))
+    assert outs[0][2] == outs[1][2]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] < 1).float().mean()) > 0.01          # the epoch really moved the mixing weights
+
+
+def test_dgrad_of_one_half_of_a_concatenated_input_equals_that_half_of_the_full_dgrad():
+    from fedicra_amd import ops
+    import torch.nn as nn
+    torch.manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        conv = nn.Conv2d(48, 32, 3, padding=1).to(DEV)
+        bn = nn.BatchNorm2d(32).to(DEV)
+        a = torch.randn(2, 20, 24, 16, device=DEV).to(dt)
+        b = torch.randn(2, 20, 24, 32, device=DEV).to(dt)
+        grads = {}
+        for need in ("both", "x0", "x1"):
+            a_ = a.clone().requires_grad_(need in ("both", "x0"))
+            b_ = b.clone().requires_grad_(need in ("both", "x1"))
+            conv.weight.requires_grad_(False), conv.bias.requires_grad_(False)
+            ops.begin_iteration(a.device)
+            z = ops.conv_bn_act(a_, b_, conv, bn, 0.01)
+            z.float().square().sum().backward()
+            grads[need] = (a_.grad, b_.grad)
+        assert torch.equal(grads["x0"][0], grads["both"][0]) and grads["x0"][1] is None
+        assert torch.equal(grads["x1"][1], grads["both"][1]) and grads["x1"][0] is None
