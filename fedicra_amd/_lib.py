@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv_weight_chunk16", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -776,6 +776,27 @@ def channel_gate_bwd(x, dy, h, amax, davg, dmx, dx, dh):
     N, H, W, Cc = _dev(x).shape
     _chk(lib().fi_channel_gate_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(h), ptr(amax), ptr(davg), ptr(dmx), ptr(dx),
                                    ptr(dh), N, H * W, Cc, stream()), "fi_channel_gate_bwd")
+
+
+def pcs_gate_fwd(avg, mx, who, w1a, w1b, w2a, w2b, h, hidden):
+    B, Cc = _dev(avg).shape
+    _chk(lib().fi_pcs_gate_fwd(ptr(avg), ptr(mx), ptr(who), ptr(w1a), ptr(w1b), ptr(w2a), ptr(w2b), ptr(h), ptr(hidden), B, Cc,
+                               w1a.shape[1], stream()), "fi_pcs_gate_fwd")
+
+
+def pcs_gate_bwd(dh, h, hidden, w2a, w2b, davg, dmx):
+    B, Cc = _dev(h).shape
+    _chk(lib().fi_pcs_gate_bwd(ptr(dh), ptr(h), ptr(hidden), ptr(w2a), ptr(w2b), ptr(davg), ptr(dmx), B, Cc, stream()),
+         "fi_pcs_gate_bwd")
+
+
+def lc_loss_fwd(h, others, loss_ce, alpha, G, out, dcoef):
+    _chk(lib().fi_lc_loss_fwd(ptr(_dev(h)), ptr(others), ptr(loss_ce), C.c_float(alpha), int(G), h.numel(), ptr(out), ptr(dcoef),
+                              stream()), "fi_lc_loss_fwd")
+
+
+def lc_loss_bwd(dcoef, g, alpha, dh):
+    _chk(lib().fi_lc_loss_bwd(ptr(_dev(dcoef)), ptr(g), C.c_float(alpha), ptr(dh), dcoef.numel(), stream()), "fi_lc_loss_bwd")
 
 
 def cast(src, dst):

@@ -827,6 +827,172 @@ extern "C" int fi_probe_tr16(const short* in, const int* offs, short* out, void*
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PersonalizedChannelSelection's gate as ONE launch per direction (/root/reference/code/networks/unet.py:103-144):
+//   e  = W1b relu(W1a onehot(who))                  fc1: 1x1 convs K -> C -> C, no bias
+//   a  = W2b relu(W2a [avg ; e]),  m = W2b relu(W2a [mx ; e])      fc2: 2C -> C/16 -> C, shared, no bias
+//   h  = sigmoid(a + m)
+// One workgroup per image; everything fp32 (a few hundred kFLOP).  The reference evaluates these as 1x1 convolutions of
+// [B,C,1,1] maps: each output is the dot product taken in channel order, which is the order of the loops here.  The
+// hidden activations (C/16 each) are kept for the backward pass; the PCS weights are frozen in the reference (they are not
+// registered, unet.py:172-177), so backward only produces d/d avg and d/d max.
+// ------------------------------------------------------------------------------------------------
+#define FI_PCS_MAXC 512
+__global__ __launch_bounds__(256) void pcs_gate_fwd_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                           const int* __restrict__ who, const float* __restrict__ w1a,
+                                                           const float* __restrict__ w1b, const float* __restrict__ w2a,
+                                                           const float* __restrict__ w2b, float* __restrict__ h,
+                                                           float* __restrict__ hidden, int C, int K) {
+  __shared__ float v[3][FI_PCS_MAXC];         // avg, max, e (first as e1)
+  __shared__ float e1[FI_PCS_MAXC];
+  __shared__ float t[2][FI_PCS_MAXC / 16];
+  const int b = blockIdx.x, tid = threadIdx.x, R = C / 16;
+  const int k = who[b];
+  for (int c = tid; c < C; c += 256) {
+    v[0][c] = avg[(size_t)b * C + c];
+    v[1][c] = mx[(size_t)b * C + c];
+    const float x = w1a[(size_t)c * K + k];                    // column `who` of fc1[0]: the one-hot embedding picks it
+    e1[c] = x > 0.f ? x : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    const float* row = w1b + (size_t)c * C;
+    for (int j = 0; j < C; ++j) s += row[j] * e1[j];
+    v[2][c] = s;
+  }
+  __syncthreads();
+  // hidden layer: 2 x R dot products of length 2C, one wave-quarter (16 lanes) each would idle most lanes; a thread each
+  for (int i = tid; i < 2 * R; i += 256) {
+    const int which = i / R, r = i % R;
+    const float* row = w2a + (size_t)r * 2 * C;
+    float s = 0.f;
+    for (int j = 0; j < C; ++j) s += row[j] * v[which][j];
+    for (int j = 0; j < C; ++j) s += row[C + j] * v[2][j];
+    t[which][r] = s > 0.f ? s : 0.f;
+    hidden[((size_t)b * 2 + which) * R + r] = t[which][r];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const float* row = w2b + (size_t)c * R;
+    float a = 0.f, m = 0.f;
+    for (int r = 0; r < R; ++r) {
+      a += row[r] * t[0][r];
+      m += row[r] * t[1][r];
+    }
+    h[(size_t)b * C + c] = 1.f / (1.f + expf(-(a + m)));
+  }
+}
+
+__global__ __launch_bounds__(256) void pcs_gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                           const float* __restrict__ hidden, const float* __restrict__ w2a,
+                                                           const float* __restrict__ w2b, float* __restrict__ davg,
+                                                           float* __restrict__ dmx, int C) {
+  __shared__ float ds[FI_PCS_MAXC];
+  __shared__ float dt[2][FI_PCS_MAXC / 16];
+  const int b = blockIdx.x, tid = threadIdx.x, R = C / 16;
+  for (int c = tid; c < C; c += 256) {
+    const float hv = h[(size_t)b * C + c];
+    ds[c] = dh[(size_t)b * C + c] * hv * (1.f - hv);            // through the sigmoid; a and m share it
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * R; i += 256) {
+    const int which = i / R, r = i % R;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += w2b[(size_t)c * R + r] * ds[c];
+    dt[which][r] = hidden[((size_t)b * 2 + which) * R + r] > 0.f ? s : 0.f;     // through the ReLU
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, m = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float wv = w2a[(size_t)r * 2 * C + c];
+      a += wv * dt[0][r];
+      m += wv * dt[1][r];
+    }
+    davg[(size_t)b * C + c] = a;
+    dmx[(size_t)b * C + c] = m;
+  }
+}
+
+extern "C" int fi_pcs_gate_fwd(const float* avg, const float* mx, const int* who, const float* w1a, const float* w1b,
+                               const float* w2a, const float* w2b, float* h, float* hidden, int B, int C, int K,
+                               void* stream) {
+  if (!avg || !mx || !who || !w1a || !w1b || !w2a || !w2b || !h || !hidden) return FI_ERR_NULL;
+  if (B < 1 || C < 16 || C % 16 || C > FI_PCS_MAXC || K < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(pcs_gate_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, avg, mx, who, w1a, w1b, w2a, w2b, h,
+                     hidden, C, K);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_pcs_gate_bwd(const float* dh, const float* h, const float* hidden, const float* w2a, const float* w2b,
+                               float* davg, float* dmx, int B, int C, void* stream) {
+  if (!dh || !h || !hidden || !w2a || !w2b || !davg || !dmx) return FI_ERR_NULL;
+  if (B < 1 || C < 16 || C % 16 || C > FI_PCS_MAXC) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(pcs_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dh, h, hidden, w2a, w2b, davg, dmx, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FedICRA's LC loss (/root/reference/code/flower_pCE_2D.py:128-139) and its place in the total, one launch per direction:
+//   loss_lc = -(1 / G) sum_g mean((h - o_g)^2)        h: own heat-map [n], o: the G other clients' [G][n]
+//   total   = loss_ce + alpha * loss_lc
+// out = {total, loss_lc}; dcoef[i] = d loss_lc / d h[i] = -(2 / (G n)) sum_g (h[i] - o_g[i]) is kept for backward, which is
+// dh = g * alpha * dcoef (g = the upstream gradient of `total`, a device scalar).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void lc_loss_fwd_kernel(const float* __restrict__ h, const float* __restrict__ others,
+                                                           const float* __restrict__ loss_ce, float alpha, int G, int n,
+                                                           float* __restrict__ out, float* __restrict__ dcoef) {
+  __shared__ double part[16];
+  double acc = 0.0;
+  const float inv = 1.f / ((float)G * (float)n);
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float hv = h[i];
+    float d1 = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const float d = hv - others[(size_t)g * n + i];
+      acc += (double)(d * d);
+      d1 += d;
+    }
+    dcoef[i] = -2.f * inv * d1;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += part[w];
+    const float lc = -(float)(s / ((double)G * (double)n));
+    out[1] = lc;
+    out[0] = loss_ce[0] + alpha * lc;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(const float* __restrict__ src, const float* __restrict__ g,
+                                                                     float k, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i] * (g[0] * k);
+}
+
+extern "C" int fi_lc_loss_fwd(const float* h, const float* others, const float* loss_ce, float alpha, int G, int n,
+                              float* out, float* dcoef, void* stream) {
+  if (!h || !others || !loss_ce || !out || !dcoef) return FI_ERR_NULL;
+  if (G < 1 || n < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(lc_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h, others, loss_ce, alpha, G, n, out, dcoef);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_lc_loss_bwd(const float* dcoef, const float* g, float alpha, float* dh, int n, void* stream) {
+  if (!dcoef || !g || !dh) return FI_ERR_NULL;
+  if (n < 1) return FI_ERR_SHAPE;
+  hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(fi_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dcoef, g, alpha, dh, n);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int fi_abi_version(void) { return FI_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------

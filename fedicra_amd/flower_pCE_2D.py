@@ -141,15 +141,25 @@ class MyClient(BaseClient):
             others = [c for c in range(args.min_num_clients) if c != args.cid]
             with torch.no_grad():                                                    # all K-1 forwards as one batch
                 batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
-            for k, other_client in enumerate(others):
-                if batched is not None:
-                    other_map = batched[k]
-                else:
-                    with torch.no_grad():
-                        other_map = self.model(x, other_client, heatmap_only=True)[6][-1]   # nothing else of it is read
-                acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], other_map.detach())
-            loss_lc = -acc / (args.min_num_clients - 1)
-            loss = torch.add(loss, loss_lc, alpha=args.alpha)
+            base = None
+            if batched is not None and heatmaps[-1].is_cuda:
+                base = batched[0]._base if batched[0]._base is not None else batched[0]
+                if base.numel() != len(others) * heatmaps[-1].numel() or base.dtype != torch.float32 or not base.is_contiguous():
+                    base = None
+            if base is not None:
+                # all K-1 heat-maps sit back to back in one tensor (probe_heatmaps returns views of it): the K-1 MSEs, their
+                # mean, the sign and the alpha-weighted sum are ONE launch (fi_lc_loss_fwd)
+                loss, loss_lc = ops.lc_total(loss_ce, heatmaps[-1], base.detach(), len(others), args.alpha)
+            else:
+                for k, other_client in enumerate(others):
+                    if batched is not None:
+                        other_map = batched[k]
+                    else:
+                        with torch.no_grad():
+                            other_map = self.model(x, other_client, heatmap_only=True)[6][-1]   # nothing else of it is read
+                    acc = acc + torch.nn.functional.mse_loss(heatmaps[-1], other_map.detach())
+                loss_lc = -acc / (args.min_num_clients - 1)
+                loss = torch.add(loss, loss_lc, alpha=args.alpha)
         if self.amp:                                         # :143-146
             self.scaler.scale(loss).backward()
             self.scaler.step(opt)

@@ -200,17 +200,25 @@ class PersonalizedChannelSelection(_FiModule):
     def forward_emb(self, emb):
         return self._mlp(self.fc1, emb.reshape(emb.shape[0], 1, 1, -1).float())
 
-    def _run(self, x, emb):
+    def _run(self, x, who):
+        """x: dense NHWC; who: int32 [B], the embedding index of every image (the reference feeds the one-hot rows of them,
+        unet.py:180-184).  The whole gate -- fc1 of the embedding, fc2 of [avg ; e] and [max ; e], sigmoid -- is one launch
+        (fi_pcs_gate_fwd); on the CPU (host logic tests) the same arithmetic through the 1x1-convolution helpers."""
         B, H, W, C = x.shape
         avg, mx = ops.global_avgmax(x)                       # [B,C] fp32 each
-        e = self.forward_emb(emb)                            # [B,1,1,C]
-        a = self._mlp(self.fc2, avg.reshape(B, 1, 1, C), e)  # cat([avg, emb], 1) folded into the gather
-        m = self._mlp(self.fc2, mx.reshape(B, 1, 1, C), e)
-        hmap = torch.sigmoid(a + m)                          # [B,1,1,C]
+        if x.is_cuda:
+            hmap = ops.pcs_gate(avg, mx, who, self.fc1, self.fc2).reshape(B, 1, 1, C)
+        else:
+            emb = torch.zeros((B, self.fc1[0].weight.shape[1]), device=x.device)
+            emb[torch.arange(B), who.long()] = 1
+            e = self.forward_emb(emb)                            # [B,1,1,C]
+            a = self._mlp(self.fc2, avg.reshape(B, 1, 1, C), e)  # cat([avg, emb], 1) folded into the gather
+            m = self._mlp(self.fc2, mx.reshape(B, 1, 1, C), e)
+            hmap = torch.sigmoid(a + m)                          # [B,1,1,C]
         return ops.channel_gate(x, hmap.reshape(B, C)), hmap
 
     def forward(self, x, emb):
-        y, h = self._run(self._in(x), emb)
+        y, h = self._run(self._in(x), emb.argmax(dim=1).to(torch.int32))
         return self._out(y), self._out(h)
 
 
@@ -245,8 +253,7 @@ class LCEncoder(_FiModule):
 
     def _run(self, x, emb_idx=None):
         who = self.cid if not emb_idx else emb_idx           # unet.py:186 (quirk 2: 0 means "own")
-        emb = torch.zeros((x.shape[0], self.n_client), device=x.device)
-        emb[:, who] = 1
+        emb = self._who((who,), x.shape[0], x.device)        # one-hot row `who` for every image, as its index
         feats, hmaps = [], []
         n = len(self.conv_list)
         for i, blk in enumerate(self.conv_list):
@@ -257,6 +264,16 @@ class LCEncoder(_FiModule):
             feats.append(x)
             hmaps.append(h)
         return feats, hmaps
+
+    def _who(self, ids, B, device):
+        """int32 [len(ids) * B]: embedding index of every image of a batch of len(ids) groups of B (cached: the training
+        step asks for the same few combinations every iteration, and a captured step must not re-create them)."""
+        cache = self.__dict__.setdefault("_who_cache", {})
+        key = (ids, B, str(device))
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.tensor([i for i in ids for _ in range(B)], dtype=torch.int32, device=device)
+        return t
 
     def _probe(self, x, emb_ids):
         """The encoder for len(emb_ids) forwards of the SAME batch x under different embeddings, as one batch of groups
@@ -269,9 +286,7 @@ class LCEncoder(_FiModule):
             r = blk.maxpool_conv[1]._probe(r, None, G, pool=True)
             feats.append(r)
         z = ops.probe_materialize(feats[4], G)
-        emb = torch.zeros((G * B, self.n_client), device=x.device)
-        for g, e in enumerate(emb_ids):
-            emb[g * B:(g + 1) * B, self.cid if not e else e] = 1   # unet.py:186 (quirk 2: 0 means "own")
+        emb = self._who(tuple(self.cid if not e else e for e in emb_ids), B, x.device)   # unet.py:186 (quirk 2: 0 means "own")
         x4, h = self.pcs_list[0]._run(z, emb)
         return feats[:4], x4, h
 

@@ -569,6 +569,62 @@ class _GlobalAvgMax(Function):
         return dx
 
 
+class _PCSGate(Function):
+    """h = sigmoid(fc2([avg ; e]) + fc2([max ; e])), e = fc1(onehot(who))  (unet.py:122-141) -- fi_pcs_gate_fwd / _bwd.  The PCS
+    weights are frozen in the reference (unregistered, never optimised): backward yields d/d avg and d/d max only."""
+
+    @staticmethod
+    def forward(ctx, avg, mx, who, w1a, w1b, w2a, w2b):
+        B, Cc = avg.shape
+        h = torch.empty_like(avg)
+        hidden = torch.empty((B, 2, Cc // 16), dtype=torch.float32, device=avg.device)
+        L.pcs_gate_fwd(avg.contiguous(), mx.contiguous(), who, w1a, w1b, w2a, w2b, h, hidden)
+        ctx.save_for_backward(h, hidden, w2a, w2b)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        h, hidden, w2a, w2b = ctx.saved_tensors
+        davg, dmx = torch.empty_like(h), torch.empty_like(h)
+        L.pcs_gate_bwd(dh.contiguous(), h, hidden, w2a, w2b, davg, dmx)
+        return davg, dmx, None, None, None, None, None
+
+
+def pcs_gate(avg, mx, who, fc1, fc2):
+    """avg / mx fp32 [B,C]; who int32 [B]; fc1 / fc2: the nn.Sequential(Conv2d 1x1, ReLU, Conv2d 1x1) pairs of the module."""
+    f = lambda m: m.weight.detach().reshape(m.weight.shape[0], m.weight.shape[1]).float().contiguous()
+    return _PCSGate.apply(avg, mx, who, f(fc1[0]), f(fc1[2]), f(fc2[0]), f(fc2[2]))
+
+
+class _LCTotal(Function):
+    """(total, loss_lc) = (loss_ce + alpha * loss_lc, -(1/G) sum_g mse(h, o_g))  (flower_pCE_2D.py:128-139), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, loss_ce, h, others, G, alpha):
+        out = torch.empty(2, dtype=torch.float32, device=h.device)
+        dcoef = torch.empty(h.numel(), dtype=torch.float32, device=h.device)
+        L.lc_loss_fwd(h.contiguous(), others, loss_ce.reshape(1), alpha, G, out, dcoef)
+        ctx.save_for_backward(dcoef)
+        ctx.alpha, ctx.hshape = alpha, h.shape
+        total, lc = out[0], out[1]
+        ctx.mark_non_differentiable(lc)
+        return total, lc
+
+    @staticmethod
+    def backward(ctx, g, _g_lc):
+        (dcoef,) = ctx.saved_tensors
+        dh = torch.empty(ctx.hshape, dtype=torch.float32, device=dcoef.device)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        L.lc_loss_bwd(dcoef, gs, ctx.alpha, dh)
+        return g, dh, None, None, None
+
+
+def lc_total(loss_ce, h, others, G, alpha):
+    """h: the client's own heat-map (any shape, fp32, n elements); others: ONE fp32 tensor holding the G other heat-maps back to
+    back ([G * n] elements, no gradient).  -> (loss_ce + alpha * loss_lc, loss_lc)."""
+    return _LCTotal.apply(loss_ce, h.float(), others, int(G), float(alpha))
+
+
 # ----------------------------------------------------------------------------- functional API
 def conv2d(x0, x1, mod, y_f32=False):
     return _Conv.apply(x0, x1, mod.weight, mod.bias, mod, y_f32)

@@ -467,6 +467,24 @@ int fi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, vo
 int fi_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, void* stream);
 int fi_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int C, int H, int W, void* stream);
 
+/* PersonalizedChannelSelection's gate (/root/reference/code/networks/unet.py:103-144) as one launch per direction:
+ *   e = fc1(onehot(who)),  h = sigmoid(fc2([avg ; e]) + fc2([max ; e]))       fc1: K -> C -> C, fc2: 2C -> C/16 -> C, ReLU between,
+ * no biases.  avg / mx / h: fp32 [B][C] (fi_global_avgmax); who: int32 [B] embedding index per image; w1a [C][K], w1b [C][C],
+ * w2a [C/16][2C], w2b [C][C/16]: the four 1x1-conv weights as stored; hidden: fp32 [B][2][C/16], kept for backward.  C % 16 == 0,
+ * C <= 512.  The PCS weights are frozen in the reference (never registered: unet.py:172-177): backward yields d/d avg, d/d max. */
+int fi_pcs_gate_fwd(const float* avg, const float* mx, const int* who, const float* w1a, const float* w1b, const float* w2a,
+                    const float* w2b, float* h, float* hidden, int B, int C, int K, void* stream);
+int fi_pcs_gate_bwd(const float* dh, const float* h, const float* hidden, const float* w2a, const float* w2b, float* davg,
+                    float* dmx, int B, int C, void* stream);
+
+/* FedICRA's LC loss and the total it enters (/root/reference/code/flower_pCE_2D.py:128-139):
+ *   out[1] = loss_lc = -(1/G) sum_g mean((h - others[g])^2),   out[0] = loss_ce[0] + alpha * loss_lc
+ * h: fp32 [n] (the client's own heat-map), others: fp32 [G][n] (the heat-maps under the other clients' embeddings, no gradient),
+ * loss_ce: device scalar.  dcoef fp32 [n] = d loss_lc / d h, kept for fi_lc_loss_bwd: dh = g[0] * alpha * dcoef. */
+int fi_lc_loss_fwd(const float* h, const float* others, const float* loss_ce, float alpha, int G, int n, float* out,
+                   float* dcoef, void* stream);
+int fi_lc_loss_bwd(const float* dcoef, const float* g, float alpha, float* dh, int n, void* stream);
+
 /* ---------------------------------------------------------------- defined-but-unused module surface -----------
  * ConvTranspose{2,3}d(kernel 2, stride 2) -- UpBlock(bilinear=False) (/root/reference/code/networks/unet.py:60-62, never
  * selected by the reference's decoders) and VNet's UpsamplingDeconvBlock (networks/vnet.py:94-118) -- has no overlapping

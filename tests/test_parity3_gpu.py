@@ -239,3 +239,45 @@ def test_dgrad_of_one_half_of_a_concatenated_input_equals_that_half_of_the_full_
             grads[need] = (a_.grad, b_.grad)
         assert torch.equal(grads["x0"][0], grads["both"][0]) and grads["x0"][1] is None
         assert torch.equal(grads["x1"][1], grads["both"][1]) and grads["x1"][0] is None
+
+
+def test_pcs_gate_and_lc_total_kernels_against_the_module_arithmetic():
+    """fi_pcs_gate_fwd / _bwd against the reference module's expression sigmoid(fc2(cat(avg, e)) + fc2(cat(max, e))),
+    e = fc1(onehot) (unet.py:122-141) in torch on the CPU -- values and the gradients w.r.t. avg / max; fi_lc_loss_fwd / _bwd
+    against -mean_g mse(h, o_g) and its place in the total (flower_pCE_2D.py:128-139)."""
+    import torch.nn as nn
+    from fedicra_amd import ops
+    torch.manual_seed(9)
+    B, Cc, K = 5, 256, 8
+    fc1 = nn.Sequential(nn.Conv2d(K, Cc, 1, bias=False), nn.ReLU(), nn.Conv2d(Cc, Cc, 1, bias=False))
+    fc2 = nn.Sequential(nn.Conv2d(2 * Cc, Cc // 16, 1, bias=False), nn.ReLU(), nn.Conv2d(Cc // 16, Cc, 1, bias=False))
+    avg = torch.randn(B, Cc, requires_grad=True)
+    mx = torch.randn(B, Cc, requires_grad=True)
+    who = torch.tensor([3, 0, 7, 3, 1])
+    emb = torch.zeros(B, K)
+    emb[torch.arange(B), who] = 1
+    e = fc1(emb.reshape(B, K, 1, 1))
+    ref = torch.sigmoid(fc2(torch.cat([avg.reshape(B, Cc, 1, 1), e], 1)) + fc2(torch.cat([mx.reshape(B, Cc, 1, 1), e], 1))).reshape(B, Cc)
+    gout = torch.randn(B, Cc)
+    ref.backward(gout)
+    a2, m2 = avg.detach().to(DEV).requires_grad_(True), mx.detach().to(DEV).requires_grad_(True)
+    got = ops.pcs_gate(a2, m2, who.to(torch.int32).to(DEV), fc1.to(DEV), fc2.to(DEV))
+    got.backward(gout.to(DEV))
+    assert float((got.detach().cpu() - ref.detach()).abs().max()) < 2e-6
+    assert float((a2.grad.cpu() - avg.grad).abs().max()) < 2e-6 and float((m2.grad.cpu() - mx.grad).abs().max()) < 2e-6
+    # LC total
+    G, n = 7, 12 * 256
+    h = torch.rand(12, 256, 1, 1, requires_grad=True)
+    others = torch.rand(G, n)
+    ce = torch.tensor(0.7, requires_grad=True)
+    acc = 0
+    for g_ in range(G):
+        acc = acc + torch.nn.functional.mse_loss(h, others[g_].reshape(h.shape))
+    lc_ref = -acc / G
+    tot_ref = torch.add(ce, lc_ref, alpha=0.5)
+    (tot_ref * 3.0).backward()
+    h2, ce2 = h.detach().to(DEV).requires_grad_(True), ce.detach().to(DEV).requires_grad_(True)
+    tot, lc = ops.lc_total(ce2, h2, others.to(DEV).reshape(-1), G, 0.5)
+    (tot * 3.0).backward()
+    assert abs(float(tot) - float(tot_ref)) < 1e-6 and abs(float(lc) - float(lc_ref)) < 1e-6 and not lc.requires_grad
+    assert float((h2.grad.cpu() - h.grad).abs().max()) < 1e-9 and abs(float(ce2.grad) - 3.0) < 1e-7
