@@ -185,6 +185,206 @@ class Federation:
         return {k: round(v, 3) for k, v in out.items()}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# --workload c4: BASELINE.json configs[3] -- 4 clients, 3D U-Net 128^3 CT patches, bf16, one client per MI355X
+# ---------------------------------------------------------------------------------------------------------------------
+C4_CLIENTS = 4
+C4_FWD_GF = 289.14          # conv FLOPs of one forward of unet_3D(1,2) at 128^3, per volume
+
+
+class Volumes:
+    """The hosted 3D client: ``unet_3D(n_classes=2, in_channels=1)`` (networks/unet_3D.py:20-94) on 2 x 1 x S^3 patches.  The
+    reference never trains its 3D networks in a federation (nothing calls net_factory_3d), so the step is
+    the 2D client loop carried over: zero-grad, forward, CE, backward, SGD(momentum 0.9, wd 1e-4 -- the reference's 3D trainers'
+    optimizer) with the poly LR, and FedAvg every ``round_iters`` steps (pre-scaled flat state -> weighted all-reduce -> load)."""
+
+    def __init__(self, a, rank, world, dev, dtype):
+        from fedicra_amd.comm import WeightedAllReduce
+        from fedicra_amd.flower_common import DeviceWeights
+        from fedicra_amd.networks.net_factory_3d import net_factory_3d
+        from fedicra_amd.networks.unet import set_compute_dtype
+        from fedicra_amd.optim import FusedSGD
+        self.a, self.rank, self.world, self.dev = a, rank, world, dev
+        torch.manual_seed(2022)
+        self.net = net_factory_3d("unet_3D", 1, 2).to(dev).train()
+        set_compute_dtype(self.net, dtype)
+        g = torch.Generator().manual_seed(2022 + 1000 * rank)
+        S = a.size
+        self.batches = [(torch.rand(a.batch, 1, S, S, S, generator=g).to(dev),
+                         (torch.rand(a.batch, S, S, S, generator=g) > 0.5).to(torch.uint8).to(dev)) for _ in range(2)]
+        self.opt = FusedSGD(self.net, lr=0.01, base_lr=0.01, max_iterations=30000)
+        n_all = [21, 13, 17, 59][:C4_CLIENTS]
+        absent = None
+        if world < C4_CLIENTS:
+            absent = (DeviceWeights(self.net.flat_state.clone(), self.net.flat_counters.clone()), sum(n_all[world:]))
+        self.agg = WeightedAllReduce(n_all[rank], device=dev, constant_term=absent, timing=True)
+        self.backend = None
+        if world > 1:
+            import torch.distributed as dist
+            self.backend = dist.get_backend()
+            if not os.environ.get("FEDICRA_DIST_BACKEND"):
+                assert self.backend == "nccl", f"multi-GPU bench must exchange over RCCL, got backend {self.backend!r}"
+            dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
+            torch.cuda.synchronize()
+        self.it = 0
+        self.agg_events = []
+
+    def step(self):
+        from fedicra_amd import ops
+        x, y = self.batches[self.it % 2]
+        ops.begin_iteration(self.dev)
+        self.opt.zero_grad()
+        out = self.net(x)                                        # NCDHW view of fp32 NDHWC logits
+        lg = out.permute(0, 2, 3, 4, 1)
+        N, D, H, W, Cc = lg.shape
+        loss = ops.ce_loss(lg.reshape(N * D, H, W, Cc), y.reshape(N * D, H, W), 255)
+        loss.backward()
+        self.opt.step()
+        self.opt.advance_lr()
+        self.it += 1
+
+    def run_steps(self, nsteps):
+        from fedicra_amd.flower_common import DeviceWeights
+        a, done = self.a, 0
+        while done < nsteps:
+            it = min(a.round_iters, nsteps - done)
+            for _ in range(it):
+                self.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            glob = self.agg.aggregate(DeviceWeights(self.net.flat_state, self.net.flat_counters))
+            self.net.flat_state.copy_(glob.state)
+            self.net.flat_counters.copy_(glob.counters)
+            e1.record()
+            self.agg_events.append((e0, e1))
+            done += it
+
+    def timed(self, warmup, steps, dist):
+        self.run_steps(warmup)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        self.agg_events, self.agg.splits = [], []
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        agg_ms = [e0.elapsed_time(e1) for e0, e1 in self.agg_events]
+        return elapsed, sum(agg_ms) / max(len(agg_ms), 1)
+
+    def roofline(self, dtype_name):
+        from fedicra_amd import _lib as L
+        self.step()
+        L.profile_begin(subtract_overhead=False)
+        for _ in range(2):
+            self.step()
+        prof = L.profile_end().summary()
+        pk_f, pk_b = MFMA_PEAK[dtype_name] * 1e12, HBM_PEAK_GBS * 1e9
+        fam = {}
+        for k, v in prof.items():
+            f = fam.setdefault(k[0], {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "ideal": 0.0})
+            for q in ("calls", "ms", "flops", "bytes"):
+                f[q] += v[q]
+            f["ideal"] += max(v["flops"] / pk_f, v["bytes"] / pk_b) * 1e3
+        total_ms = sum(v["ms"] for v in fam.values())
+        name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = dom["ms"] / dom["calls"]
+        flops, nbytes = dom["flops"] / dom["calls"], dom["bytes"] / dom["calls"]
+        ai = flops / max(nbytes, 1.0)
+        if ai >= pk_f / pk_b:
+            bound, ach, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, MFMA_PEAK[dtype_name], "TFLOP/s"
+        else:
+            bound, ach, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        table = os.environ.get("FEDICRA_BENCH_TABLE")
+        if table:
+            with open(table, "w") as f:
+                f.write(f"# per-launch-shape roofline of one unet_3D training iteration (2 instrumented iterations, HIP events, {dtype_name})\n")
+                for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                    us = v["ms"] / v["calls"] * 1e3
+                    idl = max(v["flops"] / pk_f, v["bytes"] / pk_b) / v["calls"] * 1e6
+                    f.write(f"{'/'.join(map(str, k)):64s} {v['calls']:4d} {us:9.1f} us  ideal {idl:8.1f}  frac {idl / max(us, 1e-9):6.3f}  "
+                            f"{v['flops'] / v['calls'] / (us * 1e-6) / 1e12:8.1f} TF/s {v['bytes'] / v['calls'] / (us * 1e-6) / 1e9:8.1f} GB/s\n")
+        return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                "kernel": f"{name} (all shapes of the unet_3D iteration)/{dtype_name}", "avg_us": round(avg_ms * 1e3, 2),
+                "launches_per_step": dom["calls"] / 2.0, "arithmetic_intensity_flop_per_byte": round(ai, 1),
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+                "share_of_timed_launch_time": round(dom["ms"] / total_ms, 4),
+                "min_roofline_frac": round(dom["ideal"] / max(dom["ms"], 1e-9), 4),
+                "kernel_time_breakdown_ms_per_step": {k: round(v["ms"] / 2.0, 3) for k, v in sorted(fam.items())},
+                "profile_command": "python bench.py --workload c4 --roofline-only  (profiles/*_c4_*)"}
+
+
+def cpu_baseline_c4(a):
+    """oracle.unet3d_ref.RefUNet3D (kind "port") on the host cores: one warm-up + one timed iteration (forward, CE, backward, SGD) on
+    ONE volume of half the edge (1 x 64^3 = 1/16 of the timed batch's voxels), scaled linearly in the voxel count."""
+    from oracle.unet3d_ref import RefUNet3D
+    cores = min(os.cpu_count() or 1, int(os.environ.get("FEDICRA_CPU_THREADS", "32")))
+    torch.set_num_threads(cores)
+    torch.manual_seed(2022)
+    S = max(16, a.size // 2)
+    m = RefUNet3D(n_classes=2, in_channels=1).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    x, y = torch.rand(1, 1, S, S, S), (torch.rand(1, S, S, S) > 0.5).long()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x), y)
+        loss.backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    vox_ratio = float(a.size ** 3) / float(S ** 3)
+    return {"value": round(1.0 / (ts[-1] * vox_ratio), 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.unet3d_ref.RefUNet3D (torch {torch.__version__} CPU fp32, {cores} threads): 1 warm-up + 1 timed training "
+                      f"iteration on 1x1x{S}^3, scaled by the voxel ratio {vox_ratio:.0f} to a {a.size}^3 volume"}
+
+
+def main_c4(a, rank, local, world, dev, dist):
+    assert world <= C4_CLIENTS, "configs[3] is a federation of 4 clients, one per GPU"
+    vol = Volumes(a, rank, world, dev, a.dtype)
+    if a.roofline_only:
+        roof = vol.roofline(a.dtype)
+        if rank == 0:
+            print(json.dumps({"roofline": roof}), flush=True)
+        return
+    elapsed, agg_ms = vol.timed(a.warmup, a.steps, dist)
+    value = a.steps * a.batch * world / elapsed
+    if rank == 0:
+        step_s = (elapsed - agg_ms * 1e-3 * len(vol.agg_events)) / a.steps
+        f_train = 3.0 * C4_FWD_GF * (a.size / 128.0) ** 3 * a.batch                  # GF per step (dgrad + wgrad for every conv)
+        line = {"metric": "volumes/sec/client (3D U-Net 128^3 local training, configs[3]) ; ms/aggregation round in config",
+                "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
+                "config": {"workload": f"BASELINE.json configs[3]: {C4_CLIENTS} clients FedAvg, unet_3D(n_classes=2, in_channels=1), "
+                                       f"{a.batch}x1x{a.size}^3 patches per batch, one client per MI355X ({world} hosted); step = one "
+                                       f"local iteration (fwd, CE, bwd, SGD momentum 0.9, poly LR), eager launches; round = "
+                                       f"{a.round_iters} steps + weighted all-reduce + load, all timed; data resident in HBM",
+                           "clients_hosted": world, "federation": C4_CLIENTS, "global_batch": a.batch * world,
+                           "volumes_per_sec_per_client": round(value / world, 3), "ms_per_aggregation_round": round(agg_ms, 3),
+                           "conv_tflops_per_gpu": round(f_train / step_s / 1e3, 2),
+                           "frac_of_mfma_peak": round(f_train / step_s / 1e3 / MFMA_PEAK[a.dtype], 4),
+                           "hipgraph": False, "parallelism": f"fed-dp{world}"}}
+        if world > 1:
+            sp = vol.agg.split_ms() or {}
+            line["config"].update({"rccl_ranks": world if vol.backend == "nccl" else 0, "dist_backend": vol.backend,
+                                   "allreduce_us_per_round": round(sp.get("collective", 0.0) * 1e3, 1)})
+        if not a.no_roofline:
+            try:
+                line["roofline"] = vol.roofline(a.dtype)
+            except Exception as e:  # noqa: BLE001
+                line["roofline"] = {"error": repr(e)}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_c4(a)
+        print(json.dumps(line), flush=True)
+
+
 def cpu_baseline(a):
     """The CPU oracle (oracle/, kind "port") on this box's host cores, on a bounded sample of the same workload:
     the FedICRA local-training iteration (LC forwards included) in the timed run's head : body mix, then one aggregation
@@ -363,9 +563,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3 (default): BASELINE configs[2], the configuration the metric is quoted on; c4: configs[3], the 3D path "
+                         "(4 clients, unet_3D, 2x1x128^3 bf16) with the same JSON shape in volumes/s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--in-chns", type=int, default=3, choices=[1, 3])
     ap.add_argument("--round-iters", type=int, default=10)
     ap.add_argument("--loader-batches", type=int, default=8,
@@ -382,6 +585,8 @@ def main():
                     help="only the instrumented eager iterations of the roofline object (the command rocprofv3 is pointed at "
                          "for profiles/*_roofline_kernel_stats.csv and the PMC traffic passes: same launch mix)")
     a = ap.parse_args()
+    a.size = a.size or (512 if a.workload == "c3" else 128)
+    a.batch = a.batch or (12 if a.workload == "c3" else 2)
     a.classes = 2 if a.in_chns == 1 else 3
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -390,13 +595,19 @@ def main():
     rank, local, world = init_process_group_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
-    assert world <= FEDERATION, "configs[2] is a federation of 8 clients, one per GPU"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
     from fedicra_amd import _lib
     _lib.lib()
+    if a.workload == "c4":
+        main_c4(a, rank, local, world, dev, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    assert world <= FEDERATION, "configs[2] is a federation of 8 clients, one per GPU"
 
     fed = Federation(a, rank, world, dev, a.dtype)
     if a.roofline_only:

@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv_weight_chunk16", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_wgrad_fused", "fi_conv3d_wgrad_fused_workspace", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -79,6 +79,7 @@ def lib():
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
         _lib.fi_conv2d_wgrad_workspace.restype = C.c_long
+        _lib.fi_conv3d_wgrad_fused_workspace.restype = C.c_long
         _lib.fi_tree_mst_workspace.restype = C.c_long
     return _lib
 
@@ -654,8 +655,11 @@ def conv3d_fwd(x0, x1, w_taps, bias, y, stats, *, ksize, y_f32=False):
     c1 = 0 if x1 is None else x1.shape[4]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, y.shape[4], 0, 1, 0, int(y_f32))
     stride = 0 if stats is None else stats.stride(0)
-    _chk(lib().fi_conv3d_fwd(C.byref(d), D, ptr(x0), ptr(x1), _taps_array(w_taps), ptr(bias), ptr(y), ptr(stats),
-                             C.c_long(stride), stream()), "fi_conv3d_fwd")
+    cin, co, vox = c0 + c1, y.shape[4], N * D * H * W
+    with _timed("conv3d_fwd", (str(x0.dtype)[6:], N, D, H, W, cin, co, ksize, "taps"), 2.0 * vox * cin * co * ksize ** 3,
+                vox * cin * _esz(x0) + vox * co * _esz(y) + cin * co * ksize ** 3 * _esz(x0)):
+        _chk(lib().fi_conv3d_fwd(C.byref(d), D, ptr(x0), ptr(x1), _taps_array(w_taps), ptr(bias), ptr(y), ptr(stats),
+                                 C.c_long(stride), stream()), "fi_conv3d_fwd")
 
 
 def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):
@@ -664,8 +668,11 @@ def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):
     c1 = 0 if x1 is None else x1.shape[4]
     d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, y.shape[4], 0, 0, 0, 0)
     stride = 0 if stats is None else stats.stride(0)
-    rc = lib().fi_conv3d_fwd_fused(C.byref(d), D, ptr(x0), ptr(x1), ptr(w_all), ptr(bias), ptr(y), ptr(stats),
-                                   C.c_long(stride), stream())
+    cin, co, vox = c0 + c1, y.shape[4], N * D * H * W
+    with _timed("conv3d_fwd", (str(x0.dtype)[6:], N, D, H, W, cin, co, ksize), 2.0 * vox * cin * co * ksize ** 3,
+                vox * (cin + co) * _esz(x0) + cin * co * ksize ** 3 * _esz(x0)):
+        rc = lib().fi_conv3d_fwd_fused(C.byref(d), D, ptr(x0), ptr(x1), ptr(w_all), ptr(bias), ptr(y), ptr(stats),
+                                       C.c_long(stride), stream())
     if rc == FI_ERR_UNSUPPORTED:
         return False
     _chk(rc, "fi_conv3d_fwd_fused")
@@ -675,7 +682,10 @@ def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):
 def conv3d_dgrad_fused(dy, wt_all, d0, d1, *, ksize):
     N, D, H, W, cout = _dev(dy).shape
     d = FiConv(dt(dy.dtype), N, H, W, ksize, cout, 0, d0.shape[4], 0 if d1 is None else d1.shape[4], 0, 0, 0)
-    rc = lib().fi_conv3d_dgrad_fused(C.byref(d), D, ptr(dy), ptr(wt_all), ptr(d0), ptr(d1), stream())
+    cin, vox = d0.shape[4] + (0 if d1 is None else d1.shape[4]), N * D * H * W
+    with _timed("conv3d_dgrad", (str(dy.dtype)[6:], N, D, H, W, cout, cin, ksize), 2.0 * vox * cin * cout * ksize ** 3,
+                vox * (cin + cout) * _esz(dy) + cin * cout * ksize ** 3 * _esz(dy)):
+        rc = lib().fi_conv3d_dgrad_fused(C.byref(d), D, ptr(dy), ptr(wt_all), ptr(d0), ptr(d1), stream())
     if rc == FI_ERR_UNSUPPORTED:
         return False
     _chk(rc, "fi_conv3d_dgrad_fused")
@@ -685,7 +695,10 @@ def conv3d_dgrad_fused(dy, wt_all, d0, d1, *, ksize):
 def conv3d_dgrad(dy, wt_taps, d0, d1, *, ksize):
     N, D, H, W, cout = _dev(dy).shape
     d = FiConv(dt(dy.dtype), N, H, W, ksize, cout, 0, d0.shape[4], 0 if d1 is None else d1.shape[4], 1, 1, 0)
-    _chk(lib().fi_conv3d_dgrad(C.byref(d), D, ptr(dy), _taps_array(wt_taps), ptr(d0), ptr(d1), stream()), "fi_conv3d_dgrad")
+    cin, vox = d0.shape[4] + (0 if d1 is None else d1.shape[4]), N * D * H * W
+    with _timed("conv3d_dgrad", (str(dy.dtype)[6:], N, D, H, W, cout, cin, ksize, "taps"), 2.0 * vox * cin * cout * ksize ** 3,
+                vox * (cin + cout) * _esz(dy) + cin * cout * ksize ** 3 * _esz(dy)):
+        _chk(lib().fi_conv3d_dgrad(C.byref(d), D, ptr(dy), _taps_array(wt_taps), ptr(d0), ptr(d1), stream()), "fi_conv3d_dgrad")
 
 
 def conv3d_wgrad(x0, x1, dy, dw_taps, dbias, *, ksize):
@@ -697,8 +710,30 @@ def conv3d_wgrad(x0, x1, dy, dw_taps, dbias, *, ksize):
     if nbytes < 0:
         _chk(int(nbytes), "fi_conv3d_wgrad_workspace")
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x0.device)      # caller-owned workspace
-    _chk(lib().fi_conv3d_wgrad(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_taps), ptr(dbias), ptr(ws), C.c_long(nbytes),
-                               stream()), "fi_conv3d_wgrad")
+    cin, co, vox = c0 + c1, dy.shape[4], N * D * H * W
+    with _timed("conv3d_wgrad", (str(x0.dtype)[6:], N, D, H, W, cin, co, ksize), 2.0 * vox * cin * co * ksize ** 3,
+                vox * (cin + co) * _esz(x0) + cin * co * ksize ** 3 * 4):
+        _chk(lib().fi_conv3d_wgrad(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_taps), ptr(dbias), ptr(ws), C.c_long(nbytes),
+                                   stream()), "fi_conv3d_wgrad")
+
+
+def conv3d_wgrad_fused(x0, x1, dy, dw_all, dbias, *, ksize):
+    """One-launch 3x3x3 filter gradient: dw_all fp32 [cout][9][3][cin] (added to).  -> False when the shape is not covered."""
+    N, D, H, W, c0 = _dev(x0).shape
+    c1 = 0 if x1 is None else x1.shape[4]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[4], 0, 0, 0, 0)
+    nbytes = lib().fi_conv3d_wgrad_fused_workspace(C.byref(d), D)
+    if nbytes == FI_ERR_UNSUPPORTED:
+        return False
+    if nbytes < 0:
+        _chk(int(nbytes), "fi_conv3d_wgrad_fused_workspace")
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x0.device)      # caller-owned workspace
+    cin, co, vox = c0 + c1, dy.shape[4], N * D * H * W
+    with _timed("conv3d_wgrad", (str(x0.dtype)[6:], N, D, H, W, cin, co, ksize, "fused"), 2.0 * vox * cin * co * ksize ** 3,
+                vox * (cin + co) * _esz(x0) + cin * co * ksize ** 3 * 4):
+        _chk(lib().fi_conv3d_wgrad_fused(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_all), ptr(dbias), ptr(ws),
+                                         C.c_long(nbytes), stream()), "fi_conv3d_wgrad_fused")
+    return True
 
 
 def convtranspose2x_fwd(x, w_packed, bias_taps, packed, y, N, D, H, W, cin, cout, three_d):

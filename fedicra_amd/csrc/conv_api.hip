@@ -363,12 +363,12 @@ struct WgradPlan {
   int nfo, nfi, nco, nci, th, tilesX, tilesY, sb;
   size_t part_stride;
 };
-static int plan_wgrad(const FiConv* d, WgradPlan* p) {
+static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   if (!d) return FI_ERR_NULL;
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   if (d->ksize != 1 && d->ksize != 3) return FI_ERR_UNSUPPORTED;
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->c0 < 1 || d->c1 < 0 || d->co0 < 1) return FI_ERR_SHAPE;
-  const int cin = d->c0 + d->c1, cout = d->co0;
+  const int cin = (depth > 0 ? 3 : 1) * (d->c0 + d->c1), cout = d->co0;       // depth > 0: the depth taps are channel groups
   p->quad = (cin >= 32 && cout >= 32) ? 1 : 0;
   if (p->quad) {
     p->nfo = p->nfi = 2;
@@ -401,7 +401,7 @@ extern "C" long fi_conv2d_wgrad_workspace(const FiConv* d) {
 
 static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw, float* dbias,
                       void* workspace, long workspace_bytes, int reduce_now, int* slices_out, long* stride_out,
-                      void* stream);
+                      void* stream, int depth = 0);
 
 extern "C" int fi_conv2d_wgrad(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw,
                                float* dbias, void* workspace, long workspace_bytes, void* stream) {
@@ -479,13 +479,13 @@ extern "C" int fi_wgrad_reduce_multi(const long long* table, int ntensors, int n
 
 static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw, float* dbias,
                       void* workspace, long workspace_bytes, int reduce_now, int* slices_out, long* stride_out,
-                      void* stream) {
+                      void* stream, int depth) {
   if (!d || !x0 || !dy || !dw) return FI_ERR_NULL;
   WgradPlan p;
-  const int rc = plan_wgrad(d, &p);
+  const int rc = plan_wgrad(d, &p, depth);
   if (rc) return rc;
   if (d->c1 > 0 && !x1) return FI_ERR_NULL;
-  const int cin = d->c0 + d->c1, cout = d->co0;
+  const int cin = (depth > 0 ? 3 : 1) * (d->c0 + d->c1), cout = d->co0;
   if (workspace && workspace_bytes < (long)(p.part_stride * p.sb * sizeof(float))) return FI_ERR_SHAPE;
   WgradArgs a;
   a.x0 = x0;
@@ -506,6 +506,7 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   a.nco = p.nco;
   a.nci = p.nci;
   a.spatialBlocks = p.sb;
+  a.depth = depth;
 #ifdef FI_TRACE
   a.trace = g_trace;
 #endif
@@ -644,6 +645,35 @@ extern "C" long fi_conv3d_wgrad_workspace(const FiConv* d, int D) {
   FiConv s = *d;
   s.N = D;
   return fi_conv2d_wgrad_workspace(&s);
+}
+
+// The 3x3x3 filter gradient as ONE launch over all slices of all volumes (conv_wgrad*_kernel with WgradArgs.depth): the depth
+// taps are channel groups of the input side, dw_all fp32 [cout][9][3][c0 + c1] = the layout of fi_conv3d_fwd_fused's operand,
+// ADDED to (caller zeroes), dbias fp32 [cout] or NULL.  The per-tap form below is 3 N launches + 3 N slice reductions per
+// convolution (40 % of a unet_3D iteration at 2 x 128^3).  Whole-vector channel counts only: FI_ERR_UNSUPPORTED otherwise.
+static int conv3d_wgrad_fused_ok(const FiConv* d, int D) {
+  if (!d) return FI_ERR_NULL;
+  const int vg = d->dtype == FI_F32 ? 4 : 8;
+  if (d->ksize != 3 || D < 1 || d->c0 % vg || d->c1 % vg || d->co0 % vg) return FI_ERR_UNSUPPORTED;
+  if ((long)d->N * D > 0x7fffffffL) return FI_ERR_SHAPE;
+  return 0;
+}
+extern "C" long fi_conv3d_wgrad_fused_workspace(const FiConv* d, int D) {
+  if (int rc = conv3d_wgrad_fused_ok(d, D)) return rc;
+  FiConv s = *d;
+  s.N = d->N * D;
+  WgradPlan p;
+  if (int rc = plan_wgrad(&s, &p, D)) return rc;
+  return (long)(p.part_stride * p.sb * sizeof(float));
+}
+extern "C" int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_all,
+                                     float* dbias, void* workspace, long workspace_bytes, void* stream) {
+  if (!d || !x0 || !dy || !dw_all || !workspace) return FI_ERR_NULL;
+  if (int rc = conv3d_wgrad_fused_ok(d, D)) return rc;
+  if (d->c1 > 0 && !x1) return FI_ERR_NULL;
+  FiConv s = *d;
+  s.N = d->N * D;
+  return wgrad_impl(&s, x0, x1, dy, dw_all, dbias, workspace, workspace_bytes, 1, nullptr, nullptr, stream, D);
 }
 
 // dw_taps: fp32 [kd][cout][k][k][cin] (one 2D filter gradient per depth tap), dbias fp32 [cout] or NULL; both ADDED to.

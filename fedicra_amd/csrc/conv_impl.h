@@ -2187,10 +2187,26 @@ struct WgradArgs {
   int N, H, W;
   int c0, c1, cout;
   int tilesX, tilesY, nco, nci, spatialBlocks;
+  int depth;            // > 0: 3x3x3 filter gradient in ONE launch -- an "image" is a slice of a volume of `depth` slices, the three
+                        // depth taps are channel groups of the input side (group kd of the c0 + c1 channels reads slice n + kd - 1,
+                        // zero outside the volume): dw [cout][9][3][c0 + c1], the layout of the one-launch forward operand
 #ifdef FI_TRACE
   long long* trace;
 #endif
 };
+
+// load_cat_clamped for the input side of the one-launch 3D filter gradient: channel ci of the 3 (c0 + c1)-wide contraction
+// belongs to depth tap kd = ci / (c0 + c1) and is read from slice n + kd - 1 of the same volume.
+template <typename T>
+__device__ __forceinline__ typename DT<T>::vec_t load_cat_depth(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+                                                                int c1, int n, int gy, int gx, int H, int W, int ci,
+                                                                bool live, int depth) {
+  const int cr = c0 + c1;
+  const int kd = ci >= 2 * cr ? 2 : (ci >= cr ? 1 : 0);
+  const int d = n % depth + kd - 1;
+  const bool ok = live && ci < 3 * cr && d >= 0 && d < depth;
+  return load_cat_clamped<T>(x0, x1, c0, c1, ok ? n + kd - 1 : n, gy, gx, H, W, ok ? ci - kd * cr : 0, ok);
+}
 
 #ifdef FI_TRACE
 #define FI_TR_BEGIN()                                                                                       \
@@ -2295,7 +2311,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
-  const int cin = a.c0 + a.c1, cout = a.cout;
+  const int cin = (a.depth > 0 ? 3 : 1) * (a.c0 + a.c1), cout = a.cout;
   int bid = blockIdx.x;
   const int cit = bid % a.nci;
   bid /= a.nci;
@@ -2335,8 +2351,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int ii = i < NXV ? i : 0;
         const int v = ii % VPX, pix = ii / VPX;
         const int py = pix / XW, px = pix % XW;
-        val = load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
-                                  cit * BCI + v * VG, i < NXV);
+        val = a.depth > 0 ? load_cat_depth<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                              cit * BCI + v * VG, i < NXV, a.depth)
+                          : load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                                cit * BCI + v * VG, i < NXV);
       } else {
         memset(&val, 0, sizeof(val));
         if (i < NXV) {
@@ -2534,7 +2552,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
   const int qo = wave >> 1, qi = wave & 1;
-  const int cin = a.c0 + a.c1, cout = a.cout;
+  const int cin = (a.depth > 0 ? 3 : 1) * (a.c0 + a.c1), cout = a.cout;
   int bid = blockIdx.x;
   const int cit = bid % a.nci;
   bid /= a.nci;
@@ -2565,8 +2583,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
         const int ii = i < NXV ? i : 0;
         const int v = ii % VPX, pix = ii / VPX;
         const int py = pix / XW, px = pix % XW;
-        val = load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
-                                  cit * BC + v * VG, i < NXV);
+        val = a.depth > 0 ? load_cat_depth<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                              cit * BC + v * VG, i < NXV, a.depth)
+                          : load_cat_clamped<T>(x0, x1, a.c0, a.c1, n, ty * TH + py - HALO, tx * 16 + px - HALO, H, W,
+                                                cit * BC + v * VG, i < NXV);
       } else {
         memset(&val, 0, sizeof(val));
         if (i < NXV) {

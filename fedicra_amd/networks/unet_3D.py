@@ -207,9 +207,8 @@ class unet_3D_lc(unet_3D):
 
         def gate(center):
             B, d, h, w, C = center.shape
-            emb = torch.zeros((B, self.n_client), device=center.device)
-            emb[:, who] = 1
-            y, hmap = self.pcs_list[0]._run(center.reshape(B, d * h, w, C), emb)    # pooled over the whole volume
+            idx = torch.full((B,), int(who), dtype=torch.int32, device=center.device)        # one-hot row `who` as its index
+            y, hmap = self.pcs_list[0]._run(center.reshape(B, d * h, w, C), idx)    # pooled over the whole volume
             hm.append(hmap)
             return y.reshape(B, d, h, w, C)
         final, enc, dec = self._trunk(inputs, gate)

@@ -146,10 +146,20 @@ class _Conv3d(Function):
             dx0 = d0 if need_x0 else None
             dx1 = d1 if need_x1 else None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gwk = torch.zeros((kd, cout, ksize, ksize, cin), dtype=torch.float32, device=dev)
             gb = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            L.conv3d_wgrad(x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous(), gwk, gb, ksize=ksize)
-            gw = gwk.permute(1, 4, 0, 2, 3).contiguous()               # [Cout,Cin,kD,kH,kW]
+            x0c, x1c, dyc = x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous()
+            gw = None
+            if kd == 3 and ksize == 3:
+                # ONE launch over all slices of all volumes, the depth taps as channel groups of the input side
+                gall = torch.zeros((cout, ksize, ksize, kd, cin), dtype=torch.float32, device=dev)       # [Cout][9][3][Cin]
+                if L.conv3d_wgrad_fused(x0c, x1c, dyc, gall, gb, ksize=ksize):
+                    gw = gall.permute(0, 4, 3, 1, 2).contiguous()      # [Cout,Cin,kD,kH,kW]
+                elif gb is not None:
+                    gb.zero_()
+            if gw is None:
+                gwk = torch.zeros((kd, cout, ksize, ksize, cin), dtype=torch.float32, device=dev)
+                L.conv3d_wgrad(x0c, x1c, dyc, gwk, gb, ksize=ksize)
+                gw = gwk.permute(1, 4, 0, 2, 3).contiguous()           # [Cout,Cin,kD,kH,kW]
         return dx0, dx1, gw, gb, None, None
 
 

@@ -163,6 +163,12 @@ int fi_conv3d_dgrad_fused(const FiConv* d, int D, const void* dy, const void* wt
 long fi_conv3d_wgrad_workspace(const FiConv* d, int D);
 int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_taps, float* dbias,
                     void* workspace, long workspace_bytes, void* stream);
+/* The same filter gradient in ONE launch (whole-vector channel counts; FI_ERR_UNSUPPORTED otherwise): dw_all fp32
+ * [cout][9][3][c0 + c1] -- depth taps as channel groups, the layout of fi_conv3d_fwd_fused's operand -- and dbias are ADDED to;
+ * workspace >= fi_conv3d_wgrad_fused_workspace(d, D) bytes (deterministic two-stage reduction). */
+long fi_conv3d_wgrad_fused_workspace(const FiConv* d, int D);
+int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_all, float* dbias,
+                          void* workspace, long workspace_bytes, void* stream);
 
 /* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
  * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of

@@ -282,9 +282,11 @@ def test_config3_unet_lc_512_forward_matches_oracle():
 C4_LAYERS = [(128, 16, 0, 16), (64, 32, 0, 32), (32, 64, 0, 64), (32, 64, 32, 32), (64, 32, 16, 16)]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("layer", C4_LAYERS, ids=lambda l: "{}^3_{}+{}to{}".format(*l))
-def test_config4_conv3d_instancenorm_at_full_size_bf16(layer):
-    """configs[3] (4 clients, 3D U-Net, 2 x 128^3 patches, bf16) at its own layer sizes, through size-independent properties:
+def test_config4_conv3d_instancenorm_at_full_size_bf16(layer, dtype):
+    """configs[3] (4 clients, 3D U-Net, 2 x 128^3 patches, bf16) and configs[4]'s storage type (fp16) at the same layer sizes,
+    through size-independent properties:
     (a) the adjoint identities tying the depth-sliced forward, dgrad and wgrad together -- <conv(x; w), g> = <x, dgrad(g)>
     = <w, wgrad(x, g)> (bias 0), all three products of 16-bit operands accumulated in fp32, compared in fp64 to bf16 output
     rounding (2^-8 per element, random signs: relative 4e-3 on sums of 1e6+ terms);  (b) the fused InstanceNorm3d + ReLU
@@ -293,7 +295,7 @@ def test_config4_conv3d_instancenorm_at_full_size_bf16(layer):
     whole volume to 0.5 % / 1 %."""
     from fedicra_amd import ops3d
     S, c0, c1, cout = layer
-    Nb, cin, dt = 2, c0 + c1, torch.bfloat16
+    Nb, cin, dt = 2, c0 + c1, (torch.bfloat16 if dtype == "bf16" else torch.float16)
     conv = torch.nn.Conv3d(cin, cout, 3, 1, 1).to(DEV)
     with torch.no_grad():
         conv.weight.copy_((rnd(*conv.weight.shape, seed=21) * (1.7 / np.sqrt(27 * cin))).to(dt).float())

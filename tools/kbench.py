@@ -17,9 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-class FiConv(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "ksize", "c0", "c1", "co0", "co1", "accumulate0",
-                                       "accumulate1", "y_f32")]
+from fedicra_amd._lib import FiConv  # noqa: E402  (the C struct, incl. the chunk-major second operand fields)
 
 
 # (H, c0, c1, cout, k) of every conv in UNet(1,2) at 256^2 (encoder, decoder), batch 12
