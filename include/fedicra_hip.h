@@ -47,7 +47,8 @@ extern "C" {
  * points included): the host mirror (fedicra_amd/_lib.py) refuses a library whose version differs from the header it was
  * written against, so a stale or foreign libfedicra_hip.so fails at load, not by passing a pointer in the wrong slot.
  *   1: rounds 1-2 (fi_ala_update gained `skip` without a bump -- the reason for this note)
- *   2: round 3 (fi_lc_loss_*, fi_pcs_*, consumer-side up-sampling in FiInXform, this check) */
+ *   2: round 3 (FiConv.w16 / w16_rows + fi_pack_weights modes 2 / 3 and the 8-column pack table, fi_conv_weight_chunk16,
+ *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check) */
 #define FI_ABI_VERSION 2
 int fi_abi_version(void);
 
