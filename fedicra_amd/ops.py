@@ -94,6 +94,7 @@ class _Context:
         self.seed_offset = None        # device int32[1] added to every RNG seed (training-iteration counter)
         self.call_idx = {}             # uid -> how many times this layer drew a mask in the current iteration
         self.graph_tables = []         # pinned + device reduce tables of the steps captured under this context
+        self.bn_events = None          # dict while the LC forwards run beside the client's own forward (see probe_after)
 
 
 _ctx = _Context()
@@ -408,6 +409,10 @@ class _ConvBNAct(Function):
         # BN finalize (batch statistics -> scale/shift, running-stat update) + apply + activation + dropout: 1 launch
         L.bn_fused_fwd(y, z, stats, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                        bn.eps, training, coef, slope, drop)
+        if _ctx.bn_events is not None and training:
+            ev = torch.cuda.Event()                 # this layer's running statistics have taken the own forward's update
+            ev.record()
+            _ctx.bn_events[id(bn)] = ev
         ctx.save_for_backward(x0, x1, wk, y, coef)
         ctx.mod, ctx.bn, ctx.ksize, ctx.slope, ctx.drop, ctx.training = mod, bn, ksize, slope, drop, training
         ctx.need_x0 = ctx.needs_input_grad[0]
@@ -665,6 +670,17 @@ class RawAct:
         self.y, self.coef, self.slope, self.shared = y, coef, slope, shared
 
 
+def probe_after(bn):
+    """The batched LC forwards may run on a second stream beside the client's own forward (flower_pCE_2D._iteration).  The
+    reference makes them AFTER it (flower_pCE_2D.py:106,128-139), and a BatchNorm's running statistics are an order-dependent
+    recursion (r <- 0.9 r + 0.1 b): before the probe moves a layer's statistics it waits for the event the own forward recorded
+    behind its update of the same layer."""
+    if _ctx.bn_events is not None:
+        ev = _ctx.bn_events.get(id(bn))
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
 def probe_ready():
     """The batched probe forward draws its masks from the device RNG stream of the current context (a training client's
     iteration counter); parity runs that feed host masks take the sequential path instead."""
@@ -707,6 +723,7 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
     y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev) if store else None
     L.conv2d_fwd_fused(x0, t0, x1, t1, wp, conv.bias, y, stats, ksize=ksize, groups=groups, cout=cout, shared0=shared0)
     coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
+    probe_after(bn)
     L.bn_finalize_groups(stats, groups, float((N // groups) * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, bn.momentum, bn.eps, coef)
     return RawAct(y, coef, slope) if store else None
@@ -724,6 +741,7 @@ def probe_first_conv_bn(x, conv, bn, slope, groups):
     y = torch.empty((N, H, W, cout), dtype=x.dtype, device=dev)
     L.conv2d_fwd(x, None, wp, conv.bias, y, None, stats, ksize=ksize)
     coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
+    probe_after(bn)
     L.bn_finalize_groups(stats, groups, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, bn.momentum, bn.eps, coef, shared=True)
     return RawAct(y, coef, slope, shared=True)

@@ -281,3 +281,38 @@ def test_pcs_gate_and_lc_total_kernels_against_the_module_arithmetic():
     (tot * 3.0).backward()
     assert abs(float(tot) - float(tot_ref)) < 1e-6 and abs(float(lc) - float(lc_ref)) < 1e-6 and not lc.requires_grad
     assert float((h2.grad.cpu() - h.grad).abs().max()) < 1e-9 and abs(float(ce2.grad) - 3.0) < 1e-7
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lc_forwards_beside_the_own_forward_leave_the_state_of_the_in_line_order(use_graph):
+    """The K-1 no-grad LC forwards on a second stream beside the client's own forward (flower_pCE_2D._iteration) against the
+    in-line order of the reference (own forward, then the loop, flower_pCE_2D.py:106,128-139): same losses, same parameters,
+    same BatchNorm running statistics and counters after a round of head- and body-phase iterations -- the per-layer events
+    keep the order-dependent running-statistics recursion in the reference's order (fp64 statistic sums are atomic: fp32
+    round-off apart)."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks import net_factory
+    from helpers import loader
+    res = []
+    for beside in (False, True):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=4, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=5, rep_iters=2, alpha=1.0,
+                                  snapshot_path=None, use_graph=use_graph)
+        torch.manual_seed(2022)
+        ops.manual_seed(11)
+        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
+        batches = loader(3, 4, 64, cid=1, device=DEV)
+        model = MyModel(args, net, batches, batches)
+        client = MyClient(args, model, batches, batches)
+        client.probe_beside = beside
+        cfg = {"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
+        client._train(cfg)
+        client._train(cfg)                                   # second round: the captured steps replay
+        torch.cuda.synchronize()
+        res.append((list(client.last_losses), net.flat_state.clone(), net.flat_counters.clone()))
+    (l0, s0, c0), (l1, s1, c1) = res
+    assert torch.equal(c0, c1)
+    assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=2e-5), float((s0 - s1).abs().max())
