@@ -25,8 +25,8 @@ int fi_conv_thin_bf16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStre
 int fi_conv_thin_f16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
-int fi_conv_fwd_ws2_bf16(int tr, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
-int fi_conv_fwd_ws2_f16(int tr, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws2_bf16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_ws2_f16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -78,7 +78,7 @@ static long env_ws2() {
 }
 extern "C" int fi_conv_weight_chunk16(int dtype, int ksize, int cin, int cout) {
   if (env_ws2() == 0) return 0;
-  return (dtype == FI_BF16 || dtype == FI_F16) && ksize == 3 && cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0;
+  return (dtype == FI_BF16 || dtype == FI_F16) && ksize == 3 && cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0;
 }
 
 static int pick_th(int N, int H, int W, long per_tile_mult) {
@@ -240,10 +240,28 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       const long big = (long)d->N * d->H * d->W * 2;
       const int rows = d->w16_rows > 0 ? d->w16_rows : cout;
       // pixel groups of 64 (16-row tiles) / 32 (32-row tiles) channels must not straddle the two sources
-      const bool ok32 = d->c0 % 32 == 0 && d->c1 % 32 == 0 && cin >= 32 && cout % 64 == 0 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&
-                        big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
-                        big * d->co1 < (1L << 32) && (long)rows * 9 * cin * 2 < (1L << 32);
+      const bool okb = d->c0 % 32 == 0 && d->c1 % 32 == 0 && cin >= 32 && d->co0 % 8 == 0 && d->co1 % 8 == 0 &&
+                       big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
+                       big * d->co1 < (1L << 32) && (long)rows * 9 * cin * 2 < (1L << 32);
+      const bool ok32 = okb && cout % 64 == 0;
       const bool ok16 = ok32 && d->c0 % 64 == 0 && d->c1 % 64 == 0 && cout % 128 == 0;
+      // whole filter resident in LDS (forms 3 / 4): Cout = 64 or 32 and 2 pixel groups (78 336 B) + Cin x Cout x 18 B + strip fit.
+      // Measured (profiles/r03_s_kbench2_ws2res.txt, same box): the batched fused launches of 256^2 32->32 233 -> 200 us (with
+      // dropout 359 -> 293), 256^2 64->32 385 -> 335, 128^2 64->64 146 -> 136 (with dropout 194 -> 172) against the 32-pixel-tile form
+      const bool okres = okb && (cout == 64 || cout == 32) && 78336L + (long)cin * cout * 18 + 768 <= 160 * 1024;
+      static const long res_min = env_long("FI_WS2_RES_MIN", 1024);
+      const long tiles32 = (long)d->N * fi_cdiv(d->H, 32) * fi_cdiv(d->W, 16);
+      const bool want_res = okres && (g_tune[0] == 7 ? g_tune[1] == 4 : (env_ws2() == 2 || (a.xf == 1 && tiles32 >= res_min)));
+      if (want_res) {
+        a.w = d->w16;
+        a.wrows = rows;
+        a.tilesY = fi_cdiv(d->H, 32);
+        a.nct = 1;
+        const int form = cout == 64 ? 3 : 4;
+        // 32 outputs with element dropout in the loader: runs of half the length measured 10 % ahead (329 -> 291 us, 256^2 32->32)
+        const int wgs = g_tune[3] ? (int)g_tune[3] : ((form == 4 && a.xf == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM) ? 2 : 0);
+        return d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, wgs, a, st) : fi_conv_fwd_ws2_bf16(form, wgs, a, st);
+      }
       // measured rule (FI_WS2 = 1; profiles/r03_*_kbench2_ws2*.txt): the batched fused launches that fill the persistent grid,
       // 128-channel slabs with 64-channel pixel groups -- 1.05-1.16x the 32-pixel-tile form there (64^2 128->128 160 -> 145 us,
       // 32^2 256->256 159 -> 137, head 887 -> 841); the 32-row x 64-channel shape and the 12-image launches measured level
@@ -261,7 +279,8 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
         a.wrows = rows;
         a.tilesY = fi_cdiv(d->H, tr);
         a.nct = cout / (tr == 16 ? 128 : 64);
-        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(tr, (int)g_tune[3], a, st) : fi_conv_fwd_ws2_bf16(tr, (int)g_tune[3], a, st);
+        const int form = tr == 16 ? 1 : 2;
+        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, (int)g_tune[3], a, st) : fi_conv_fwd_ws2_bf16(form, (int)g_tune[3], a, st);
         return rc;
       }
     }

@@ -54,24 +54,31 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
 #define FI_T2(tag) do { } while (0)
 #endif
 
-template <typename T, int TR, int BN, int XF>
+// WR = 1 ("weights resident"): layers whose WHOLE filter fits beside two pixel groups (Cin * Cout * 18 bytes <= ~74 KB: 64 -> 64,
+// 64 -> 32, 32 -> 32 ...) load it once per workgroup run instead of one slab per stage -- at 32 / 64 output channels the
+// slab of a stage is as many bytes as its pixels, and the producers' fill rate is what bounds these layers.  A package is
+// then a pixel part only.  BN = 32 (one 32-channel block per consumer wave) exists for this form only.
+template <typename T, int TR, int BN, int XF, int WR>
 __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage");
-  static_assert((TR == 16 && BN == 128) || (TR == 32 && BN == 64), "8 consumer waves of 4 rows x 64 channels");
+  static_assert((TR == 16 && BN == 128 && WR == 0) || (TR == 32 && BN == 64) || (TR == 32 && BN == 32 && WR == 1),
+                "8 consumer waves of 4 rows x 64 (32) channels");
   static_assert(XF == 0 || XF == 1, "plain or transforming loader");
   constexpr int CW = 8, PT = 256;                                // consumer waves; threads of one producer team
-  constexpr int RG = TR / 4, CG = BN / 64;                       // consumer grid: row groups x 64-channel groups
+  constexpr int RG = TR / 4, CG = BN >= 64 ? BN / 64 : 1;        // consumer grid: row groups x channel groups
+  constexpr int CWC = BN / CG, NCB = CWC / 32;                   // channels / 32-channel accumulator blocks of a consumer wave
   constexpr int XH = TR + 2, XW = 18, KK = 9, CK = 16, VG = 8;
   constexpr int GC = TR == 16 ? 64 : 32;                         // channels of a pixel GROUP (what the loader fetches per pixel)
   constexpr int NQ = GC / CK, NP = GC / VG;                      // stages per group; 16-byte pieces per staged pixel
   constexpr int XG = XH * XW * NP * 16;                          // bytes of a group's halo tile
   constexpr int WROW = KK * CK * 2, WT = BN * WROW;              // bytes of a staged weight row (288, unpadded) / slab
-  constexpr int O_W = 2 * XG, O_STRIP = 2 * XG + 2 * WT;         // LDS map: [2] pixel groups, [2] weight slabs, [CG] strips
-  static_assert(O_STRIP + CG * 192 * 4 <= 160 * 1024, "LDS");
+  constexpr int O_W = 2 * XG;                                    // LDS map: [2] pixel groups, [2 | all] weight slabs, [CG] strips
+  static_assert(O_W + 2 * WT + CG * 192 * 4 <= 160 * 1024, "LDS");
   typedef typename DT<T>::vec_t vec_t;
   typedef typename DT<T>::frag_t frag_t;
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   if (i_begin >= i_end) return;
   const int nchunk = cin / CK, ngrp = cin / GC;
   const int nstage = (i_end - i_begin) * nchunk, ngroups = (i_end - i_begin) * ngrp;
+  const int o_strip = O_W + (WR ? nchunk : 2) * WT;
 
   constexpr unsigned esz = 2;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 
     struct Set {
       vec_t x[XPASS];
-      vec_t w[WPASS];
+      vec_t w[WR ? 1 : WPASS];
       float sc[XF != 0 ? VG : 1], sh[XF != 0 ? VG : 1];         // this thread's 8 scale / shift values (its piece of the group)
       unsigned flags;           // bit p: pass p is inside the image; bit 16: source 0; bit 17: transform active
     };
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
         float f[VG];
         VecWords<T>::unpack(raw, f);
 #pragma unroll
-        for (int j = 0; j < VG; ++j) {
+        for (int j = 0; j < VG; ++j) {                 // (packed v_pk_fma_f32 / v_pk_mul_f32 measured 10 % SLOWER per launch)
           const float v = f[j] * S.sc[j] + S.sh[j];
           f[j] = fmaxf(v, v * slope);                  // = v > 0 ? v : v * slope for 0 <= slope <= 1 (host-checked)
         }
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #if FI_WS2_DEBUG & 2
       return;
 #endif
+      if constexpr (WR) return;
       // chunk-major operand: [chunk][wrows][9][16]: the slab is one contiguous block starting at row it.ct * BN
       const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(it.ct * BN)) * (KK * 2) + (unsigned)ptid) * 16u;
       const __amdgpu_buffer_rsrc_t rw = rsrc(a.w, (unsigned)__builtin_amdgcn_readfirstlane((int)(live ? wbytes : 0u)));
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #if FI_WS2_DEBUG & 4
       return;
 #endif
+      if constexpr (WR) return;
       char* const wb = smem + O_W + buf * WT;
 #pragma unroll
       for (int p = 0; p < WPASS; ++p) {
@@ -380,6 +390,30 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       commit_x(itx, grp_of(itx, cgx), qx, gi & 1);
       commit_w(k & 1);
     };
+    if constexpr (WR) {
+      // the whole filter, once: [chunk][BN rows][288 bytes], rows swizzled like a streamed slab (host: one slab, Cout == BN)
+      const int pt = tid - CW * 64, total = nchunk * BN * (KK * 2);
+      const __amdgpu_buffer_rsrc_t rw = rsrc(a.w, wbytes);
+      for (int v0 = pt; v0 < total; v0 += 4 * 2 * PT) {
+        vec_t t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int v = v0 + j * 2 * PT;
+          const int chunk = v / (BN * KK * 2), r = v - chunk * (BN * KK * 2);
+          const unsigned src = ((unsigned)chunk * (unsigned)a.wrows * (KK * 2) + (unsigned)r) * 16u;
+          t[j] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rw, v < total ? src : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int v = v0 + j * 2 * PT;
+          if (v < total) {
+            const int chunk = v / (BN * KK * 2), r = v - chunk * (BN * KK * 2);
+            const int co = r / (KK * 2), q18 = r - co * (KK * 2);
+            *reinterpret_cast<vec_t*>(smem + O_W + chunk * WT + co * WROW + (q18 >> 1) * 32 + ((((q18 & 1) ^ (co >> 3)) & 1) << 4)) = t[j];
+          }
+        }
+      }
+    }
     if (team == 0) {
       issue();
       commit();                                                  // package 0: slab 0 + the LAST part of group 0
@@ -413,7 +447,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     const int rg = wave % RG, cgp = wave / RG;                   // row group, 64-channel group of this wave
     const int n32 = lane & 31, hh = lane >> 5;
     const int prow = n32 >> 4, pcol = n32 & 15;
-    const int rowbase = rg * 4, cobase = cgp * 64;
+    const int rowbase = rg * 4, cobase = cgp * CWC;
     // fragment addresses: lane constants (+ the chunk's xor, + the group buffer) + immediates.
     //   pixel (row, col), piece k = 2 * chunk + half:  ((row * 18 + col) * NP + (k ^ ((col >> 1) & (NP - 1)))) * 16
     //   weight row co, tap t, half h:                  co * 288 + t * 32 + ((h ^ (co >> 3)) & 1) * 16
@@ -427,18 +461,18 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc(
         a.y1, 0, (a.y1 && a.co1) ? (unsigned)a.N * hw * (unsigned)a.co1 * esz : 0u, 0x00020000);
 
-    f32x16 acc[2][2];                                            // [pixel pair: rows 0-1 / 2-3 of the wave][32-channel block]
+    f32x16 acc[2][NCB];                                          // [pixel pair: rows 0-1 / 2-3 of the wave][32-channel block]
 
     auto mma = [&](int wbuf, int gbuf, int cq) __attribute__((always_inline)) {
       const char* const sw = smem + wbuf * WT;
       unsigned px[3];
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx) px[sx] = (pre[sx] ^ (unsigned)(cq << 5)) + (unsigned)(gbuf * XG);
-      frag_t P[2][2], Wf[2][2];
+      frag_t P[2][2], Wf[2][NCB];
       auto fetch = [&](int t, int q) __attribute__((always_inline)) {
         const int r = t / 3, sx = t % 3;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) Wf[q][cb] = *reinterpret_cast<const frag_t*>(sw + wb + cb * (32 * WROW) + t * 32);
+        for (int cb = 0; cb < NCB; ++cb) Wf[q][cb] = *reinterpret_cast<const frag_t*>(sw + wb + cb * (32 * WROW) + t * 32);
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
           P[q][pp] = *reinterpret_cast<const frag_t*>(smem + px[sx] + (2 * pp + r) * (XW * NP * 16));
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) acc[pp][cb] = mfma32(Wf[t & 1][cb], P[t & 1][pp], acc[pp][cb]);
+          for (int cb = 0; cb < NCB; ++cb) acc[pp][cb] = mfma32(Wf[t & 1][cb], P[t & 1][pp], acc[pp][cb]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -459,13 +493,13 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     // one strip per 64-channel group, shared by its row-group waves: [sum 64][sum of squares 64][bias 64] floats.  The waves
     // ADD their per-tile totals (ds_add_f32); the row-group-0 wave clears / flushes it and loads the bias at the START of a
     // tile -- at least one stage barrier away from the adds on either side (a tile has >= 2 stages).
-    float* const strip = reinterpret_cast<float*>(smem + O_STRIP) + cgp * 192;
+    float* const strip = reinterpret_cast<float*>(smem + o_strip) + cgp * 192;
     auto stats_clear = [&]() __attribute__((always_inline)) { strip[lane] = strip[64 + lane] = 0.f; };
     auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
       if (!a.stats) return;
       const int slot = (blockIdx.x * CG + cgp) & (FI_STATS_SLOTS - 1);
       const int co = ct * BN + cobase + lane;
-      if (co < cout) {
+      if (lane < CWC && co < cout) {
         double* const dst = &a.stats[(size_t)grp * a.stats_gstride + ((size_t)slot * cout + co) * 2];
         atomicAdd(dst, (double)strip[lane]);
         atomicAdd(dst + 1, (double)strip[64 + lane]);
@@ -473,46 +507,55 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     };
     auto load_bias = [&](int ct) __attribute__((always_inline)) {
       const int co = ct * BN + cobase + lane;
-      strip[128 + lane] = (a.bias && co < cout) ? a.bias[co] : 0.f;
+      strip[128 + lane] = (a.bias && lane < CWC && co < cout) ? a.bias[co] : 0.f;
     };
 
+    // Epilogue of a tile.  Per 32-channel block a lane holds, for its pixel column, 16 channels x 2 pixel rows (pp): bias,
+    // rounding and the per-lane statistics partials are PACKED fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma on register
+    // pairs); the 16 sums + 16 sums of squares are then reduced over the 32 lanes of the half-wave by a TRANSPOSING
+    // butterfly -- each level pairs two values, a lane keeps one of the pair and adds its partner's copy of it
+    // (v_permlane16_swap for the row pair, then DPP row mirror / half-row mirror / quad xor 2 / quad xor 1), so the value
+    // count halves as the lane sets double: per block 16 swaps + ~60 adds / selects instead of 128 DPP adds, and two
+    // ds_add_f32 of 32 lanes instead of 16 of four.  (Half a block -- 8 registers -- at a time: the whole block's 32 partials
+    // beside the accumulators do not fit 128 registers.)  (tools/ws2_trace.py: the epilogue was 3 800 cycles of a 10 900-cycle tile on the
+    // 32 -> 32 layers, 7 300 of 16 800 at 64 -> 64.)
+#define FI_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
     auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
       const int gx = it.tx * 16 + pcol;
       const bool colok = gx < W;
+      const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
-          // the two 4-channel groups j = 2 jp, 2 jp + 1 of this lane: channels cobase + cb * 32 + 8 j + 4 hh + (0..3)
+          // the two 4-channel groups j = 2 jp + u of this lane: channels cobase + cb * 32 + 8 j + 4 hh + (0..3), registers 4 j + r
           float4 bv[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) bv[u] = *reinterpret_cast<const float4*>(&strip[128 + cb * 32 + 8 * (2 * jp + u) + 4 * hh]);
-          float ps[2][4], pq[2][4];
+          f2 S[4], Q[4];                                         // [register pair 2 u + r / 2]: sums over the wave's pixel rows
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ps[u][r] = pq[u][r] = 0.f;
+          for (int m = 0; m < 4; ++m) S[m] = Q[m] = f2{0.f, 0.f};
           const int cg = it.ct * BN + cobase + cb * 32 + 8 * (2 * jp + hh);     // the 8 channels this lane stores
           const bool second = cg >= a.co0;
 #pragma unroll
           for (int pp = 0; pp < 2; ++pp) {
             const int gy = it.ty * TR + rowbase + 2 * pp + prow;
             const bool okp = colok && gy < H;
-            const float mk = okp ? 1.f : 0.f;
+            const float mk1 = okp ? 1.f : 0.f;                   // tile overhang does not count (and is not stored)
+            const f2 mk = {mk1, mk1};
             v2u q[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-              const float bvr[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
-              float v[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = acc[pp][cb][4 * (2 * jp + u) + r] + bvr[r];
+              const int k0 = 4 * (2 * jp + u);
+              f2 v01 = {acc[pp][cb][k0], acc[pp][cb][k0 + 1]}, v23 = {acc[pp][cb][k0 + 2], acc[pp][cb][k0 + 3]};
+              v01 = (v01 + f2{bv[u].x, bv[u].y}) * mk;
+              v23 = (v23 + f2{bv[u].z, bv[u].w}) * mk;
+              float v[4] = {v01.x, v01.y, v23.x, v23.y};
               q[u] = __builtin_bit_cast(v2u, Quad<T>::pack(v));  // v := the values as stored
 #if !(FI_WS2_DEBUG & 32)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                ps[u][r] += v[r] * mk;                           // tile overhang does not count
-                pq[u][r] += (v[r] * mk) * v[r];
-              }
+              v01 = f2{v[0], v[1]}, v23 = f2{v[2], v[3]};
+              S[2 * u] += v01, S[2 * u + 1] += v23;
+              Q[2 * u] += v01 * v01, Q[2 * u + 1] += v23 * v23;
 #endif
             }
             if (a.y0) {
@@ -532,33 +575,38 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
           }
 #if !(FI_WS2_DEBUG & 32)
           if (a.stats) {
-            // over the 16 lanes of a row (DPP), then over the two rows of the half-wave: one row swap + add serves a PAIR of
-            // values (x' = [x0 y0 x2 y2], y' = [x1 y1 x3 y3]): the even row ends up with the first, the odd row with the second
+            // value list X = [S of register 0..7 | Q of register 0..7] (register = 4 u + r); level by level a lane keeps
+            // X[2 i + its class bit]
+            float Y[8], Z[4], Wv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              float tot[2][2];                                   // [sum | sum of squares][channel r = prow / r = 2 + prow]
-#pragma unroll
-              for (int h2 = 0; h2 < 2; ++h2) {
-                const float x0 = fi_row16_sum(ps[u][2 * h2]), x1 = fi_row16_sum(ps[u][2 * h2 + 1]);
-                const float y0 = fi_row16_sum(pq[u][2 * h2]), y1 = fi_row16_sum(pq[u][2 * h2 + 1]);
-                const v2u sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
-                const v2u sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(y0), __float_as_uint(y1), false, false);
-                tot[0][h2] = __uint_as_float(sx.x) + __uint_as_float(sx.y);
-                tot[1][h2] = __uint_as_float(sy.x) + __uint_as_float(sy.y);
-              }
-              if (pcol == 0) {                                   // lanes 0 / 16 / 32 / 48: channel 8 j + 4 hh + 2 h2 + prow
-                const int c = cb * 32 + 8 * (2 * jp + u) + 4 * hh + prow;
-                atomicAdd(&strip[c], tot[0][0]);
-                atomicAdd(&strip[c + 2], tot[0][1]);
-                atomicAdd(&strip[64 + c], tot[1][0]);
-                atomicAdd(&strip[64 + c + 2], tot[1][1]);
-              }
+            for (int i = 0; i < 4; ++i) {                        // rows of the half-wave (prow): even row <- .x, odd row <- .y
+              const v2u s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[i].x), __float_as_uint(S[i].y), false, false);
+              const v2u s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Q[i].x), __float_as_uint(Q[i].y), false, false);
+              Y[i] = __uint_as_float(s1.x) + __uint_as_float(s1.y);
+              Y[4 + i] = __uint_as_float(s2.x) + __uint_as_float(s2.y);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                        // lane ^ 15 (row mirror), class = bit 3
+              const float keep = b3 ? Y[2 * i + 1] : Y[2 * i], give = b3 ? Y[2 * i] : Y[2 * i + 1];
+              Z[i] = keep + FI_DPP_F(give, 0x140);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                        // lane ^ 7 (half-row mirror), class = bit 2
+              const float keep = b2 ? Z[2 * i + 1] : Z[2 * i], give = b2 ? Z[2 * i] : Z[2 * i + 1];
+              Wv[i] = keep + FI_DPP_F(give, 0x141);
+            }
+            const float keep = b1 ? Wv[1] : Wv[0], give = b1 ? Wv[0] : Wv[1];  // lane ^ 2, class = bit 1
+            float U = keep + FI_DPP_F(give, 0x4E);
+            U += FI_DPP_F(U, 0xB1);                              // lane ^ 1: both lanes of the pair hold the total
+            // ... of X[8 b1 + 4 b2 + 2 b3 + prow]: b1 = sum | sum of squares, register 4 u + r = 4 b2 + 2 b3 + prow
+            if ((lane & 1) == 0)
+              atomicAdd(&strip[(b1 ? 64 : 0) + cb * 32 + 8 * (2 * jp + (b2 ? 1 : 0)) + 4 * hh + (b3 ? 2 : 0) + prow], U);
           }
 #endif
         }
       }
     };
+#undef FI_DPP_F
 
     Item it = item_at(i_begin);
     int ch = 0, cq = 0, gpar = 0, since_flush = 0;
@@ -569,7 +617,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pp][cb][i] = 0.f;
         if (rg == 0) {                                           // strip housekeeping for this 64-channel group
@@ -589,7 +637,7 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       {
         int cr = cq + rot_of(it) % NQ;                           // the chunk of its group this stage holds (producers: chunk_of)
         cr = cr >= NQ ? cr - NQ : cr;
-        mma(wbuf, gpar, cr);
+        mma(WR ? ch : wbuf, gpar, cr);
       }
 #endif
       FI_T2(5);                                                  // MFMAs issued
@@ -619,22 +667,25 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int TR, int BN>
+template <typename T, int TR, int BN, int WR>
 static int launch_conv_fwd_ws2(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
   constexpr int XH = TR + 2, XW = 18, GC = TR == 16 ? 64 : 32;
-  const size_t lds = (size_t)2 * (XH * XW * GC * 2) + (size_t)2 * (BN * 9 * 16 * 2) + (size_t)(BN / 64) * 192 * sizeof(float);
+  const int nchunk = (a.c0 + a.c1) / 16;
+  const size_t lds = (size_t)2 * (XH * XW * GC * 2) + (size_t)(WR ? nchunk : 2) * (BN * 9 * 16 * 2) +
+                     (size_t)(BN >= 64 ? BN / 64 : 1) * 192 * sizeof(float);
+  if (lds > 160 * 1024 || (WR && (a.nct != 1 || a.co0 + a.co1 != BN))) return FI_ERR_UNSUPPORTED;
   const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
   long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
   if (blocks > nitem) blocks = nitem;
   const dim3 g((unsigned)blocks), b(1024);
   if (a.xf == 0) {
-    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 0>);
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 0, WR>);
     (void)big;
-    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 0>), g, b, lds, st, a);
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 0, WR>), g, b, lds, st, a);
   } else if (a.xf == 1) {
-    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 1>);
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 1, WR>);
     (void)big;
-    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 1>), g, b, lds, st, a);
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 1, WR>), g, b, lds, st, a);
   } else {
     return FI_ERR_UNSUPPORTED;
   }

@@ -279,7 +279,7 @@ def test_pcs_gate_and_lc_total_kernels_against_the_module_arithmetic():
     h2, ce2 = h.detach().to(DEV).requires_grad_(True), ce.detach().to(DEV).requires_grad_(True)
     tot, lc = ops.lc_total(ce2, h2, others.to(DEV).reshape(-1), G, 0.5)
     (tot * 3.0).backward()
-    assert abs(float(tot) - float(tot_ref)) < 1e-6 and abs(float(lc) - float(lc_ref)) < 1e-6 and not lc.requires_grad
+    assert abs(float(tot.detach()) - float(tot_ref.detach())) < 1e-6 and abs(float(lc) - float(lc_ref.detach())) < 1e-6 and not lc.requires_grad
     assert float((h2.grad.cpu() - h.grad).abs().max()) < 1e-9 and abs(float(ce2.grad) - 3.0) < 1e-7
 
 

@@ -58,6 +58,12 @@ WS2_CASES = [
     (2, 4, 4, 256, 0, 256, 1, "none", True, False),          # the 4 x 4 map of a 64^2 input
     (36, 128, 128, 32, 0, 128, 4, "drop", True, False),      # > 8 tiles per workgroup: the strip is flushed inside a run
     (3, 40, 24, 64, 64, 128, 1, "none", False, True),        # two sources AND two destinations
+    # whole filter resident in LDS (forms 3 / 4: Cout = 64 / 32) -- cases 1, 3 and 5 above qualify as well
+    (5, 70, 40, 32, 32, 32, 1, "xf", True, False),           # 32 outputs, two sources, ragged
+    (8, 64, 64, 32, 0, 32, 4, "drop", True, False),
+    (4, 40, 40, 128, 0, 32, 2, "shared", True, False),       # 8 resident chunks
+    (40, 128, 128, 64, 0, 64, 4, "drop", True, False),       # > 8 tiles per workgroup
+    (3, 24, 56, 64, 0, 32, 1, "none", True, False),          # plain loader, bias + statistics
 ]
 
 
@@ -68,7 +74,7 @@ def test_ws2_kernel_equals_the_one_tile_kernel(dtype, case):
     to the last bit or two of the storage type; statistics are those of the stored outputs."""
     from fedicra_amd import _lib as L
     N, H, W, c0, c1, cout, G, kind, stats, two = WS2_CASES[case]
-    if dtype == "fp16" and case == 8:
+    if dtype == "fp16" and case in (8, 13):
         pytest.skip("the long-run case once is enough")
     td = TD[dtype]
     gen = torch.Generator().manual_seed(300 + case)
@@ -108,7 +114,11 @@ def test_ws2_kernel_equals_the_one_tile_kernel(dtype, case):
         L.conv_tuning(0)
         want, st_want = run()                                  # no chunk-major operand attached: the one-tile kernel
         w._fi_w16 = w16
-        for tr in ((1, 2) if cout % 128 == 0 else (2,)):
+        forms = ([1] if cout % 128 == 0 else []) + ([2] if cout % 64 == 0 else [])
+        if cout in (32, 64) and 78336 + (c0 + c1) * cout * 18 + 768 <= 160 * 1024:
+            forms.append(4)
+        assert forms
+        for tr in forms:
             for wgs in (1, 8):
                 L.conv_tuning(7, tr, 0, wgs)
                 got, st_got = run()

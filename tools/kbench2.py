@@ -68,7 +68,7 @@ def main():
     if a.ws2:
         a.ws = True
         configs = [("v1", (0, 0, 0, 0)), ("old", (2, 0, 0, 0)), ("ws2_16", (7, 1, 0, 0)), ("ws2_32", (7, 2, 0, 0)),
-                   ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2))]
+                   ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2)), ("ws2_res", (7, 4, 0, 0)), ("ws2_resw2", (7, 4, 0, 2))]
     tot = {}
     for mode in ("plain", "fused"):
         if a.only and a.only != mode:
@@ -117,7 +117,9 @@ def main():
                     continue
                 if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
                     continue
-                if cfg[0] == 7 and (not hasattr(w, "_fi_w16") or pool or (cfg[1] == 1 and cout % 128)):
+                if cfg[0] == 7 and (not hasattr(w, "_fi_w16") or pool or (cfg[1] == 1 and cout % 128) or (cfg[1] == 2 and cout % 64)):
+                    continue
+                if cfg[0] == 7 and cfg[1] == 4 and not (cout in (32, 64) and 78336 + (c0 + c1) * cout * 18 + 768 <= 160 * 1024):
                     continue
                 if cfg[0] in (4, 5, 6) and (c0 + c1 < 32 or cout <= 16 or (cfg[1] == 4 and cout <= 32) or (pool and cfg[2] == 32)):
                     continue

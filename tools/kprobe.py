@@ -20,6 +20,8 @@ def parse_cfg(s):
     if s == "thin":
         return (3, 0, 0, 0)
     import re
+    if s == "ws2r":                                      # ... with the whole filter resident in LDS (Cout 32 / 64)
+        return (7, 4, 0, 0)
     m = re.fullmatch(r"ws2t(\d+)", s)                    # 64x64-wave-tile kernel with 16- / 32-row tiles
     if m:
         return (7, {16: 1, 32: 2}[int(m.group(1))], 0, 0)
