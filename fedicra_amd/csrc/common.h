@@ -193,19 +193,18 @@ __device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
   return x ^ (uint32_t)(seed >> 32);
 }
 // Element-wise dropout draws for the 4 consecutive elements of group `group` (= flat element index / 4): ONE full
-// hash of the group index, then one multiply per element.  Integer multiplies are quarter rate on CDNA: a full hash
-// per element plus its 64-bit index arithmetic (~65 instructions per element) made the fused BN kernels ALU-bound --
-// 4 us of arithmetic for 32 elements per thread in tools traces, against 1-3 us of memory time.
+// hash of the group index and one more multiply-xorshift round give 64 mixed bits = four 16-BIT draws, returned in the
+// top halves of r[0..3] so that callers keep comparing against the 32-bit threshold (the keep probability is quantised to
+// 2^-16: 1.5e-5 relative at p = 0.05 .. 0.5).  Integer multiplies are quarter rate on CDNA and every conv / BN kernel
+// that regenerates the mask is VALU-issue-bound (tools/ws2_trace.py: a loader stage of 256^2 32->32 takes 3 200 cycles
+// without and 5 700 with dropout): per 4 elements this is 4 multiplies + ~14 other VALU ops where the per-element
+// multiply-xorshift it replaces (round 2) cost 7 + ~30, and a full hash per element ~65 instructions per element.
 __device__ __forceinline__ void fi_rand32x4(uint64_t seed, uint64_t group, uint32_t (&r)[4]) {
   const uint32_t h = fi_rand32(seed, group);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint32_t x = h + (uint32_t)(j + 1) * 0x9E3779B9u;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    r[j] = x;
-  }
+  uint32_t g = (h ^ 0x9E3779B9u) * 0x2C1B3C6Du;
+  g ^= g >> 15;
+  r[0] = h << 16, r[1] = h & 0xFFFF0000u;
+  r[2] = g << 16, r[3] = g & 0xFFFF0000u;
 }
 // keep with probability (1-p): threshold on a 32-bit uniform
 __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t drop_thresh) {

@@ -225,6 +225,21 @@ def test_dropout_rng_statistics_and_replay():
     keep = (z1 != 0).float().mean().item()
     assert abs(keep - 0.7) < 0.01
     assert abs(z1.max().item() - 1 / 0.7) < 1e-5
+    # the four draws of a 4-element group come from ONE hash (two 32-bit words, 16 bits per draw): every position keeps at the
+    # nominal rate, and positions -- of one group and of neighbouring groups -- are pairwise independent
+    big = torch.ones(8, 128, 128, 16, device=DEV)
+    for p_drop in (0.05, 0.3, 0.5):
+        zb = torch.empty_like(big)
+        lib.bn_act_fwd(big, one, zero, zb, 1.0, (lib.DROP_RNG_ELEM, p_drop, 99, None, off))
+        k = (zb != 0).float().view(-1, 2, 4)                 # [pair of groups][group][position]
+        n = k.shape[0] * 2
+        tol = 4.0 * (p_drop * (1 - p_drop) / n) ** 0.5 + 2.0 ** -15
+        rate = k.mean(dim=(0, 1))
+        assert bool(((rate - (1 - p_drop)).abs() < tol).all()), (p_drop, rate.tolist())
+        flat = k.view(-1, 8)
+        cov = (flat.t() @ flat) / flat.shape[0] - flat.mean(0)[:, None] * flat.mean(0)[None, :]
+        cov.fill_diagonal_(0.0)
+        assert float(cov.abs().max()) < 5.0 * p_drop * (1 - p_drop) / flat.shape[0] ** 0.5, (p_drop, float(cov.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
