@@ -441,6 +441,9 @@ def roofline_pass(client, a, dtype_name):
     """Eager, instrumented iterations: HIP events around every C-ABI launch on the launch stream."""
     from fedicra_amd import _lib as L
     client.use_graph = False
+    # every launch timed ALONE: the timed rounds run the K-1 LC forwards on a second stream beside the client's own forward
+    # (flower_pCE_2D.MyClient.probe_beside), where two kernels share the chip and an event pair measures both
+    client.probe_beside = False
     iters = a.round_iters                                # the timed mix: round_iters - 3 head-phase + 3 body-phase iterations
     client.args.iters = iters
     cfg = {"iter_global": 60, "iters": iters, "eval_iters": 10 * iters, "batch_size": a.batch, "stage": "fit"}
@@ -498,7 +501,7 @@ def roofline_pass(client, a, dtype_name):
             "min_roofline_frac": round(min_roof_fam, 4), "min_roofline_frac_all_conv": round(min_roof_conv, 4),
             "min_roofline_note": "sum over launches of max(flops / MFMA peak, bytes / HBM peak) / sum of measured durations; "
                                  "per-shape table: profiles/*_per_layer_roofline.txt",
-            "instrumented_iterations": f"{iters - 3} head-phase + 3 body-phase (the timed mix)",
+            "instrumented_iterations": f"{iters - 3} head-phase + 3 body-phase (the timed mix), LC forwards in line: every launch timed alone",
             "hip_launches_per_step": round(sum(v["calls"] for v in prof.values()) / float(iters), 1),
             "conv_flops_per_step": conv_flops / float(iters),
             "kernel_time_breakdown_ms_per_step": {k: round(v / float(iters), 4) for k, v in sorted(breakdown.items())}}
