@@ -246,7 +246,7 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       const bool ok32 = okb && cout % 64 == 0;
       const bool ok16 = ok32 && d->c0 % 64 == 0 && d->c1 % 64 == 0 && cout % 128 == 0;
       // whole filter resident in LDS (forms 3 / 4): Cout = 64 or 32 and 2 pixel groups (78 336 B) + Cin x Cout x 18 B + strip fit.
-      // Measured (profiles/r03_s_kbench2_ws2res.txt, same box): the batched fused launches of 256^2 32->32 233 -> 200 us (with
+      // Measured (profiles/r03_u_kbench2_ws2res.txt, same box): the batched fused launches of 256^2 32->32 233 -> 200 us (with
       // dropout 359 -> 293), 256^2 64->32 385 -> 335, 128^2 64->64 146 -> 136 (with dropout 194 -> 172) against the 32-pixel-tile form
       const bool okres = okb && (cout == 64 || cout == 32) && 78336L + (long)cin * cout * 18 + 768 <= 160 * 1024;
       static const long res_min = env_long("FI_WS2_RES_MIN", 1024);
@@ -267,7 +267,9 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // 32^2 256->256 159 -> 137, head 887 -> 841); the 32-row x 64-channel shape and the 12-image launches measured level
       // or behind and stay where they were
       const long tiles16 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
-      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (a.xf == 1 && ok16 && tiles16 * (cout / 128) >= 1024);
+      // (64-output slabs that are not resident -- 128^2 128->64 -- take the 32-row shape: 251 -> 239 us since the butterfly epilogue)
+      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (a.xf == 1 && ok16 && tiles16 * (cout / 128) >= 1024) ||
+                          (a.xf == 1 && ok32 && cout == 64 && tiles32 >= 1024);
       if (ok32 && wanted) {
         int tr = ok16 ? 16 : 32;
         static const long force_tr = env_long("FI_WS2_TR", 0);
