@@ -281,8 +281,15 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
         a.wrows = rows;
         a.tilesY = fi_cdiv(d->H, tr);
         a.nct = cout / (tr == 16 ? 128 : 64);
-        const int form = tr == 16 ? 1 : 2;
-        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, (int)g_tune[3], a, st) : fi_conv_fwd_ws2_bf16(form, (int)g_tune[3], a, st);
+        // one 64-channel pixel group and 2..4 slabs of 128 (the auxiliary head, 64 -> 512): the slabs inside the tile (form 5;
+        // FI_WS2_SI=0 keeps the slab-major order)
+        static const long si_on = env_long("FI_WS2_SI", 1);
+        const bool si = tr == 16 && si_on && cin == 64 && a.nct >= 2 && a.nct <= 4;
+        const int form = si ? 5 : (tr == 16 ? 1 : 2);
+        // measured (84 x 128^2 64->512, statistics only, same box): slab-major 872 us, slabs inside the tile 828, and 780 with runs of
+        // half the length (512 workgroups queued on 256 CUs: the run lengths differ by up to 2x between CUs)
+        const int wgs = g_tune[3] ? (int)g_tune[3] : (si ? 2 : 0);
+        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, wgs, a, st) : fi_conv_fwd_ws2_bf16(form, wgs, a, st);
         return rc;
       }
     }

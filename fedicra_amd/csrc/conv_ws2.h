@@ -58,10 +58,16 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
 // 64 -> 32, 32 -> 32 ...) load it once per workgroup run instead of one slab per stage -- at 32 / 64 output channels the
 // slab of a stage is as many bytes as its pixels, and the producers' fill rate is what bounds these layers.  A package is
 // then a pixel part only.  BN = 32 (one 32-channel block per consumer wave) exists for this form only.
-template <typename T, int TR, int BN, int XF, int WR>
+// MODE = 2 ("slab inner", SI): a layer whose whole contraction is ONE pixel group (Cin == 64) and that has several 128-channel
+// slabs (the auxiliary head, 64 -> 512) walks the slabs INSIDE a tile: the tile's pixels are staged and transformed once
+// instead of once per slab (a quarter of the loader's vector work -- what bounds the kernel), the weight slabs stream as before.
+// An item is then a tile; its stages are slab-major; the next tile's pixel parts ride in the packages of the tile's last NQ stages.
+template <typename T, int TR, int BN, int XF, int MODE>
 __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
+  constexpr int WR = MODE == 1 ? 1 : 0;
+  constexpr bool SI = MODE == 2;
   static_assert(sizeof(T) == 2, "16-bit storage");
-  static_assert((TR == 16 && BN == 128 && WR == 0) || (TR == 32 && BN == 64) || (TR == 32 && BN == 32 && WR == 1),
+  static_assert((TR == 16 && BN == 128 && WR == 0) || (TR == 32 && BN == 64 && !SI) || (TR == 32 && BN == 32 && WR == 1),
                 "8 consumer waves of 4 rows x 64 (32) channels");
   static_assert(XF == 0 || XF == 1, "plain or transforming loader");
   constexpr int CW = 8, PT = 256;                                // consumer waves; threads of one producer team
@@ -93,12 +99,13 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
 
   // ---- this workgroup's run of items; item = slab * ntile + tile (slab-major: a run keeps its slab and statistics group)
   const int ntile = a.N * a.tilesY * a.tilesX, tpi = a.tilesY * a.tilesX;
-  const int nitem = ntile * a.nct;
+  const int nitem = SI ? ntile : ntile * a.nct;
   const int per = (nitem + (int)gridDim.x - 1) / (int)gridDim.x;
   const int i_begin = (int)blockIdx.x * per, i_end = min(nitem, i_begin + per);
   if (i_begin >= i_end) return;
   const int nchunk = cin / CK, ngrp = cin / GC;
-  const int nstage = (i_end - i_begin) * nchunk, ngroups = (i_end - i_begin) * ngrp;
+  const int spt = SI ? a.nct * nchunk : nchunk;                  // stages of an item
+  const int nstage = (i_end - i_begin) * spt, ngroups = (i_end - i_begin) * ngrp;
   const int o_strip = O_W + (WR ? nchunk : 2) * WT;
 
   constexpr unsigned esz = 2;
@@ -321,13 +328,13 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       }
     };
     // ---- weight slab of chunk `chunk` (of the whole contraction) for the slab it.ct
-    auto issue_w = [&](const Item& it, int chunk, bool live) __attribute__((always_inline)) {
+    auto issue_w = [&](int ct, int chunk, bool live) __attribute__((always_inline)) {
 #if FI_WS2_DEBUG & 2
       return;
 #endif
       if constexpr (WR) return;
       // chunk-major operand: [chunk][wrows][9][16]: the slab is one contiguous block starting at row it.ct * BN
-      const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(it.ct * BN)) * (KK * 2) + (unsigned)ptid) * 16u;
+      const unsigned o0w = (((unsigned)chunk * (unsigned)a.wrows + (unsigned)(ct * BN)) * (KK * 2) + (unsigned)ptid) * 16u;
       const __amdgpu_buffer_rsrc_t rw = rsrc(a.w, (unsigned)__builtin_amdgcn_readfirstlane((int)(live ? wbytes : 0u)));
 #pragma unroll
       for (int p = 0; p < WPASS; ++p) {
@@ -353,14 +360,18 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     };
 
     // package cursor: k = stage whose weights it carries; (gi, cgx, qx, itx) = pixel part of flat index k + NQ - 1
+    // (slab-inner: ch counts the item's spt stages; the package of stage ch >= spt - NQ carries part ch - (spt - NQ) of the NEXT
+    //  item's single group, the others carry weights only)
     Item itw = item_at(i_begin), itx = itw;
-    int ch = 0, k = 0, gi = 0, cgx = 0, qx = NQ - 1;
+    int ch = 0, k = 0, gi = 0, cgx = 0, qx = NQ - 1, ti = 0;
     auto adv = [&]() __attribute__((always_inline)) {
       ++k;
-      if (++ch == nchunk) {
+      if (++ch == spt) {
         ch = 0;
+        ++ti;
         itw = item_next(itw);
       }
+      if constexpr (SI) return;
       if (++qx == NQ) {
         qx = 0;
         ++gi;
@@ -383,11 +394,22 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       return grp_of(it, j / NQ) * NQ + i;
     };
     auto issue = [&]() __attribute__((always_inline)) {
-      issue_x(itx, grp_of(itx, cgx), qx, gi < ngroups);
-      issue_w(itw, chunk_of(itw, ch), k < nstage);
+      if constexpr (SI) {
+        const int q = ch - (spt - NQ);
+        issue_x(item_next(itw), 0, q >= 0 ? q : 0, q >= 0 && i_begin + ti + 1 < i_end);
+        issue_w(ch / nchunk, ch % nchunk, k < nstage);
+      } else {
+        issue_x(itx, grp_of(itx, cgx), qx, gi < ngroups);
+        issue_w(itw.ct, chunk_of(itw, ch), k < nstage);
+      }
     };
     auto commit = [&]() __attribute__((always_inline)) {
-      commit_x(itx, grp_of(itx, cgx), qx, gi & 1);
+      if constexpr (SI) {
+        const int q = ch - (spt - NQ);
+        if (q >= 0) commit_x(item_next(itw), 0, q, (ti + 1) & 1);   // (no next item: zeros into the idle buffer)
+      } else {
+        commit_x(itx, grp_of(itx, cgx), qx, gi & 1);
+      }
       commit_w(k & 1);
     };
     if constexpr (WR) {
@@ -415,8 +437,15 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       }
     }
     if (team == 0) {
-      issue();
-      commit();                                                  // package 0: slab 0 + the LAST part of group 0
+      if constexpr (SI) {
+        issue_x(itw, 0, NQ - 1, true);
+        issue_w(0, 0, true);
+        commit_x(itw, 0, NQ - 1, 0);
+        commit_w(0);
+      } else {
+        issue();
+        commit();                                                // package 0: slab 0 + the LAST part of group 0
+      }
       adv();
       adv();
     } else {
@@ -493,7 +522,8 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     // one strip per 64-channel group, shared by its row-group waves: [sum 64][sum of squares 64][bias 64] floats.  The waves
     // ADD their per-tile totals (ds_add_f32); the row-group-0 wave clears / flushes it and loads the bias at the START of a
     // tile -- at least one stage barrier away from the adds on either side (a tile has >= 2 stages).
-    float* const strip = reinterpret_cast<float*>(smem + o_strip) + cgp * 192;
+    float* const strip0 = reinterpret_cast<float*>(smem + o_strip) + cgp * 192;     // slab-inner: + slab * CG * 192
+    float* strip = strip0;
     auto stats_clear = [&]() __attribute__((always_inline)) { strip[lane] = strip[64 + lane] = 0.f; };
     auto stats_flush = [&](int grp, int ct) __attribute__((always_inline)) {
       if (!a.stats) return;
@@ -613,44 +643,67 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
     int sgrp = -1, sct = -1;
     auto consume = [&](int wbuf) __attribute__((always_inline)) {
       FI_T2(4);                                                  // stage start (barrier passed)
-      if (ch == 0) {
+      const int cpos = SI ? ch % nchunk : ch;                    // chunk position within the slab's contraction
+      if constexpr (SI) {
+        it.ct = ch / nchunk;
+        strip = strip0 + it.ct * (CG * 192);
+      }
+      if (cpos == 0) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pp][cb][i] = 0.f;
-        if (rg == 0) {                                           // strip housekeeping for this 64-channel group
-          const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
-          if (grp != sgrp || it.ct != sct || since_flush >= FI_WS2_FLUSH_TILES) {   // new (group, slab), or time to leave fp32
-            if (sct >= 0) stats_flush(sgrp, sct);
-            stats_clear();
-            if (it.ct != sct) load_bias(it.ct);
+      }
+      if (ch == 0 && rg == 0) {                                  // strip housekeeping for this 64-channel group
+        const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
+        if constexpr (SI) {
+          if (grp != sgrp || since_flush >= FI_WS2_FLUSH_TILES) {   // new group, or time to leave fp32: every slab's strip
+            for (int ct = 0; ct < a.nct; ++ct) {
+              strip = strip0 + ct * (CG * 192);
+              if (sgrp >= 0) stats_flush(sgrp, ct);
+              stats_clear();
+              if (sct < 0) load_bias(ct);
+            }
+            strip = strip0;
             sgrp = grp;
-            sct = it.ct;
+            sct = 0;
             since_flush = 0;
           }
-          ++since_flush;
+        } else if (grp != sgrp || it.ct != sct || since_flush >= FI_WS2_FLUSH_TILES) {   // new (group, slab), or time to leave fp32
+          if (sct >= 0) stats_flush(sgrp, sct);
+          stats_clear();
+          if (it.ct != sct) load_bias(it.ct);
+          sgrp = grp;
+          sct = it.ct;
+          since_flush = 0;
         }
+        ++since_flush;
       }
 #if !(FI_WS2_DEBUG & 1)
       {
         int cr = cq + rot_of(it) % NQ;                           // the chunk of its group this stage holds (producers: chunk_of)
         cr = cr >= NQ ? cr - NQ : cr;
-        mma(WR ? ch : wbuf, gpar, cr);
+        mma(WR ? ch : wbuf, gpar, SI ? cpos : cr);
       }
 #endif
       FI_T2(5);                                                  // MFMAs issued
-      if (++cq == NQ) {
-        cq = 0;
-        gpar ^= 1;
+      if constexpr (!SI) {
+        if (++cq == NQ) {
+          cq = 0;
+          gpar ^= 1;
+        }
       }
-      if (++ch == nchunk) {
-        ch = 0;
+      if (cpos == nchunk - 1) {
 #if !(FI_WS2_DEBUG & 16)
         epilogue(it);
 #endif
         FI_T2(6);                                                // epilogue issued
+      }
+      if (++ch == spt) {
+        ch = 0;
+        if constexpr (SI) gpar ^= 1;
         it = item_next(it);
       }
     };
@@ -662,30 +715,40 @@ __global__ __launch_bounds__(1024, 1) void conv_fwd_ws2_kernel(ConvArgs a) {
       consume(1);
       fi_lds_barrier();
     }
-    if (rg == 0 && sct >= 0) stats_flush(sgrp, sct);
+    if (rg == 0 && sct >= 0) {
+      if constexpr (SI) {
+        for (int ct = 0; ct < a.nct; ++ct) {
+          strip = strip0 + ct * (CG * 192);
+          stats_flush(sgrp, ct);
+        }
+      } else {
+        stats_flush(sgrp, sct);
+      }
+    }
     FI_T2(4);
   }
 }
 
-template <typename T, int TR, int BN, int WR>
+template <typename T, int TR, int BN, int MODE>
 static int launch_conv_fwd_ws2(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
   constexpr int XH = TR + 2, XW = 18, GC = TR == 16 ? 64 : 32;
+  constexpr bool WR = MODE == 1, SI = MODE == 2;
   const int nchunk = (a.c0 + a.c1) / 16;
   const size_t lds = (size_t)2 * (XH * XW * GC * 2) + (size_t)(WR ? nchunk : 2) * (BN * 9 * 16 * 2) +
-                     (size_t)(BN >= 64 ? BN / 64 : 1) * 192 * sizeof(float);
-  if (lds > 160 * 1024 || (WR && (a.nct != 1 || a.co0 + a.co1 != BN))) return FI_ERR_UNSUPPORTED;
-  const long nitem = (long)a.N * a.tilesX * a.tilesY * a.nct;
+                     (size_t)(SI ? a.nct : 1) * (BN >= 64 ? BN / 64 : 1) * 192 * sizeof(float);
+  if (lds > 160 * 1024 || (WR && (a.nct != 1 || a.co0 + a.co1 != BN)) || (SI && a.c0 + a.c1 != GC)) return FI_ERR_UNSUPPORTED;
+  const long nitem = (long)a.N * a.tilesX * a.tilesY * (SI ? 1 : a.nct);
   long blocks = 256L * (wgs_per_cu > 0 ? wgs_per_cu : 1);
   if (blocks > nitem) blocks = nitem;
   const dim3 g((unsigned)blocks), b(1024);
   if (a.xf == 0) {
-    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 0, WR>);
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 0, MODE>);
     (void)big;
-    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 0, WR>), g, b, lds, st, a);
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 0, MODE>), g, b, lds, st, a);
   } else if (a.xf == 1) {
-    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 1, WR>);
+    static const bool big = fi_allow_big_lds((const void*)conv_fwd_ws2_kernel<T, TR, BN, 1, MODE>);
     (void)big;
-    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 1, WR>), g, b, lds, st, a);
+    hipLaunchKernelGGL((conv_fwd_ws2_kernel<T, TR, BN, 1, MODE>), g, b, lds, st, a);
   } else {
     return FI_ERR_UNSUPPORTED;
   }

@@ -64,6 +64,11 @@ WS2_CASES = [
     (4, 40, 40, 128, 0, 32, 2, "shared", True, False),       # 8 resident chunks
     (40, 128, 128, 64, 0, 64, 4, "drop", True, False),       # > 8 tiles per workgroup
     (3, 24, 56, 64, 0, 32, 1, "none", True, False),          # plain loader, bias + statistics
+    # one 64-channel pixel group, 2..4 slabs of 128: the slabs are walked inside a tile (form 5) -- case 2 above as well
+    (6, 40, 24, 64, 0, 256, 3, "drop", True, False),
+    (3, 33, 50, 64, 0, 384, 1, "none", True, False),         # plain loader, three slabs, ragged
+    (40, 128, 128, 64, 0, 256, 4, "xf", True, False),        # > 8 tiles per workgroup: every slab's strip flushed inside a run
+    (5, 48, 48, 64, 0, 512, 1, "shared", "only", False),     # statistics only, four slabs
 ]
 
 
@@ -74,7 +79,7 @@ def test_ws2_kernel_equals_the_one_tile_kernel(dtype, case):
     to the last bit or two of the storage type; statistics are those of the stored outputs."""
     from fedicra_amd import _lib as L
     N, H, W, c0, c1, cout, G, kind, stats, two = WS2_CASES[case]
-    if dtype == "fp16" and case in (8, 13):
+    if dtype == "fp16" and case in (8, 13, 17):
         pytest.skip("the long-run case once is enough")
     td = TD[dtype]
     gen = torch.Generator().manual_seed(300 + case)
