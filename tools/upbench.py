@@ -1,11 +1,32 @@
 #!/usr/bin/env python
-"""Up-sampling kernel timing at the batched LC-forward shapes: python tools/upbench.py  (FI_UP_ROWS_MIN=99999999999 = flat form)."""
-import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fedicra_amd import _lib as L
-from kbench2 import timeit
-for (N, h, C) in [(84, 256, 16), (84, 128, 32), (84, 64, 64), (84, 32, 128), (12, 256, 16)]:
-    x = torch.randn(N, h, h, C, device="cuda").to(torch.bfloat16)
-    y = torch.empty(N, 2 * h, 2 * h, C, device="cuda", dtype=torch.bfloat16)
-    t = timeit(lambda: L.upsample2x_fwd(x, y), 8)
-    print(f"{N:3d} x {h:3d}^2 x {C:3d}: {t:7.1f} us  {(x.numel() + y.numel()) * 2 / t / 1e3:7.1f} GB/s")
+"""Bilinear x2 up-sampling (fi_upsample2x_fwd) at the four decoder levels of the batched LC forwards: us per launch and
+GB/s of the algorithmic traffic (read the low-resolution tensor once, write the result once).
+    python tools/upbench.py [--images 84] [--size 512]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fedicra_amd import _lib as L  # noqa: E402
+from tools.kbench2 import timeit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=84)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=8)
+    a = ap.parse_args()
+    for f, c in ((16, 128), (8, 64), (4, 32), (2, 16)):
+        h = a.size // f
+        x = torch.randn(a.images, h, h, c, device="cuda").to(torch.bfloat16)
+        y = torch.empty(a.images, 2 * h, 2 * h, c, device="cuda", dtype=torch.bfloat16)
+        us = timeit(lambda: L.upsample2x_fwd(x, y), a.reps)
+        nb = (x.numel() + y.numel()) * 2
+        print(f"{a.images} x {h:3d}^2 x {c:3d} -> {2 * h:3d}^2: {us:8.1f} us  {nb / us / 1e3:8.1f} GB/s")
+
+
+main()
