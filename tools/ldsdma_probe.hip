@@ -1,4 +1,4 @@
-// Probe: does `buffer_load_dwordx4 ... lds` (gfx950) put lane L's 16 bytes at LDS[M0 base + 16 L]?   hipcc --offload-arch=gfx950 -O3 tools/ldsdma_probe.hip -o variants/ldsdma_probe
+// Probe: does `buffer_load_dwordx4 ... lds` (gfx950) put lane L's 16 bytes at LDS[M0 base + 16 L]?   hipcc --offload-arch=gfx950 -O3 tools/ldsdma_probe.hip -o variants/ldsdma_probe (variants/ is git-ignored)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
