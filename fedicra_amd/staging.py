@@ -59,6 +59,10 @@ class BatchStager:
         if len(self._pending) >= self.slots - 2:              # never more copies in flight than the ring can hold
             return
         x, y = batch["image"], batch["label"]
+        if not (x.is_pinned() and y.is_pinned()):
+            # pageable memory: the runtime bounces such a copy through its own pinned buffer and the "async" call blocks the
+            # host -- nothing to overlap, and two streams bouncing at once is not something to lean on: fetch() copies it serially
+            return
         pair = self._pair(x, y)
         if pair[2] is not None and not pair[2].query():
             self.side.wait_event(pair[2])             # the consumer that last read this pair has not run yet

@@ -316,3 +316,32 @@ def test_lc_forwards_beside_the_own_forward_leave_the_state_of_the_in_line_order
     assert torch.equal(c0, c1)
     assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
     assert torch.allclose(s0, s1, rtol=1e-4, atol=2e-5), float((s0 - s1).abs().max())
+
+
+def test_batch_stager_hands_out_the_batches_it_was_given_pinned_ahead_and_pageable_serially():
+    """staging.BatchStager: pinned host batches are copied ahead on the side stream (several in flight, ring re-use), pageable ones
+    serially at fetch(); either way the consumer sees the batch it asked for."""
+    from fedicra_amd.staging import BatchStager
+    g = torch.Generator().manual_seed(11)
+    st = BatchStager(DEV, slots=4)
+    mk = lambda pin: {"image": (lambda t: t.pin_memory() if pin else t)(torch.randn(3, 32, 32, generator=g)),
+                      "label": (lambda t: t.pin_memory() if pin else t)(torch.randint(0, 3, (3, 32, 32), generator=g).to(torch.uint8))}
+    pinned = [mk(True) for _ in range(9)]
+    for i, b in enumerate(pinned):
+        for nxt in pinned[i + 1:i + 3]:
+            st.prefetch(nxt)
+        x, y = st.fetch(b)
+        xc, yc = x.clone(), y.clone()
+        st.release()
+        torch.cuda.synchronize()
+        assert torch.equal(xc.cpu(), b["image"]) and torch.equal(yc.cpu(), b["label"]), i
+    assert st.h2d_bytes == sum(b["image"].numel() * 4 + b["label"].numel() for b in pinned)
+    pageable = [mk(False) for _ in range(3)]
+    for i, b in enumerate(pageable):
+        st.prefetch(pageable[(i + 1) % 3])
+        assert not st._pending                                       # nothing goes ahead from pageable memory
+        x, y = st.fetch(b)
+        xc, yc = x.clone(), y.clone()
+        st.release()
+        torch.cuda.synchronize()
+        assert torch.equal(xc.cpu(), b["image"]) and torch.equal(yc.cpu(), b["label"]), i
