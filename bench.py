@@ -228,10 +228,11 @@ class Volumes:
             torch.cuda.synchronize()
         self.it = 0
         self.agg_events = []
+        self.graphs, self.graph_error = {}, None
 
-    def step(self):
+    def _step_eager(self, key):
         from fedicra_amd import ops
-        x, y = self.batches[self.it % 2]
+        x, y = self.batches[key]
         ops.begin_iteration(self.dev)
         self.opt.zero_grad()
         out = self.net(x)                                        # NCDHW view of fp32 NDHWC logits
@@ -241,6 +242,37 @@ class Volumes:
         loss.backward()
         self.opt.step()
         self.opt.advance_lr()
+
+    def step(self):
+        """One iteration; with --no-graph off, captured per batch buffer (the two resident batches alternate) after one eager
+        pass and replayed from then on.  A capture that fails leaves the iteration eager and says so in the bench line."""
+        from fedicra_amd import ops
+        key = self.it % 2
+        st = None if self.a.no_graph else self.graphs.get(key, "new")
+        if st is None or st == "eager":
+            self._step_eager(key)
+        elif st == "new":
+            self._step_eager(key)
+            self.graphs[key] = "warm"
+        elif st == "warm":
+            torch.cuda.synchronize()
+            ops.reserve_graph_tables()
+            ops.bump_weights_epoch()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._step_eager(key)
+                self.graphs[key] = g
+                g.replay()
+                ops.bump_weights_epoch()
+            except Exception as e:                               # noqa: BLE001 -- reported, not hidden
+                self.graphs[key] = "eager"
+                self.graph_error = repr(e)[:300]
+                torch.cuda.synchronize()
+                self._step_eager(key)
+        else:
+            st.replay()
+            ops.bump_weights_epoch()
         self.it += 1
 
     def run_steps(self, nsteps):
@@ -280,6 +312,7 @@ class Volumes:
 
     def roofline(self, dtype_name):
         from fedicra_amd import _lib as L
+        self.a.no_graph = True                                   # instrumented launches are eager
         self.step()
         L.profile_begin(subtract_overhead=False)
         for _ in range(2):
@@ -370,7 +403,8 @@ def main_c4(a, rank, local, world, dev, dist):
                            "volumes_per_sec_per_client": round(value / world, 3), "ms_per_aggregation_round": round(agg_ms, 3),
                            "conv_tflops_per_gpu": round(f_train / step_s / 1e3, 2),
                            "frac_of_mfma_peak": round(f_train / step_s / 1e3 / MFMA_PEAK[a.dtype], 4),
-                           "hipgraph": False, "parallelism": f"fed-dp{world}"}}
+                           "hipgraph": any(not isinstance(g, str) for g in vol.graphs.values()), "hipgraph_error": vol.graph_error,
+                           "parallelism": f"fed-dp{world}"}}
         if world > 1:
             sp = vol.agg.split_ms() or {}
             line["config"].update({"rccl_ranks": world if vol.backend == "nccl" else 0, "dist_backend": vol.backend,
