@@ -150,24 +150,32 @@ class Federation:
             self.iter_global += 1
             done += it
 
-    def timed(self, warmup, steps, dist):
+    def timed(self, warmup, steps, dist, windows=1):
+        """W untimed warm-up steps, then `windows` back-to-back windows of EXACTLY `steps` steps, each bracketed by barrier +
+        synchronize on both sides and reduced with MAX over ranks.  -> (elapsed of the MEDIAN window, its mean aggregation
+        round in ms, [elapsed of every window]).  The event lists round_split() reads are those of the median window."""
         self.run_steps(warmup)
-        torch.cuda.synchronize()
-        if self.world > 1:
-            dist.barrier()
-        self.agg_events, self.train_events, self.agg.splits = [], [], []
-        t0 = time.perf_counter()
-        self.run_steps(steps)
-        torch.cuda.synchronize()
-        if self.world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if self.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.model.model.flat_state.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        res = []
+        for _ in range(max(1, windows)):
+            torch.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier()
+            self.agg_events, self.train_events, self.agg.splits = [], [], []
+            t0 = time.perf_counter()
+            self.run_steps(steps)
+            torch.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            if self.world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=self.model.model.flat_state.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            res.append((elapsed, self.agg_events, self.train_events, self.agg.splits))
+        order = sorted(range(len(res)), key=lambda i: res[i][0])
+        elapsed, self.agg_events, self.train_events, self.agg.splits = res[order[(len(order) - 1) // 2]]
         agg_ms = [e0.elapsed_time(e1) for e0, e1, _ in self.agg_events]
-        return elapsed, sum(agg_ms) / max(len(agg_ms), 1)
+        return elapsed, sum(agg_ms) / max(len(agg_ms), 1), [r[0] for r in res]
 
     def round_split(self):
         """Mean ms per round of the last timed() call: local training (round_iters steps), then the aggregation round cut
@@ -430,8 +438,6 @@ def cpu_baseline(a):
     from fedicra_amd.synth import client_num_batches, phantom_batch
     # torch's CPU conv path stops scaling (and collapses from oversubscription) far below the 256 hardware
     # threads of the GPU box's host: use at most 32 threads and report that number as `cores`.
-    cores = min(os.cpu_count() or 1, int(os.environ.get("FEDICRA_CPU_THREADS", "32")))
-    torch.set_num_threads(cores)
     torch.manual_seed(2022)
     B = max(1, min(a.batch, int(os.environ.get("FEDICRA_CPU_BATCH", "4"))))
     m = RefUNetLC(a.in_chns, a.classes, 1, FEDERATION, FEDERATION, 0, heads=1)
@@ -439,6 +445,27 @@ def cpu_baseline(a):
     for i in range(2):
         img, weak, _ = phantom_batch(B, a.size, a.in_chns, a.classes, cid=0, index=i)
         batches.append({"image": torch.from_numpy(img), "label": torch.from_numpy(weak)})
+    # thread-scaling table: one train-mode forward + backward of the same model on the same B images per thread
+    # count, after a warm-up at that count; the sample below then runs at the FASTEST count, which is what `cores` reports
+    ncpu = os.cpu_count() or 1
+    forced = os.environ.get("FEDICRA_CPU_THREADS")
+    scaling = {}
+    if forced:
+        cores = min(ncpu, int(forced))
+    else:
+        xb = batches[0]["image"] if a.in_chns != 1 else batches[0]["image"].unsqueeze(1)
+        for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu // 2, ncpu) if 0 < t <= ncpu}):
+            torch.set_num_threads(th)
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                m.zero_grad()
+                m(xb)[0].square().mean().backward()
+                ts.append(time.perf_counter() - t0)
+            scaling[th] = round(B / ts[-1], 3)
+        m.zero_grad()
+        cores = max(scaling, key=scaling.get)
+    torch.set_num_threads(cores)
     st = fed_ref.TrainState(0.01)
     kw = dict(num_classes=a.classes, base_lr=0.01, max_iterations=30000, img_class="faz" if a.in_chns == 1 else "odoc",
               strategy="FedICRA", alpha=1.0, cid=0, num_clients=FEDERATION)
@@ -463,12 +490,56 @@ def cpu_baseline(a):
     t_ala_batch = (time.perf_counter() - t0) * (a.batch / float(B))           # one ALA batch of the full size
     return {"value": round(B / s_iter, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_aggregation_round": round((t_agg + t_ala_batch * a.loader_batches) * 1e3, 1),
-            "ms_fedavg_numpy_k8": round(t_agg * 1e3, 2),
+            "ms_fedavg_numpy_k8": round(t_agg * 1e3, 2), "host_hardware_threads": ncpu,
+            "thread_scaling_fwd_bwd_images_per_sec": scaling or None,
             "sec_per_head_iteration": round(float(np.median(t_head)), 3), "sec_per_body_iteration": round(float(np.median(t_body)), 3),
-            "sample": f"oracle.fed_ref.local_train on RefUNetLC (torch {torch.__version__} CPU fp32, {cores} threads): 1 warm-up + 2 "
-                      f"head-phase + 1 body-phase FedICRA iterations of {B}x{a.in_chns}x{a.size}x{a.size} (a third of the batch) incl. "
+            "sample": f"oracle.fed_ref.local_train on RefUNetLC (torch {torch.__version__} CPU fp32, {cores} threads = the fastest of the "
+                      f"measured thread-scaling table): 1 warm-up + 2 head-phase + 1 body-phase FedICRA iterations of {B}x{a.in_chns}x{a.size}x{a.size} (a third of the batch) incl. "
                       f"the 7 LC forwards, weighted {a.round_iters - 3}:3 like the timed rounds; aggregation = numpy FedAvg K=8 + one "
                       f"ALA batch of {B} images scaled to {a.loader_batches} batches of {a.batch}"}
+
+
+def dice_leg(with_cpu=True, rounds=12):
+    """Metric leg 3, "Dice vs CPU ref" (/root/reference/code/val_2D.py:9-74, flower_common.py:
+    122-136): OUTSIDE the timed region, the miniature federation of fedicra_amd/minifed.py -- 2 FedAvg clients x `rounds`
+    rounds x 8 local iterations on 4x1x64x64 phantoms (BASELINE configs[0]'s shape), weighted aggregation, `evaluate` of
+    client 0 on 16 dense-mask cases -- trained THREE times from the same seeded state with the same dropout masks: on the HIP
+    path in fp32 (parity mode) and in bf16 (the timed mode), and on the CPU port of the reference (oracle/minifed_ref.py;
+    `with_cpu`, part of the cpu_baseline leg).  After ~100 sign-like AdamW steps per client the reference's own Dice moves
+    with the dropout seed and the host's thread count (tests/golden/g19_minifed_dice.npz: the reference's own classes over
+    8 seeds x {8, 1} threads); that spread is printed beside the deltas."""
+    import numpy as np
+    from fedicra_amd.minifed import make_data, run_hip
+    from oracle.unet_ref import seeded_state      # the seeded initial state is DATA for both sides (weights are not stored)
+    data, val = make_data()
+    init = lambda net: seeded_state(net, 2022)
+    t0 = time.perf_counter()
+    out = {"rounds": rounds, "clients": 2, "local_iterations": 8, "shape": "4x1x64x64, 16 validation cases",
+           "masks": "identical (host generator, seed 100*round + cid)"}
+    h32 = run_hip(data, val, dtype="fp32", rounds=rounds, init_state=init, max_iterations=400)
+    h16 = run_hip(data, val, dtype="bf16", rounds=rounds, init_state=init, max_iterations=400)
+    out["hip_fp32"], out["hip_bf16"] = round(h32["dice"], 6), round(h16["dice"], 6)
+    out["abs_delta_bf16_vs_fp32"] = round(abs(h16["dice"] - h32["dice"]), 6)
+    if with_cpu:
+        from oracle.minifed_ref import run_oracle
+        cores = min(os.cpu_count() or 1, 8)
+        c = run_oracle(data, val, rounds=rounds, max_iterations=400, threads=cores)
+        out["cpu"], out["cpu_threads"] = round(c["dice"], 6), cores
+        out["abs_delta_fp32"] = round(abs(h32["dice"] - c["dice"]), 6)
+        out["abs_delta_bf16"] = round(abs(h16["dice"] - c["dice"]), 6)
+        out["round1_last_loss"] = {"cpu": round(c["losses"][0], 6), "hip_fp32": round(h32["losses"][0], 6),
+                                   "hip_bf16": round(h16["losses"][0], 6)}
+    fx = os.path.join(ROOT, "tests", "golden", "g19_minifed_dice.npz")
+    if os.path.exists(fx):
+        g = np.load(fx)
+        if int(g["rounds"]) == rounds:
+            d = g["dice"]
+            out["reference_own_spread"] = {"min": round(float(d.min()), 6), "max": round(float(d.max()), 6),
+                                           "mean": round(float(d.mean()), 6), "runs": int(d.size),
+                                           "what": "the reference's own classes, 8 dropout seeds x {8, 1} CPU threads "
+                                                   "(tests/golden/g19_minifed_dice.npz, oracle/gen_golden.py)"}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 def roofline_pass(client, a, dtype_name):
@@ -541,20 +612,36 @@ def roofline_pass(client, a, dtype_name):
             "kernel_time_breakdown_ms_per_step": {k: round(v / float(iters), 4) for k, v in sorted(breakdown.items())}}
     # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 PMC run of this same
     # workload (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied -- see the json's header)
+    # Only a file taken on THIS build counts: the json records the kernel-source hash of the tree it was measured in
+    # (fedicra_amd._lib.source_hash -- the GPU box has no .git); any other file is refused and `traffic` stays null.
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    here = L.source_hash()
+    roof["build_source_hash"] = here
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    refused = []
     for pmc_path in reversed(found):
         try:
             d = json.load(open(pmc_path))
             if d.get("workload_key") != workload_key(a, dtype_name):
                 continue
+            if d.get("source_hash") != here:
+                refused.append(os.path.basename(pmc_path))
+                continue
             fam_pmc = d["families"].get(fname)
-            if fam_pmc:
+            if fam_pmc and "hbm_bytes_per_launch" in fam_pmc:
                 roof["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+                roof["traffic_head"] = d.get("source_hash")
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, bytes per launch)" % os.path.basename(pmc_path)
+                m = fam_pmc.get("mfma")
+                if m:                                  # SQ counters of the same family (its own PMC pass): matrix-pipe busy share
+                    roof["mfma_busy_pct"] = m.get("mfma_busy_pct")
+                    roof["mfma_counters_per_launch"] = {k: m.get(k) for k in ("mfma_busy_cycles_per_launch", "gui_active_cycles_per_launch",
+                                                                              "sq_busy_cycles_per_launch", "mops_flops_per_launch")}
                 break
         except (OSError, ValueError, KeyError):
             continue
+    if roof["traffic"] is None and refused:
+        roof["traffic_refused"] = f"taken on another build (source hash differs from {here}): " + ", ".join(refused[:3])
     table = os.environ.get("FEDICRA_BENCH_TABLE")
     if table:
         with open(table, "w") as f:
@@ -600,6 +687,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed windows of --steps steps each, back to back after ONE warm-up; value = the median window")
+    ap.add_argument("--no-dice", action="store_true", help="skip the Dice-vs-CPU-reference leg (config.dice)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
                     help="c3 (default): BASELINE configs[2], the configuration the metric is quoted on; c4: configs[3], the 3D path "
                          "(4 clients, unet_3D, 2x1x128^3 bf16) with the same JSON shape in volumes/s")
@@ -652,8 +742,11 @@ def main():
         if rank == 0:
             print(json.dumps({"roofline": roof}), flush=True)
         return
-    elapsed, agg_ms = fed.timed(a.warmup, a.steps, dist)
+    # value = the MEDIAN of --windows (5) back-to-back windows of exactly --steps steps each (one 20-step window is 0.2 s: a
+    # +-1 % kernel change is inside its noise); every window's rate is printed beside it
+    elapsed, agg_ms, win_s = fed.timed(a.warmup, a.steps, dist, a.windows)
     value = a.steps * a.batch * world / elapsed
+    win_rates = [round(a.steps * a.batch * world / w, 2) for w in win_s]
     split = fed.round_split()
     h2d_bytes_per_step = None
     if a.data == "host":
@@ -663,7 +756,7 @@ def main():
     if a.data == "host" and not a.no_resident:
         fedr = Federation(a, rank, world, dev, a.dtype, data="resident")
         kr = min(a.steps, a.round_iters)
-        elr, aggr = fedr.timed(a.warmup, kr, dist)
+        elr, aggr, _ = fedr.timed(a.warmup, kr, dist)
         resident = {"images_per_sec": round(kr * a.batch * world / elr, 2), "steps": kr, "ms_per_aggregation_round": round(aggr, 3),
                     "round_split_ms": fedr.round_split()}
         del fedr
@@ -674,7 +767,7 @@ def main():
         # the reference's own arithmetic (--amp 0): exact-fp32 MFMA parity mode, same rounds, shorter sample
         fed32 = Federation(a, rank, world, dev, "fp32")
         k32 = min(a.steps, a.round_iters)
-        el32, agg32 = fed32.timed(a.warmup, k32, dist)
+        el32, agg32, _ = fed32.timed(a.warmup, k32, dist)
         fp32 = {"images_per_sec": round(k32 * a.batch * world / el32, 2), "steps": k32,
                 "ms_per_aggregation_round": round(agg32, 3)}
         del fed32
@@ -694,6 +787,8 @@ def main():
                                    f"all timed",
                        "clients_hosted": world, "federation": FEDERATION, "global_batch": a.batch * world,
                        "images_per_sec_per_client": round(value / world, 2),
+                       "value_is": f"median of {len(win_rates)} back-to-back timed windows of {a.steps} steps each",
+                       "value_windows": win_rates, "value_min": min(win_rates), "value_max": max(win_rates),
                        "ms_per_aggregation_round": round(agg_ms, 3),
                        "round_split_ms": split,
                        "ala_batches_per_round": a.loader_batches,
@@ -719,6 +814,11 @@ def main():
                 line["config"]["frac_of_mfma_peak"] = round(tf / MFMA_PEAK[a.dtype], 4)
             except Exception as e:  # noqa: BLE001  (never lose the headline number to the instrumented pass)
                 line["roofline"] = {"error": repr(e)}
+        if world == 1 and not a.no_dice:
+            try:
+                line["config"]["dice"] = dice_leg(with_cpu=not a.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                line["config"]["dice"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(line), flush=True)

@@ -62,6 +62,23 @@ _lib = None
 ABI_VERSION = 2             # include/fedicra_hip.h FI_ABI_VERSION
 
 
+def source_hash():
+    """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h, sorted by name): names the BUILD a
+    measurement belongs to on a box that has no .git -- bench.py refuses a committed PMC traffic file whose recorded hash
+    differs from the tree it runs in (traffic taken three kernel commits before the benchmarked build)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(here), "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -75,7 +92,6 @@ def lib():
             _lib = None
             raise FiError(f"{LIB_PATH} reports C-ABI version {got}, this host mirror was written against {ABI_VERSION} "
                           "(include/fedicra_hip.h FI_ABI_VERSION): rebuild with `make -C fedicra_amd/csrc`")
-        _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
         _lib.fi_conv2d_wgrad_workspace.restype = C.c_long

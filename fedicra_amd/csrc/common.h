@@ -193,9 +193,12 @@ __device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
   return x ^ (uint32_t)(seed >> 32);
 }
 // Element-wise dropout draws for the 4 consecutive elements of group `group` (= flat element index / 4): ONE full
-// hash of the group index and one more multiply-xorshift round give 64 mixed bits = four 16-BIT draws, returned in the
-// top halves of r[0..3] so that callers keep comparing against the 32-bit threshold (the keep probability is quantised to
-// 2^-16: 1.5e-5 relative at p = 0.05 .. 0.5).  Integer multiplies are quarter rate on CDNA and every conv / BN kernel
+// hash of the group index gives the word h, one more multiply-xorshift round of h the word g: four 16-BIT draws, returned
+// in the top halves of r[0..3] so that callers keep comparing against the 32-bit threshold (the keep probability is
+// quantised to 2^-16: 1.5e-5 relative at p = 0.05 .. 0.5).  g is a BIJECTION of h, so the four draws carry 32 bits of
+// entropy, not 64: (r[2], r[3]) is a deterministic function of (r[0], r[1]) -- a mixing one, which is what a keep mask
+// needs: each position keeps at the nominal rate and the four keep bits of a group (and of neighbouring groups) show no
+// pairwise correlation at p = 0.05 / 0.3 / 0.5 (tests/test_ops_gpu.py::test_dropout_rng_statistics_and_replay).  Integer multiplies are quarter rate on CDNA and every conv / BN kernel
 // that regenerates the mask is VALU-issue-bound (tools/ws2_trace.py: a loader stage of 256^2 32->32 takes 3 200 cycles
 // without and 5 700 with dropout): per 4 elements this is 4 multiplies + ~14 other VALU ops where the per-element
 // multiply-xorshift it replaces (round 2) cost 7 + ~30, and a full hash per element ~65 instructions per element.

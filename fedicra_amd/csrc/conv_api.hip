@@ -235,6 +235,9 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
     const bool plain = !a.y_f32 && !a.acc0 && !a.acc1 && a.co0 % 4 == 0 && a.co1 % 4 == 0;
     // 64 x 64-wave-tile form (conv_fwd_ws2_kernel; conv_ws2.h): needs the chunk-major second operand (FiConv.w16), 16-channel
     // chunks that do not straddle the two sources, whole 64-channel slabs, a plain epilogue and 32-bit byte offsets
+    // the fields the 64 x 64 form overwrites, as the other forms expect them (restored when its launcher declines)
+    const void* const w_plain = a.w;
+    const int tilesY_plain = a.tilesY, nct_plain = a.nct;
     if (d->w16 && depth == 0 && !f32 && d->ksize == 3 && (a.xf == 0 || a.xf == 1) && plain && env_ws2() != 0 &&
         (g_tune[0] < 0 || g_tune[0] == 7)) {                   // forcing any other form (incl. 2 = the old rule) keeps off it
       const long big = (long)d->N * d->H * d->W * 2;
@@ -260,7 +263,12 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
         const int form = cout == 64 ? 3 : 4;
         // 32 outputs with element dropout in the loader: runs of half the length measured 10 % ahead (329 -> 291 us, 256^2 32->32)
         const int wgs = g_tune[3] ? (int)g_tune[3] : ((form == 4 && a.xf == 1 && a.t0.drop_mode == FI_DROP_RNG_ELEM) ? 2 : 0);
-        return d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, wgs, a, st) : fi_conv_fwd_ws2_bf16(form, wgs, a, st);
+        const ConvArgs keep = a;
+        const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, wgs, a, st) : fi_conv_fwd_ws2_bf16(form, wgs, a, st);
+        if (rc != FI_ERR_UNSUPPORTED) return rc;
+        a = keep;                                // the launcher's own bounds (LDS bytes, WR / SI shapes) said no: the forms below
+        a.w = w_plain, a.wrows = 0, a.tilesY = tilesY_plain, a.nct = nct_plain;
+        goto ws2_done;
       }
       // measured rule (FI_WS2 = 1; profiles/r03_*_kbench2_ws2*.txt): the batched fused launches that fill the persistent grid,
       // 128-channel slabs with 64-channel pixel groups -- 1.05-1.16x the 32-pixel-tile form there (64^2 128->128 160 -> 145 us,
@@ -290,9 +298,11 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
         // half the length (512 workgroups queued on 256 CUs: the run lengths differ by up to 2x between CUs)
         const int wgs = g_tune[3] ? (int)g_tune[3] : (si ? 2 : 0);
         const int rc = d->dtype == FI_F16 ? fi_conv_fwd_ws2_f16(form, wgs, a, st) : fi_conv_fwd_ws2_bf16(form, wgs, a, st);
-        return rc;
+        if (rc != FI_ERR_UNSUPPORTED) return rc;
+        a.w = w_plain, a.wrows = 0, a.tilesY = tilesY_plain, a.nct = nct_plain;      //  fall through to the forms below
       }
     }
+  ws2_done:
     // wave-specialised form (conv_fwd_ws_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 32-bit
     // byte offsets into every tensor
     {

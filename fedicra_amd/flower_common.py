@@ -682,4 +682,4 @@ def get_evaluate_metrics_aggregation_fn(args, val_metrics):
 
 
 # the reference defines the tree-energy losses in this module (flower_common.py:646-818); re-exported under the same names
-from .tree_energy import MScaleRecurveTreeEnergyLoss, TreeEnergyLoss  # noqa: E402,F401
+from .tree_energy import MScaleAddTreeEnergyLoss, MScaleRecurveTreeEnergyLoss, TreeEnergyLoss, tv_loss  # noqa: E402,F401

@@ -162,6 +162,10 @@ class MyClient(BaseClient):
                 with torch.cuda.stream(probe_stream), torch.no_grad():
                     batched = net.probe_heatmaps(x, others)
                 if batched is None:
+                    # the batched form does not apply to this model (probe_heatmaps' own preconditions): the second stream
+                    # has already been forked into the capture by wait_event(fork) -- JOIN it before dropping it, a capture
+                    # must not end with an unjoined stream
+                    main.wait_stream(probe_stream)
                     probe_stream = None
         finally:
             ops._ctx.bn_events = None
@@ -250,9 +254,12 @@ class MyClient(BaseClient):
                 x, y = self._stage(sampled_batch)
                 pattern = self._set_freeze(i_iter)
                 if opt.frozen == "torch1":
-                    # which parameters step (and under which counters) also depends on which ones have ever held a
-                    # gradient: a step captured before that set is complete must not be replayed after it grew
-                    pattern = "{}/{}".format(pattern, len(opt._ever))
+                    # which parameters step, and under which step COUNTERS, also depends on which ones have ever held a
+                    # gradient and on how this round's fresh optimizer has grouped them so far (round 1: out_conv on
+                    # counter 0, the rest on counter 1; later rounds: everything on counter 0 from the first head step on).
+                    # A captured step bakes the counter addresses in, so the key carries the whole layout the step starts
+                    # from -- which, with the freeze pattern, determines the layout it leaves
+                    pattern = "{}/{}/{}".format(pattern, len(opt._ever), opt.layout_key())
                 if self.use_graph:
                     rec = self._steps.get(pattern)
                     if rec is None:

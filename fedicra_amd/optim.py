@@ -82,6 +82,11 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = True):
         self.model.zero_grad(set_to_none)
 
+    def layout_key(self):
+        """The round's parameter groups so far as (counter index, #parameters, first name) -- what a captured step of the
+        'torch1' semantics must agree on with the round it is replayed in (flower_pCE_2D.train_steps)."""
+        return tuple((gi, len(names), names[0] if names else "") for names, (gi, _) in self._groups.items())
+
     # -- the step -------------------------------------------------------------------------------
     def _group_for(self, active):
         key = tuple(active)

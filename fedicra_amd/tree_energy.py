@@ -65,3 +65,40 @@ class MScaleRecurveTreeEnergyLoss(nn.Module):
         tree_loss = (rois * torch.abs(prob - outs[2])).sum()
         tree_loss = tree_loss / N.clamp(min=1)        # `if N > 0: tree_loss /= N` without a host sync (N = 0 => sum = 0)
         return weight * tree_loss, outs[0], outs[1], outs[2]
+
+
+class MScaleAddTreeEnergyLoss(nn.Module):
+    """/root/reference/code/flower_common.py:692-753: the PARALLEL multi-scale form -- every high-level tree filters the
+    low-level affinity map `AS` itself (not the previous scale's output, as the recurve form does) and the three masked L1
+    terms are ADDED before the division by the number of unlabeled pixels.  No reference script constructs it; built for the
+    surface with the reference's signature and return tuple (weight * loss, AS_1, AS_2, AS_3)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mst_layers = MinimumSpanningTree(TreeFilter2D.norm2_distance)
+        self.tree_filter_layers = TreeFilter2D(groups=1, sigma=0.02)
+
+    def forward(self, preds, low_feats, high_feats_1, high_feats_2, high_feats_3, unlabeled_ROIs, weight):
+        preds = preds.float()
+        low_feats, rois, N, size = _prep(preds, low_feats, unlabeled_ROIs)
+        prob = torch.softmax(preds, dim=1)
+        # as in the recurve form, the reference reads AS_1..AS_3 unconditionally: all three guidance maps are required
+        highs = [F.interpolate(hf.float(), size=size, mode="bilinear", align_corners=False)
+                 for hf in (high_feats_1, high_feats_2, high_feats_3)]
+        trees = self.mst_layers.forward_many([low_feats] + highs)
+        AS = self.tree_filter_layers(feature_in=prob, embed_in=low_feats, tree=trees[0])
+        outs = [self.tree_filter_layers(feature_in=AS, embed_in=hf, tree=tree, low_tree=False)
+                for hf, tree in zip(highs, trees[1:])]
+        tree_loss = (rois * torch.abs(prob - outs[0])).sum() + (rois * torch.abs(prob - outs[1])).sum()
+        tree_loss = tree_loss + (rois * torch.abs(prob - outs[2])).sum()          # the reference's order of additions
+        tree_loss = tree_loss / N.clamp(min=1)
+        return weight * tree_loss, outs[0], outs[1], outs[2]
+
+
+def tv_loss(predication):
+    """/root/reference/code/flower_common.py:636-643: mean contour length of a soft prediction -- a 3x3 erosion (min-pool as
+    the negated max-pool of the negation) followed by a 3x3 dilation minus the eroded map, rectified, averaged.  (Argument
+    name as spelled in the reference.)  Elementwise / pooling glue on torch ops, differentiable through them."""
+    eroded = -F.max_pool2d(-predication, (3, 3), 1, 1)
+    contour = torch.relu(F.max_pool2d(eroded, (3, 3), 1, 1) - eroded)
+    return torch.mean(torch.abs(contour))

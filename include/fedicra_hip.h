@@ -195,7 +195,7 @@ int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, voi
 int fi_pack_weights(const float* src, void* dst, int cout, int kk, int cin, int mode, int dtype, void* stream);
 
 /* 1 when a filter of this shape gets the chunk-major second operand (FiConv.w16): 16-bit storage, 3x3, contraction channels
- * (cin; for the dgrad operand pass the conv's cout as cin and vice versa) a multiple of 32, output channels of 64.
+ * (cin; for the dgrad operand pass the conv's cout as cin and vice versa) and output channels both multiples of 32 (the 32-output resident-filter form; 64 / 128-output slabs otherwise).
  * FI_WS2=0 in the environment switches the form off (A/B runs of one build). */
 int fi_conv_weight_chunk16(int dtype, int ksize, int cin, int cout);
 

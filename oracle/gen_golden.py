@@ -778,12 +778,142 @@ def g8_eval_metrics():
     save("g8_eval_metrics.npz", **d)
 
 
+def g19_minifed_dice(seeds=range(8), threads=(8, 1), rounds=12, iters=8, horizon=6):
+    """Metric leg 3, "Dice vs CPU ref" (BASELINE.md section 3-5), from the reference's OWN classes: the miniature federation
+    of fedicra_amd/minifed.py -- 2 FedAvg clients x `rounds` rounds x 8 local iterations -- driven through the reference's
+    ``MyClient._train`` (flower_pCE_2D.py:51-181), ``MyModel.get_weights`` / ``set_weights`` (flower_common.py:488-489,
+    627-633) around the restated flwr ``aggregate`` (absent third party) and its ``evaluate`` (flower_common.py:122-136,
+    val_2D.py:9-74; medpy served by oracle.losses_ref.medpy_binary as in g8), for `seeds` x `threads` CPU threads: the
+    spread of the reference's own final Dice under nothing but the dropout seed and the thread count is what a second
+    correct implementation can be held to after ~100 AdamW steps per client.
+    HORIZON part: ONE client, k = 1..`horizon` local iterations from the seeded state (mask seed 0), then the eval-mode
+    logits of the first four validation cases and the validation Dice -- the vectors the HIP path must match to 1e-4 for
+    as many steps as fp32 round-off allows (tests/test_round4_gpu.py asserts the measured horizon)."""
+    import types
+    import flower_pCE_2D as ref
+    import flower_common as fc
+    import val_2D
+    from oracle import losses_ref, fed_ref
+    from fedicra_amd.minifed import make_data
+    binary = types.SimpleNamespace(**{k: getattr(losses_ref.medpy_binary, k)
+                                      for k in ("dc", "hd95", "recall", "precision", "jc", "specificity", "ravd")})
+    val_2D.metric = types.SimpleNamespace(binary=binary)
+    ref.log = lambda *a, **k: None
+    data, val = make_data()
+    n_k = (3, 2)
+
+    class Loader(list):
+        pass
+
+    vl = Loader(val)
+    vl.dataset = list(range(len(val)))
+
+    def clients(K, max_iterations):
+        out = []
+        for cid in range(K):
+            args = _args(cid=cid, min_num_clients=K, iters=iters, max_iterations=max_iterations)
+            net = ref.net_factory(args, net_type="unet", in_chns=1, class_num=2)
+            seeded_state(net, 2022)
+            model = fc.MyModel(args, net, data[cid], data[cid])
+            out.append(ref.MyClient(args, model, data[cid], data[cid]))
+        return out
+
+    import contextlib, io
+    d = {"seeds": np.array(list(seeds)), "threads": np.array(list(threads)), "rounds": np.int64(rounds), "iters": np.int64(iters)}
+    dice = np.zeros((len(d["seeds"]), len(d["threads"])))
+    last = np.zeros((len(d["seeds"]), len(d["threads"]), rounds * 2))
+    have = os.path.join(OUT, "g19_minifed_dice.npz")
+    reuse = os.path.exists(have) and os.environ.get("G19_SPREAD", "reuse") == "reuse"
+    if reuse:          # the 16 federations take 4 minutes: G19_SPREAD=new re-runs them, otherwise only the horizon part is re-made
+        old = np.load(have)
+        reuse = (int(old["rounds"]) == rounds and list(old["seeds"]) == list(d["seeds"]) and list(old["threads"]) == list(d["threads"]))
+        if reuse:
+            dice, last = old["dice"], old["last_losses"]
+    for ti, th in enumerate(() if reuse else threads):
+        torch.set_num_threads(int(th))
+        for si, seed in enumerate(seeds):
+            cl = clients(2, 400)
+            for rnd in range(rounds):
+                res = []
+                for cid in range(2):
+                    torch.manual_seed(int(seed) + 100 * rnd + cid)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        l, _ = cl[cid]._train({"iter_global": rnd, "iters": iters, "eval_iters": 99, "batch_size": 4, "stage": "fit"})
+                    last[si, ti, rnd * 2 + cid] = l
+                    res.append((cl[cid].model.get_weights(None), n_k[cid]))
+                glob = fed_ref.fedavg_aggregate(res)
+                for c in cl:
+                    c.model.set_weights(glob, {"iter_global": rnd})
+            with contextlib.redirect_stdout(io.StringIO()):
+                met = fc.evaluate(cl[0].args, cl[0].model.model, vl)
+            dice[si, ti] = float(met["val_mean_dice"])
+            print("g19", "threads", th, "seed", seed, "dice", dice[si, ti])
+    d["dice"], d["last_losses"] = dice, last
+    # horizon vectors: k = 0 is the seeded state itself (no step yet); threads 8 and 1 -- the reference against ITSELF under
+    # nothing but another summation order is the yardstick for what any second fp32 implementation can share after k steps
+    for th, sfx in ((8, ""), (1, "_t1")):
+        torch.set_num_threads(th)
+        hl, hd, hloss, ht = [], [], [], []
+        for k in range(0, horizon + 1):
+            c = clients(1, 200)[0]
+            c.args.iters = k
+            torch.manual_seed(0)
+            l = 0.0
+            with contextlib.redirect_stdout(io.StringIO()):
+                if k:
+                    l, _ = c._train({"iter_global": 0, "iters": k, "eval_iters": 99, "batch_size": 4, "stage": "fit"})
+                met = fc.evaluate(c.args, c.model.model, vl)
+            net = c.model.model.eval()
+            with torch.no_grad():
+                lg = torch.cat([net(b["image"].unsqueeze(1))[0] for b in val[:4]])
+                # TRAIN-mode logits of the client's first batch under dropout seed 77 (batch statistics: what the training
+                # iterations themselves see; the eval-mode ones above go through running statistics that k steps have barely
+                # moved off their initial (0, 1), which blows round-off-level bias steps up by orders of magnitude)
+                net.train()
+                torch.manual_seed(77)
+                lt = net(data[0][0]["image"].unsqueeze(1))[0]
+            hl.append(lg.numpy().copy()); hd.append(float(met["val_mean_dice"])); hloss.append(float(l))
+            ht.append(lt.numpy().copy())
+        d["horizon_logits" + sfx], d["horizon_dice" + sfx] = np.stack(hl).astype(np.float32), np.array(hd)
+        d["horizon_last_loss" + sfx], d["horizon_train_logits" + sfx] = np.array(hloss), np.stack(ht).astype(np.float32)
+    torch.set_num_threads(8)
+    save("g19_minifed_dice.npz", **d)
+
+
+def g20_tree_add_tv():
+    """MScaleAddTreeEnergyLoss and tv_loss of the reference (flower_common.py:692-753, 636-643; SURVEY 2.1 row 2b -- no
+    reference script calls them), the tree extension's kernels served as in g17: loss, the three filtered maps, the
+    gradients w.r.t. the logits and the three head maps; tv_loss value and gradient on a soft map."""
+    _install_tree_kernels()
+    import flower_common as rfc
+    rng = np.random.default_rng(20)
+    B, S = 2, 16
+    img = rng.random((B, 1, S, S), dtype=np.float32)
+    roi = rng.random((B, S, S)) > 0.2
+    mk = lambda *shape: (rng.standard_normal(shape) * 0.7).astype(np.float32)
+    arrs = {"preds": mk(B, 2, S, S), "h1": mk(B, 2, S // 4, S // 4), "h2": mk(B, 2, S // 2, S // 2), "h3": mk(B, 2, S, S)}
+    d = {"image": img, "roi": roi, **arrs}
+    t = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in arrs.items()}
+    low = torch.from_numpy(img).repeat(1, 3, 1, 1)
+    loss, a1, a2, a3 = rfc.MScaleAddTreeEnergyLoss()(t["preds"], low, t["h1"], t["h2"], t["h3"], torch.from_numpy(roi), 0.6)
+    loss.backward()
+    d["add/loss"] = np.array(loss.item())
+    d["add/AS1"], d["add/AS2"], d["add/AS3"] = a1.detach().numpy(), a2.detach().numpy(), a3.detach().numpy()
+    for k in arrs:
+        d[f"add/g_{k}"] = t[k].grad.numpy()
+    p = torch.softmax(torch.from_numpy(mk(B, 3, S, S)) * 3.0, dim=1).requires_grad_(True)
+    tv = rfc.tv_loss(p)
+    tv.backward()
+    d["tv/p"], d["tv/loss"], d["tv/g"] = p.detach().numpy(), np.array(tv.item()), p.grad.numpy()
+    save("g20_tree_add_tv.npz", **d)
+
+
 D_NCLS = {"faz": 2, "odoc": 3, "polyp": 2}
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g6_fedavg_counters", "g7_ala", "g8_eval_metrics", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue", "g18_ours_train"]
+    which = sys.argv[1:] or ["g2_unet", "g2_unet_lc", "g3_losses", "g4_train", "g5_fedicra_train", "g6_fedavg_counters", "g7_ala", "g8_eval_metrics", "g9_unet3d", "g10_gatedcrf", "g11_augment", "g12_vnet", "g13_heads", "g14_metric_aggregation", "g15_two_stream_sampler", "g16_base_datasets", "g17_tree_glue", "g18_ours_train", "g19_minifed_dice", "g20_tree_add_tv"]
     for w in which:
         globals()[w]()

@@ -291,3 +291,32 @@ def mscale_recurve_tree_energy_loss(preds, low_feats, high1, high2, high3, unlab
     if N > 0:
         loss = loss / N
     return weight * loss, outs[0], outs[1], outs[2]
+
+
+def mscale_add_tree_energy_loss(preds, low_feats, high1, high2, high3, unlabeled_rois, weight, sigma=0.02):
+    """MScaleAddTreeEnergyLoss.forward (flower_common.py:692-753): each high-level tree filters the low-level map AS; the
+    three masked L1 terms are summed, then divided by the number of unlabeled pixels."""
+    import torch.nn.functional as F
+    with torch.no_grad():
+        B, _, h, w = preds.shape
+        low = F.interpolate(low_feats, size=(h, w), mode="bilinear", align_corners=False)
+        roi = F.interpolate(unlabeled_rois.unsqueeze(1).float(), size=(h, w), mode="nearest")
+        N = roi.sum()
+    prob = torch.softmax(preds, dim=1)
+    AS = tree_filter(prob, low, minimum_spanning_tree(low), sigma, True)
+    outs = []
+    for hf in (high1, high2, high3):
+        hf = F.interpolate(hf, size=(h, w), mode="bilinear", align_corners=False)
+        outs.append(tree_filter(AS, hf, minimum_spanning_tree(hf), sigma, False))
+    loss = (roi * torch.abs(prob - outs[0])).sum() + (roi * torch.abs(prob - outs[1])).sum()
+    loss = loss + (roi * torch.abs(prob - outs[2])).sum()
+    if N > 0:
+        loss = loss / N
+    return weight * loss, outs[0], outs[1], outs[2]
+
+
+def tv_loss(p):
+    """tv_loss (flower_common.py:636-643): 3x3 min-pool, then 3x3 max-pool minus it, rectified, mean."""
+    import torch.nn.functional as F
+    lo = -F.max_pool2d(-p, 3, 1, 1)
+    return torch.relu(F.max_pool2d(lo, 3, 1, 1) - lo).abs().mean()

@@ -449,3 +449,76 @@ def test_g6_host_aggregate_and_set_weights_follow_the_references_round_trip(gold
         MyModel(args, recv, [], []).set_weights(agg, {"iter_global": 60})
         np.testing.assert_array_equal(recv.flat_counters.numpy(), g[f"K{K}/counters_loaded"])
         np.testing.assert_array_equal(recv.state_dict()["decoder.out_conv.weight"].numpy(), g[f"K{K}/out_conv_weight"])
+
+
+def test_batch_stager_ring_never_serves_a_batch_from_a_recycled_or_aliased_pair(monkeypatch):
+    """staging.BatchStager's slot bookkeeping, driven on the host with stand-ins for the HIP stream / event objects
+    (ADVICE r3): a batch prefetched more than a ring length before its use, out-of-order consumption, serial fetches that
+    walk over pending pairs, and a dropped host batch whose id() is re-used by a new dict -- the consumer must always see
+    the pixels of the batch it asked for."""
+    import contextlib
+    import gc
+    from fedicra_amd import staging
+
+    class Ev:
+        def record(self, stream=None): pass
+        def query(self): return True
+
+    class St:
+        def wait_event(self, ev): pass
+
+    class Hip:
+        Stream = staticmethod(lambda device: St())
+        Event = staticmethod(lambda: Ev())
+        current_stream = staticmethod(lambda: St())
+        stream = staticmethod(lambda s: contextlib.nullcontext())
+        pinned = staticmethod(lambda t: True)
+
+    monkeypatch.setattr(staging, "_Hip", Hip)
+    mk = lambda v: {"image": torch.full((2, 4, 4), float(v)), "label": torch.full((2, 4, 4), v % 250, dtype=torch.uint8)}
+
+    def take(st, b, v):
+        x, y = st.fetch(b)
+        assert float(x.min()) == float(x.max()) == float(v) and int(y[0, 0, 0]) == v % 250, (v, float(x[0, 0, 0]))
+        st.release()
+
+    # (1) trigger 1 of the finding: batch k prefetched, then >= ring-length other batches staged before k is used
+    for slots in (2, 3, 4, 12):
+        st = staging.BatchStager("cpu", slots=slots)
+        late = mk(1000)
+        st.prefetch(late)
+        others = [mk(i) for i in range(3 * slots + 1)]
+        for i, b in enumerate(others):
+            if i + 1 < len(others):
+                st.prefetch(others[i + 1])
+            take(st, b, i)
+        take(st, late, 1000)                                # from its own pair, or serially after its prefetch was given up
+    # (2) out-of-order consumption with several copies in flight, ring of 2
+    st = staging.BatchStager("cpu", slots=2)
+    bs = [mk(i) for i in range(8)]
+    for b in bs[:4]:
+        st.prefetch(b)
+    for i in (2, 0, 3, 1):
+        take(st, bs[i], i)
+    # (3) a held pair is not handed to the next prefetch before release()
+    st = staging.BatchStager("cpu", slots=2)
+    a, b, c = mk(1), mk(2), mk(3)
+    st.prefetch(a); st.prefetch(b)
+    xa, ya = st.fetch(a)
+    st.prefetch(c)                                          # both pairs taken (a held, b pending): c waits for its turn or drops b
+    assert float(xa[0, 0, 0]) == 1.0
+    st.release()
+    take(st, b, 2); take(st, c, 3)
+    # (4) id() aliasing: a prefetched batch is dropped by its owner; a NEW dict (which CPython is free to give the same
+    # id) must not be served the stale pair.  The entry holds its batch, so the id cannot be re-used while it is alive.
+    st = staging.BatchStager("cpu", slots=4)
+    for rep in range(200):
+        old = mk(7)
+        st.prefetch(old)
+        oid = id(old)
+        del old
+        gc.collect()
+        new = mk(9)
+        take(st, new, 9)
+        assert oid in st._pending and id(new) != oid
+        st._pending.clear()
