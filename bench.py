@@ -595,6 +595,10 @@ def roofline_pass(client, a, dtype_name):
     for k, v in prof.items():
         breakdown[k[0]] = breakdown.get(k[0], 0.0) + v["ms"]
     conv_flops = sum(v["flops"] for k, v in prof.items() if k[0].startswith("conv"))
+    # what the launches EXECUTE: differs from the reference-defined count where an algebraic form stands in for a layer (the
+    # statistics-only head of the LC forwards from the input's autocorrelation, csrc/xcorr.hip: 13 x 64 x 64 instead of
+    # 9 x 64 x 512 multiply-adds per pixel) -- a fraction of peak that rises because work was REMOVED shows here
+    conv_xflops = sum(v.get("xflops", v["flops"]) for k, v in prof.items() if k[0].startswith("conv"))
     roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": None, "kernel": f"{fname} (all shapes of the FedICRA iteration)/{dtype_name}",
             "profile_command": "python bench.py --roofline-only  (profiles/*_roofline_kernel_stats.csv, *_pmc_traffic.json)",
@@ -609,6 +613,9 @@ def roofline_pass(client, a, dtype_name):
             "instrumented_iterations": f"{iters - 3} head-phase + 3 body-phase (the timed mix), LC forwards in line: every launch timed alone",
             "hip_launches_per_step": round(sum(v["calls"] for v in prof.values()) / float(iters), 1),
             "conv_flops_per_step": conv_flops / float(iters),
+            "executed_flops_per_step": conv_xflops / float(iters),
+            "executed_flops_note": "conv_flops_per_step = the reference-defined algorithmic conv FLOPs of the iteration (what "
+                                   "frac_of_mfma_peak divides); executed_flops_per_step = what the launches really multiply",
             "kernel_time_breakdown_ms_per_step": {k: round(v / float(iters), 4) for k, v in sorted(breakdown.items())}}
     # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 PMC run of this same
     # workload (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied -- see the json's header)
@@ -812,6 +819,8 @@ def main():
                 tf = roof["conv_flops_per_step"] / step_s / 1e12          # same head : body mix on both sides of the ratio
                 line["config"]["conv_tflops_per_gpu"] = round(tf, 2)
                 line["config"]["frac_of_mfma_peak"] = round(tf / MFMA_PEAK[a.dtype], 4)
+                line["config"]["executed_tflops_per_gpu"] = round(roof["executed_flops_per_step"] / step_s / 1e12, 2)
+                line["config"]["executed_frac_of_mfma_peak"] = round(roof["executed_flops_per_step"] / step_s / 1e12 / MFMA_PEAK[a.dtype], 4)
             except Exception as e:  # noqa: BLE001  (never lose the headline number to the instrumented pass)
                 line["roofline"] = {"error": repr(e)}
         if world == 1 and not a.no_dice:

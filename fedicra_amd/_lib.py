@@ -28,6 +28,7 @@ EXPORTS = [
     "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
+    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout",
 ]
 
 
@@ -97,6 +98,7 @@ def lib():
         _lib.fi_conv2d_wgrad_workspace.restype = C.c_long
         _lib.fi_conv3d_wgrad_fused_workspace.restype = C.c_long
         _lib.fi_tree_mst_workspace.restype = C.c_long
+        _lib.fi_conv2d_stats_xcorr_workspace.restype = C.c_long
     return _lib
 
 
@@ -181,12 +183,13 @@ class KernelProfile:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, nbytes, e0, e1 in self.rows:
-            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for key, flops, nbytes, e0, e1, xflops in self.rows:
+            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "xflops": 0.0})
             a["calls"] += 1
             a["ms"] += max(e0.elapsed_time(e1) - self.overhead_ms, 0.0)
-            a["flops"] += flops
+            a["flops"] += flops                          # ALGORITHMIC work of the layer (the reference-defined count)
             a["bytes"] += nbytes
+            a["xflops"] += xflops                        # work the launch EXECUTES (differs where an algebraic form replaces the layer)
         return agg
 
 
@@ -217,10 +220,10 @@ def profile_block():
 
 
 class _Timed:
-    __slots__ = ("key", "flops", "bytes", "e0")
+    __slots__ = ("key", "flops", "bytes", "e0", "xflops")
 
-    def __init__(self, key, flops, nbytes):
-        self.key, self.flops, self.bytes = key, flops, nbytes
+    def __init__(self, key, flops, nbytes, xflops):
+        self.key, self.flops, self.bytes, self.xflops = key, flops, nbytes, xflops
 
     def __enter__(self):
         self.e0 = torch.cuda.Event(enable_timing=True)
@@ -229,7 +232,7 @@ class _Timed:
     def __exit__(self, *a):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        _prof.rows.append((self.key, self.flops, self.bytes, self.e0, e1))
+        _prof.rows.append((self.key, self.flops, self.bytes, self.e0, e1, self.xflops))
 
 
 class _NoTime:
@@ -243,10 +246,10 @@ class _NoTime:
 _NOTIME = _NoTime()
 
 
-def _timed(kind, shape_key, flops, nbytes):
+def _timed(kind, shape_key, flops, nbytes, executed_flops=None):
     if _prof is None:
         return _NOTIME
-    return _Timed((kind,) + tuple(shape_key), float(flops), float(nbytes))
+    return _Timed((kind,) + tuple(shape_key), float(flops), float(nbytes), float(flops if executed_flops is None else executed_flops))
 
 
 def _esz(t):
@@ -328,6 +331,41 @@ def conv2d_fwd_fused(x0, t0, x1, t1, w, bias, y, stats, *, ksize, groups, cout=N
                                        int(gi), int(bool(shared0)), ptr(x0), ptr(x1), ptr(w), ptr(bias), ptr(y), ptr(stats),
                                        C.c_long(0 if stats is None else stats.numel() // groups), stream()),
              "fi_conv2d_fwd_fused")
+
+
+_xcorr_ws = {}
+
+
+def conv2d_stats_xcorr(x0, t0, w, bias, stats, *, groups, cout, workspace=None, tag="conv_stats_xcorr"):
+    """fi_conv2d_stats_xcorr: the statistics a statistics-only fi_conv2d_fwd_fused launch would add, from the input's
+    autocorrelation (csrc/xcorr.hip).  x0 dense NHWC [N][H][W][64] 16-bit (raw + t0, or the activation itself); w the 3x3
+    forward operand; stats fp64 [G][SLOTS][cout][2] zeroed.  Returns False when the shape is not covered (nothing launched).
+    The workspace (~190 MB for 84 x 128^2 -> 512) is cached per (device, shape): stream-ordered reuse, like the arena."""
+    _dev(x0)
+    N, H, W, c0 = x0.shape
+    d = FiConv(dt(x0.dtype), N, H, W, 3, c0, 0, int(cout), 0, 0, 0, 0)
+    gi = N // groups
+    need = lib().fi_conv2d_stats_xcorr_workspace(C.byref(d), int(gi))
+    if need == FI_ERR_UNSUPPORTED:
+        return False
+    if need < 0:
+        _chk(int(need), "fi_conv2d_stats_xcorr_workspace")
+    if workspace is None:
+        # per stream: two clients hosted by one process run their LC forwards on different streams at the same time
+        key = (x0.device.index, torch.cuda.current_stream().cuda_stream, N, H, W, int(cout), gi, x0.dtype)
+        workspace = _xcorr_ws.get(key)
+        if workspace is None or workspace.numel() < need:
+            workspace = _xcorr_ws[key] = torch.empty(need, dtype=torch.uint8, device=x0.device)
+    px = N * H * W
+    with _timed(tag, (str(x0.dtype)[6:], N, H, W, c0, int(cout), 3, "xcorr"), 2.0 * px * c0 * cout * 9,
+                x0.numel() * _esz(x0) + c0 * cout * 9 * _esz(x0), executed_flops=2.0 * px * 13 * c0 * c0):
+        rc = lib().fi_conv2d_stats_xcorr(C.byref(d), None if t0 is None else C.byref(t0), int(gi), ptr(x0), ptr(w), ptr(bias),
+                                         ptr(stats), C.c_long(stats.numel() // groups), ptr(workspace),
+                                         C.c_long(workspace.numel()), stream())
+    if rc == FI_ERR_UNSUPPORTED:
+        return False
+    _chk(rc, "fi_conv2d_stats_xcorr")
+    return True
 
 
 def bn_finalize_groups(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, shared=False):

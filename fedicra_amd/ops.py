@@ -659,6 +659,10 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
 
 
 # ----------------------------------------------------------------------------- fused probe forward
+_XCORR = os.environ.get("FI_XCORR", "1") != "0"                # measurement switch: 0 = the direct statistics-only launch
+_XCORR_MIN_COUT = int(os.environ.get("FI_XCORR_MIN_COUT", "192"))   # 13 x 64 x 64 vs 9 x 64 x Cout multiply-adds: pays from Cout ~ 2 x 92 on
+
+
 class RawAct:
     """A ConvBlock half whose activation z = dropout(act(BN(y))) is never materialised: the raw convolution output y, the
     coefficient rows of its BatchNorm (fp32 [2][G][C], one row pair per statistics group) and the activation slope.  The
@@ -721,7 +725,15 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
         raise L.FiError("pooling / dropout in the loader need a raw source 0")
     stats = _ctx.arena.take(groups * L.STATS_SLOTS * cout * 2, dev)
     y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev) if store else None
-    L.conv2d_fwd_fused(x0, t0, x1, t1, wp, conv.bias, y, stats, ksize=ksize, groups=groups, cout=cout, shared0=shared0)
+    done = False
+    if (not store and _XCORR and ksize == 3 and x1 is None and not shared0 and not pool and in_drop is None
+            and x0.dtype != torch.float32 and cin == 64 and cout >= _XCORR_MIN_COUT):
+        # statistics-only launch of a wide layer on a 64-channel input (the auxiliary head of the LC forwards, 64 -> 512): the
+        # statistics from the input's autocorrelation instead of the convolution nobody reads (csrc/xcorr.hip).  fp32 parity
+        # mode, other shapes and FI_XCORR=0 keep the direct launch; False = shape not covered, nothing was launched
+        done = L.conv2d_stats_xcorr(x0, t0, wp, conv.bias, stats, groups=groups, cout=cout)
+    if not done:
+        L.conv2d_fwd_fused(x0, t0, x1, t1, wp, conv.bias, y, stats, ksize=ksize, groups=groups, cout=cout, shared0=shared0)
     coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
     probe_after(bn)
     L.bn_finalize_groups(stats, groups, float((N // groups) * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,

@@ -119,6 +119,26 @@ int fi_conv2d_fwd_fused(const FiConv* d, const FiInXform* t0, const FiInXform* t
                         const void* x0, const void* x1, const void* w, const float* bias, void* y, double* stats,
                         long stats_group_stride, void* stream);
 
+/* The statistics of a 3x3 convolution WITHOUT the convolution (csrc/xcorr.hip): what a STATISTICS-ONLY fi_conv2d_fwd_fused
+ * launch (y == NULL) adds to `stats` -- per group and output channel the sum and the sum of squares of y = conv(z) + bias over
+ * the group's pixels -- from the 13 autocorrelation matrices of the 64-channel input (A_d = sum_q z(q) z(q+d)^T, |d| <= 2,
+ * on the matrix pipe with K = pixels), the quadratic form with the filter, and the convolution evaluated on the one-pixel
+ * frame around each image (taken off again).  53 K instead of 295 K multiply-adds per pixel for the auxiliary head
+ * Conv2d(64, 512, 3) of the LC forwards (/root/reference/code/networks/unet.py:261-267, flower_pCE_2D.py:128-139), whose
+ * output nobody reads.  Covered: 16-bit storage, ksize 3, c0 == 64, c1 == 0, W in {64, 128}, 4 <= H <= 144, co0 % 8 == 0,
+ * at most 8 groups; t0 as for fi_conv2d_fwd_fused without pool / dropout (NULL: x0 is the activation itself); w = the
+ * forward operand [co0][9][64] (fi_pack_weights mode 0).  FI_ERR_UNSUPPORTED otherwise: the caller makes the direct launch.
+ * stats: fp64 [groups][FI_STATS_SLOTS][co0][2], zeroed by the caller; slot 0 of every group is WRITTEN.  The values are those
+ * of the exact fp32 outputs; the direct launch takes them of the outputs as rounded to the storage type (~1e-6 relative
+ * apart).  workspace: caller-owned, fi_conv2d_stats_xcorr_workspace bytes (< 0: FI_ERR_*).
+ * fi_conv2d_stats_xcorr_layout (tests): byte offsets of { partials, A fp64 [groups][13*4096 + 64], B, edge strips, ring
+ * weights, ring statistics, Q, workgroups per group that hold rows } inside the workspace. */
+long fi_conv2d_stats_xcorr_workspace(const FiConv* d, int group_images);
+int fi_conv2d_stats_xcorr_layout(const FiConv* d, int group_images, long* offsets);
+int fi_conv2d_stats_xcorr(const FiConv* d, const FiInXform* t0, int group_images, const void* x0, const void* w,
+                          const float* bias, double* stats, long stats_group_stride, void* workspace, long workspace_bytes,
+                          void* stream);
+
 /* Measurement hook (tools/kbench.py, tests): which forward kernel fi_conv2d_fwd[_fused] launches.  v2 = -1: the library's
  * per-layer choice (default), 0: the one-tile kernel everywhere, 1: the persistent kernel wherever it applies (16-bit
  * storage, 3x3, whole-vector channel counts, plain epilogue), 3: the thin-layer kernel (filter in registers) wherever it
