@@ -51,6 +51,12 @@ static long wgrad_blocks() {
   static long v = env_long("FI_WGRAD_BLOCKS", 512);
   return v;
 }
+// the pixel-split kernel of the thin layers (fewer than 32 channels on a side): its slices are a few KB, what it lacks is
+// bytes in flight -- its own workgroup count (FI_WGRAD_BLOCKS_THIN; 0 = FI_WGRAD_BLOCKS)
+static long wgrad_blocks_thin() {
+  static long v = env_long("FI_WGRAD_BLOCKS_THIN", 0);
+  return v > 0 ? v : wgrad_blocks();
+}
 
 // which forward kernel: [0] -1 = FI_V2 from the environment (default 2: per-layer choice), 0 = one-tile kernel, 1 = persistent
 // kernel wherever it applies, 3 = thin-layer kernel, 4 / 5 / 6 = wave-specialised kernel with 4 / 8 / 2 x 4 producer waves, 7 = the
@@ -422,7 +428,7 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   p->tilesY = fi_cdiv(d->H, p->th);
   const long ntiles = (long)d->N * p->tilesX * p->tilesY;
   // ~2 workgroups per CU in total; every spatial workgroup costs one |dw| slice of workspace traffic
-  long sb = wgrad_blocks() / ((long)p->nco * p->nci);
+  long sb = (p->quad ? wgrad_blocks() : wgrad_blocks_thin()) / ((long)p->nco * p->nci);
   if (sb < 1) sb = 1;
   if (sb > ntiles) sb = ntiles;
   p->sb = (int)sb;
