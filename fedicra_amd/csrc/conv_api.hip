@@ -1,5 +1,6 @@
 // C-ABI entry points for the convolution kernels: argument checks + tile-shape selection.
 #include "conv_impl.h"
+#include "wgrad_rows.h"
 
 int fi_conv_fwd_f32_k1(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_f32_k3(int th, int nf, int ck, const ConvArgs& a, hipStream_t st);
@@ -9,6 +10,8 @@ int fi_conv_wgrad_f32_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream
 int fi_conv_wgrad_f32_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_bf16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_bf16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
+int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_bf16_k1(int th, const WgradArgs& a, hipStream_t st);
@@ -406,7 +409,19 @@ struct WgradPlan {
   int quad;             // 1: 32x32 channel tile, one 16x16 quadrant per wave (Cin, Cout >= 32)
   int nfo, nfi, nco, nci, th, tilesX, tilesY, sb;
   size_t part_stride;
+  int rows;             // 1: the row-streaming kernel (wgrad_rows.h) when the caller gives a workspace: sb_rows items, one slice each
+  int ws, strips, rpw, chunks, sb_rows;
 };
+// FI_WGRAD_ROWS (default 1) / fi_wgrad_tuning: the row-streaming kernel on the thin 3x3 layers it covers
+static long g_wgrad_rows = -1;
+static bool wgrad_rows_on() {
+  static long v = env_long("FI_WGRAD_ROWS", 1);
+  return (g_wgrad_rows >= 0 ? g_wgrad_rows : v) != 0;
+}
+extern "C" int fi_wgrad_tuning(int rows) {
+  g_wgrad_rows = rows;
+  return 0;
+}
 static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   if (!d) return FI_ERR_NULL;
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
@@ -433,6 +448,25 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   if (sb > ntiles) sb = ntiles;
   p->sb = (int)sb;
   p->part_stride = (((size_t)cout * d->ksize * d->ksize * cin + cout) + 3) & ~(size_t)3;   // 16-B rows for the reducer
+  // thin 3x3 layers on large maps: whole rows streamed through an LDS ring instead of 16 x 16-pixel tiles (wgrad_rows.h)
+  p->rows = 0;
+  if (wgrad_rows_on() && depth == 0 && d->dtype != FI_F32 && d->ksize == 3 && (cout == 16 || cout == 32) &&
+      (cin == 16 || cin == 32) && (cin == 16 || cout == 16) && d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->W % 32 == 0 && (d->W <= 256 || d->W % 256 == 0) &&
+      d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 17)) {
+    p->rows = 1;
+    p->ws = d->W <= 256 ? d->W : 256;
+    p->strips = d->W / p->ws;
+    // ~3 workgroups per CU (16 input channels: 49 KB of LDS each), ~1.5 with 32 (66 KB; measured 67 us at 384 items against
+    // 78 at 768 on 12 x 512^2 32 -> 16); a run is at least FI_WGRAD_ROWS_MINR rows (two dy halo rows per run)
+    static const long items_env = env_long("FI_WGRAD_ROWS_ITEMS", 0), minr = env_long("FI_WGRAD_ROWS_MINR", 16);
+    const long items_target = items_env > 0 ? items_env : (cin == 16 ? 768 : 384);
+    long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
+    if (rpw < minr) rpw = minr;
+    if (rpw > d->H) rpw = d->H;
+    p->rpw = (int)rpw;
+    p->chunks = fi_cdiv(d->H, p->rpw);
+    p->sb_rows = d->N * p->strips * p->chunks;
+  }
   return 0;
 }
 
@@ -440,7 +474,7 @@ extern "C" long fi_conv2d_wgrad_workspace(const FiConv* d) {
   WgradPlan p;
   const int rc = plan_wgrad(d, &p);
   if (rc) return rc;
-  return (long)(p.part_stride * p.sb * sizeof(float));
+  return (long)(p.part_stride * (p.rows && p.sb_rows > p.sb ? p.sb_rows : p.sb) * sizeof(float));
 }
 
 static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const void* dy, float* dw, float* dbias,
@@ -530,6 +564,8 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   if (rc) return rc;
   if (d->c1 > 0 && !x1) return FI_ERR_NULL;
   const int cin = (depth > 0 ? 3 : 1) * (d->c0 + d->c1), cout = d->co0;
+  if (!workspace) p.rows = 0;                               // (atomic accumulation: the tile kernels)
+  if (p.rows) p.sb = p.sb_rows;
   if (workspace && workspace_bytes < (long)(p.part_stride * p.sb * sizeof(float))) return FI_ERR_SHAPE;
   WgradArgs a;
   a.x0 = x0;
@@ -556,7 +592,16 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
 #endif
   hipStream_t st = (hipStream_t)stream;
   int r;
-  if (p.quad) {
+  if (p.rows) {
+    WgRowsArgs ra;
+    ra.x0 = x0, ra.x1 = x1 ? x1 : x0, ra.dy = dy;
+    ra.part = (float*)workspace, ra.part_stride = p.part_stride;
+    ra.N = d->N, ra.H = d->H, ra.W = d->W, ra.c0 = d->c0, ra.c1 = d->c1;
+    ra.ws = p.ws, ra.strips = p.strips, ra.rpw = p.rpw, ra.chunks = p.chunks;
+    ra.want_bias = dbias != nullptr;
+    r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_f16(cin / 16, cout / 16, ra, p.sb, st)
+                           : fi_conv_wgrad_rows_bf16(cin / 16, cout / 16, ra, p.sb, st);
+  } else if (p.quad) {
     if (d->dtype == FI_F32)
       r = d->ksize == 3 ? fi_conv_wgrad_quad_f32_k3(p.th, a, st) : fi_conv_wgrad_quad_f32_k1(p.th, a, st);
     else if (d->dtype == FI_F16)

@@ -1,0 +1,240 @@
+// Row-streaming filter gradient for the THIN layers (16 / 32 channels a side at 512^2 and 256^2; gfx950 only).
+//
+// dW[co][kr][kc][ci] = sum_{n,r,c} dy[n][r][c][co] * x[n][r + kr - 1][c + kc - 1][ci]   (/root/reference/code/networks/unet.py:14-30:
+// the weight gradient of ConvBlock's 3x3 convolutions; dbias = sum dy).  At these widths the layer is HBM-bound -- 64 ... 96
+// bytes per pixel against 9 x 16 x 16 ... 32 multiply-adds -- and the tile kernels (conv_wgrad_kernel) sit at a quarter of
+// the roofline: a 16 x 16-pixel tile is sixteen 512-byte row segments 16 KB apart, one tile of loads in flight per workgroup,
+// two barriers and an LDS commit per 256 pixels.  Here a workgroup STREAMS image rows:
+//   * it owns a run of x rows of one image strip (<= 256 columns); x row rho meets the three dy rows rho - 1, rho, rho + 1 (filter
+//     rows kr = 2, 1, 0), so per 32-pixel K step three x operands (the column shifts kc) and three dy operands feed nine MFMAs
+//     (v_mfma_f32_16x16x32) per 16 x 16 channel block -- a third of the LDS reads of the dy-major order;
+//   * rows arrive as whole contiguous segments (8 ... 16 KB per row and tensor), one row of x and one of dy per step, staged
+//     through TWO register stages (a row's loads are issued two steps before its store) into a 2-row (x) / 4-row (dy) LDS
+//     ring: ONE barrier per row; 2-3 workgroups per CU keep several rows of loads in flight;
+//   * LDS holds channel-BLOCK planes [block][pixel][16 ch] (32 bytes per pixel): the 32 lanes a transposing read serves at
+//     once cover 8 consecutive pixels = 256 contiguous bytes (the K order inside an operand is permuted for that: the same
+//     permutation on both operands), no padding, no conflicts;
+//   * the four waves split the K steps of a row; their accumulators (9 taps x blocks x 4 registers) are folded through LDS once
+//     per workgroup and written as ONE partial slice in the layout of conv_wgrad_kernel, which fi_wgrad_reduce_multi folds.
+#pragma once
+#include "conv_impl.h"
+
+struct WgRowsArgs {
+  const void* x0;
+  const void* x1;
+  const void* dy;
+  float* part;             // [items][part_stride]
+  size_t part_stride;
+  int N, H, W;
+  int c0, c1;              // input channels from x0 / x1 (multiples of 16)
+  int ws, strips, rpw, chunks;     // strip width, strips per row, x rows per item, items per (image, strip)
+  int want_bias;
+};
+
+template <typename T>
+__device__ __forceinline__ typename DT<T>::frag_t wgr_frag(const char* addr) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_v;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)addr);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(addr + 16 * 32));     // pixels + 16
+  union {
+    s16x4_t h[2];
+    typename DT<T>::frag_t v;
+  } u;
+  u.h[0] = lo;
+  u.h[1] = hi;
+  return u.v;
+}
+
+// NCI / NCO: 16-channel blocks of the input / gradient side.  WSP = ws + 2 (x row with its two halo pixels).
+template <typename T, int NCI, int NCO>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, ws = a.ws;
+  const int xplane = (ws + 2) * 32, dplane = ws * 32;
+  const int xrow = NCI * xplane, drow = NCO * dplane;
+  char* const xs = smem;                        // [2][NCI][ws + 2][16]
+  char* const ds = smem + 2 * xrow;             // [4][NCO][ws][16]
+  // item -> (image, strip, row chunk)
+  int item = blockIdx.x;
+  const int chunk = item % a.chunks;
+  item /= a.chunks;
+  const int strip = item % a.strips, n = item / a.strips;
+  const int r0 = chunk * a.rpw, r1 = min(r0 + a.rpw, H);
+  const int cs = strip * ws;
+  const T* const x0 = reinterpret_cast<const T*>(a.x0) + (size_t)n * H * W * a.c0;
+  const T* const x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * H * W * a.c1;
+  const T* const dyg = reinterpret_cast<const T*>(a.dy) + (size_t)n * H * W * (NCO * 16);
+
+  // ---- staging: vectors of 8 channels.  x row: (ws + 2) pixels x 2 NCI vectors; dy row: ws pixels x 2 NCO vectors
+  constexpr int MAXW = 256;
+  constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 * NCO + 255) / 256;
+  const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2 * NCO;
+  uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];      // two register stages: a row's loads are issued two steps before its store
+  auto load_x = [&](uint4 (&xr)[NXV], int rho) {                  // x row rho, columns cs - 1 .. cs + ws
+    const bool rowok = rho >= 0 && rho < H;
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCI), px = i / (2 * NCI);
+      const int gx = cs + px - 1, ch = v * 8;
+      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
+      const bool first = ch < a.c0;
+      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
+                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
+      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+    }
+  };
+  auto load_d = [&](uint4 (&dr)[NDV], int r) {                    // dy row r, columns cs .. cs + ws - 1
+    const bool rowok = r >= 0 && r < H;
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCO), px = i / (2 * NCO);
+      const bool ok = rowok && i < ndv;
+      const T* src = dyg + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * (NCO * 16) + v * 8;
+      dr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+    }
+  };
+  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCI), px = i / (2 * NCI);
+      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
+    }
+  };
+  auto store_d = [&](const uint4 (&dr)[NDV], int slot) {
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCO), px = i / (2 * NCO);
+      if (i < ndv) *reinterpret_cast<uint4*>(ds + slot * drow + (v >> 1) * dplane + px * 32 + (v & 1) * 16) = dr[it];
+    }
+  };
+
+  f32x4 acc[3][3][NCO][NCI];
+  f32x4 accb[NCO];
+#pragma unroll
+  for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+      for (int o = 0; o < NCO; ++o)
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) acc[kr][kc][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < NCO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const frag_t onesv = WgFrag<T>::ones();
+
+  // operand address of a lane: pixel 4 g + (li >> 2) of the K step (+ 16 for the second read), channels 4 (li & 3) .. + 3
+  const int g = lane >> 4, li = lane & 15;
+  const int laneoff = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
+
+  // prologue: x row r0 and dy rows r0 - 1, r0, r0 + 1 into the ring; stage A <- (x r0 + 1, dy r0 + 2), stage B <- (x r0 + 2, dy r0 + 3)
+  load_x(xrA, r0);
+  load_d(drA, r0 - 1);
+  load_d(drB, r0);
+  store_x(xrA, r0 & 1);
+  store_d(drA, (r0 - 1) & 3);
+  load_d(drA, r0 + 1);
+  store_d(drB, r0 & 3);
+  store_d(drA, (r0 + 1) & 3);
+  load_x(xrA, r0 + 1);
+  load_d(drA, r0 + 2);
+  load_x(xrB, r0 + 2);
+  load_d(drB, r0 + 3);
+  __syncthreads();
+
+  const int nks = ws / 32;
+  auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[NDV]) __attribute__((always_inline)) {
+    store_x(xr, (rho + 1) & 1);                 // x row rho + 1, dy row rho + 2: slots nobody reads during this step
+    store_d(dr, (rho + 2) & 3);
+    load_x(xr, rho + 3);                        // back in two steps
+    load_d(dr, rho + 4);
+    const char* const xb = xs + (rho & 1) * xrow + laneoff;
+    const char* db[3];
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr) db[kr] = ds + ((rho - kr + 1) & 3) * drow + laneoff;
+    for (int ks = wave; ks < nks; ks += 4) {
+      frag_t av[3][NCO], bv[3][NCI];
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int o = 0; o < NCO; ++o) av[kr][o] = wgr_frag<T>(db[kr] + o * dplane + ks * 32 * 32);
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) bv[kc][i] = wgr_frag<T>(xb + i * xplane + (ks * 32 + kc) * 32);
+      if (a.want_bias) {
+#pragma unroll
+        for (int o = 0; o < NCO; ++o) accb[o] = mfma16(av[1][o], onesv, accb[o]);
+      }
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+          for (int o = 0; o < NCO; ++o)
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) acc[kr][kc][o][i] = mfma16(av[kr][o], bv[kc][i], acc[kr][kc][o][i]);
+    }
+    fi_lds_barrier();
+  };
+  for (int rho = r0; rho < r1; rho += 2) {
+    step(rho, xrA, drA);
+    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+  }
+
+  // ---- fold the four waves' sums through LDS (the ring is dead), fixed order: deterministic
+  constexpr int NACC = 9 * NCO * NCI * 256;
+  float* const red = reinterpret_cast<float*>(smem);       // [tap][o][i][co 16][ci 16], then [NCO * 16] for the bias
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+          for (int o = 0; o < NCO; ++o)
+#pragma unroll
+            for (int i = 0; i < NCI; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                // D[row = co = g * 4 + r][col = ci = li]
+                float* dst = &red[((((kr * 3 + kc) * NCO + o) * NCI + i) * 16 + g * 4 + r) * 16 + li];
+                *dst = (w == 0) ? acc[kr][kc][o][i][r] : *dst + acc[kr][kc][o][i][r];
+              }
+      if (li == 0) {
+#pragma unroll
+        for (int o = 0; o < NCO; ++o)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = &red[NACC + o * 16 + g * 4 + r];
+            *dst = (w == 0) ? accb[o][r] : *dst + accb[o][r];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  // this item's slice: slice[(co * 9 + t) * cin + ci], bias behind it (conv_wgrad_kernel's layout)
+  constexpr int CIN = NCI * 16, COUT = NCO * 16;
+  float* const slice = a.part + (size_t)blockIdx.x * a.part_stride;
+  for (int e = tid; e < 9 * COUT * CIN; e += 256) {
+    const int ci = e % CIN, t = (e / CIN) % 9, co = e / (CIN * 9);
+    slice[e] = red[((((t * NCO) + (co >> 4)) * NCI + (ci >> 4)) * 16 + (co & 15)) * 16 + (ci & 15)];
+  }
+  if (a.want_bias && tid < COUT) slice[(size_t)COUT * 9 * CIN + tid] = red[NACC + tid];
+}
+
+template <typename T, int NCI, int NCO>
+static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st) {
+  size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)4 * NCO * a.ws * 32;
+  const size_t red = (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
+  if (lds < red) lds = red;
+  hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCI, NCO>), dim3((unsigned)items), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,10 @@
+// Instantiations of the row-streaming thin-layer filter gradient (conv_wgrad_rows_kernel, wgrad_rows.h) for dtype=f16.
+#include "wgrad_rows.h"
+
+int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (nci == 1 && nco == 1) return launch_conv_wgrad_rows<f16_t, 1, 1>(a, items, st);
+  if (nci == 2 && nco == 1) return launch_conv_wgrad_rows<f16_t, 2, 1>(a, items, st);
+  if (nci == 1 && nco == 2) return launch_conv_wgrad_rows<f16_t, 1, 2>(a, items, st);
+  if (nci == 2 && nco == 2) return launch_conv_wgrad_rows<f16_t, 2, 2>(a, items, st);
+  return FI_ERR_UNSUPPORTED;
+}

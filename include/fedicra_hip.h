@@ -204,6 +204,10 @@ int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1
 int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
                             void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
 int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, void* stream);
+/* Measurement / test hook: rows = 0 keeps every filter gradient on the tile kernels, 1 lets the thin 3x3 layers on large maps
+ * (16 / 32 channels a side, 16-bit storage, W % 32 == 0, a workspace given) take the row-streaming kernel (csrc/wgrad_rows.h),
+ * -1 = the FI_WGRAD_ROWS environment default (1). */
+int fi_wgrad_tuning(int rows);
 
 /* weight repack from the fp32 master [Cout][k*k][Cin]:
  *   mode 0: dst[co][t][ci]          = (dtype) src[co][t][ci]          (forward operand)

@@ -252,3 +252,44 @@ def test_trained_dice_of_five_seeds_lies_inside_the_references_own_spread(golden
           f"min {lo:.5f} max {hi:.5f} mean {float(g['dice'].mean()):.5f}")
     assert lo <= float(np.mean(got)) <= hi, (got, lo, hi)
     assert min(got) >= lo - (hi - lo), (got, lo, hi)
+
+
+# ------------------------------------------------------------------------------------------------ row-streaming thin-layer wgrad
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 256, 256, 16, 0, 16), (1, 512, 512, 16, 16, 16), (3, 250, 512, 32, 0, 16),
+                                   (2, 264, 256, 16, 0, 32), (4, 256, 128, 16, 16, 32), (1, 1024, 256, 16, 0, 16)])
+def test_row_streaming_wgrad_against_fp64_and_the_tile_kernels(shape, dtype):
+    """csrc/wgrad_rows.h (the thin 3x3 layers on large maps: whole rows through an LDS ring, x row rho against dy rows rho - 1 ..
+    rho + 1) against an fp64 convolution backward of the same rounded operands and against the tile kernels it replaces
+    (fi_wgrad_tuning(0)): two strips per row, a second source, 32 output channels, ragged row chunks, one-image launches;
+    weight and bias gradients."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    N, H, W, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(H + c1 + cout)
+    x0 = torch.randn(N, H, W, c0, generator=g).to(dtype).to(DEV)
+    x1 = torch.randn(N, H, W, c1, generator=g).to(dtype).to(DEV) if c1 else None
+    dy = (torch.randn(N, H, W, cout, generator=g) * 0.1).to(dtype).to(DEV)
+    cin = c0 + c1
+    res = []
+    try:
+        for rows in (1, 0):
+            L.lib().fi_wgrad_tuning(rows)
+            dw = torch.zeros(cout, 3, 3, cin, device=DEV)
+            db = torch.zeros(cout, device=DEV)
+            L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=3)
+            res.append((dw.double().cpu(), db.double().cpu()))
+    finally:
+        L.lib().fi_wgrad_tuning(-1)
+    x = x0 if x1 is None else torch.cat([x0, x1], 3)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(xd, wref, torch.zeros(cout, dtype=torch.float64, device=DEV), padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    want = wref.grad.permute(0, 2, 3, 1).cpu()                  # [cout][kh][kw][cin]
+    want_b = dy.double().sum((0, 1, 2)).cpu()
+    scale = want.abs().max().item()
+    e_new = (res[0][0] - want).abs().max().item() / scale
+    e_old = (res[1][0] - want).abs().max().item() / scale
+    assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)       # fp32 accumulation of ~1e5 .. 1e6 products
+    assert (res[0][1] - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
+    assert (res[0][0] - res[1][0]).abs().max().item() / scale < 2e-5

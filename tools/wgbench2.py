@@ -25,7 +25,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--rows", type=int, default=-1, help="fi_wgrad_tuning: 0 = tile kernels only, 1 = row-streaming kernel where it applies")
     a = ap.parse_args()
+    L.lib().fi_wgrad_tuning(a.rows)
     tot = ideal = 0.0
     for h, c0, c1, cout, ks, calls in LAYERS:
         x0 = torch.randn(a.batch, h, h, c0, device="cuda").to(torch.bfloat16)
@@ -39,7 +41,7 @@ def main():
         ideal += idl * calls
         print(f"{a.batch} x {h:3d}^2 {c0 + c1:3d}->{cout:3d} k{ks}: {us:8.1f} us  ideal {idl:6.1f}  frac {idl / us:5.2f}  x{calls}")
     print(f"TOTAL {tot:.0f} us per iteration, ideal {ideal:.0f}, frac {ideal / tot:.3f}  "
-          f"(FI_WGRAD_BLOCKS={os.environ.get('FI_WGRAD_BLOCKS', '512')} THIN={os.environ.get('FI_WGRAD_BLOCKS_THIN', '-')})")
+          f"(FI_WGRAD_BLOCKS={os.environ.get('FI_WGRAD_BLOCKS', '512')} THIN={os.environ.get('FI_WGRAD_BLOCKS_THIN', '-')} rows={a.rows})")
 
 
 main()
