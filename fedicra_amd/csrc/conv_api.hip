@@ -12,6 +12,8 @@ int fi_conv_wgrad_bf16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStrea
 int fi_conv_wgrad_bf16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows3d_f16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_bf16_k1(int th, const WgradArgs& a, hipStream_t st);
@@ -467,6 +469,22 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     p->chunks = fi_cdiv(d->H, p->rpw);
     p->sb_rows = d->N * p->strips * p->chunks;
   }
+  // ... and the thin 3x3x3 layers (conv_wgrad_rows3d_kernel): Cout = 16, c0 + c1 = 16 / 32 / 48, slices up to 128 wide
+  const int cr = d->c0 + d->c1;
+  if (wgrad_rows_on() && depth > 0 && d->dtype != FI_F32 && d->ksize == 3 && cout == 16 && (cr == 16 || cr == 32 || cr == 48) &&
+      d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->W % 32 == 0 && d->W <= 128 && d->H >= 8 && d->N % depth == 0 &&
+      (long)d->N * d->H * d->W >= (1L << 17)) {
+    p->rows = 2;
+    p->ws = d->W;
+    p->strips = 1;
+    static const long items3 = env_long("FI_WGRAD_ROWS3D_ITEMS", 512);          // ~2 workgroups per CU (56 ... 73 KB of LDS)
+    long rpw = ((long)d->N * d->H + items3 - 1) / items3;
+    if (rpw < 16) rpw = 16;
+    if (rpw > d->H) rpw = d->H;
+    p->rpw = (int)rpw;
+    p->chunks = fi_cdiv(d->H, p->rpw);
+    p->sb_rows = d->N * p->chunks;
+  }
   return 0;
 }
 
@@ -599,8 +617,13 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
     ra.N = d->N, ra.H = d->H, ra.W = d->W, ra.c0 = d->c0, ra.c1 = d->c1;
     ra.ws = p.ws, ra.strips = p.strips, ra.rpw = p.rpw, ra.chunks = p.chunks;
     ra.want_bias = dbias != nullptr;
-    r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_f16(cin / 16, cout / 16, ra, p.sb, st)
-                           : fi_conv_wgrad_rows_bf16(cin / 16, cout / 16, ra, p.sb, st);
+    ra.depth = depth;
+    if (p.rows == 2)
+      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows3d_f16((d->c0 + d->c1) / 16, ra, p.sb, st)
+                             : fi_conv_wgrad_rows3d_bf16((d->c0 + d->c1) / 16, ra, p.sb, st);
+    else
+      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_f16(cin / 16, cout / 16, ra, p.sb, st)
+                             : fi_conv_wgrad_rows_bf16(cin / 16, cout / 16, ra, p.sb, st);
   } else if (p.quad) {
     if (d->dtype == FI_F32)
       r = d->ksize == 3 ? fi_conv_wgrad_quad_f32_k3(p.th, a, st) : fi_conv_wgrad_quad_f32_k1(p.th, a, st);
@@ -753,7 +776,7 @@ extern "C" long fi_conv3d_wgrad_fused_workspace(const FiConv* d, int D) {
   s.N = d->N * D;
   WgradPlan p;
   if (int rc = plan_wgrad(&s, &p, D)) return rc;
-  return (long)(p.part_stride * p.sb * sizeof(float));
+  return (long)(p.part_stride * (p.rows && p.sb_rows > p.sb ? p.sb_rows : p.sb) * sizeof(float));
 }
 extern "C" int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_all,
                                      float* dbias, void* workspace, long workspace_bytes, void* stream) {

@@ -29,6 +29,7 @@ struct WgRowsArgs {
   int c0, c1;              // input channels from x0 / x1 (multiples of 16)
   int ws, strips, rpw, chunks;     // strip width, strips per row, x rows per item, items per (image, strip)
   int want_bias;
+  int depth;               // conv_wgrad_rows3d_kernel: slices per volume (an "image" is a slice)
 };
 
 template <typename T>
@@ -235,6 +236,195 @@ static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st
   const size_t red = (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
   if (lds < red) lds = red;
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCI, NCO>), dim3((unsigned)items), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same for the 3x3x3 filter gradient of the thin 3D layers (unet_3D at 128^3: 16 -> 16, 48 -> 16; /root/reference/code/
+// networks/utils.py:99-123), layout of the one-launch form: dw [16][9][3][c0 + c1], the depth taps as channel groups.  An item
+// is a run of x rows of ONE slice sigma; x row (sigma, rho) meets the NINE gradient rows (sigma - kd + 1, rho - kr + 1): per K step
+// 3 x operands and 9 dy operands feed 27 MFMAs per 16-channel block.  The dy ring holds 4 rows of each of the three slices (every
+// dy row is loaded by the items of three slices: 2x the ideal traffic at 16 -> 16, against a tile kernel at 0.09 of the
+// roofline).  Cout = 16.  NCI = 1: the four waves split the K steps; NCI = 2, 3: wave w < NCI owns input block w (27
+// accumulators of 4 registers each either way), the blocks of a wave's run need no cross-wave sum.
+template <typename T, int NCI, int MAXW>
+__global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, ws = a.ws, D = a.depth;
+  const int xplane = (ws + 2) * 32, dplane = ws * 32;
+  const int xrow = NCI * xplane;
+  char* const xs = smem;                        // [2][NCI][ws + 2][16]
+  char* const ds = smem + 2 * xrow;             // [3 kd][4][ws][16]
+  int item = blockIdx.x;
+  const int chunk = item % a.chunks;
+  item /= a.chunks;
+  const int strip = item % a.strips, n = item / a.strips;        // n: slice index over all volumes
+  const int sigma = n % D;
+  const int r0 = chunk * a.rpw, r1 = min(r0 + a.rpw, H);
+  const int cs = strip * ws;
+  const size_t plane = (size_t)H * W;
+  const T* const x0 = reinterpret_cast<const T*>(a.x0) + (size_t)n * plane * a.c0;
+  const T* const x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * plane * a.c1;
+  const T* const dyv = reinterpret_cast<const T*>(a.dy);
+
+  constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 + 255) / 256;
+  const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2;
+  uint4 xrA[NXV], xrB[NXV], drA[3][NDV], drB[3][NDV];
+  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
+    const bool rowok = rho >= 0 && rho < H;
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCI), px = i / (2 * NCI);
+      const int gx = cs + px - 1, ch = v * 8;
+      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
+      const bool first = ch < a.c0;
+      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
+                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
+      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+    }
+  };
+  auto load_d = [&](uint4 (&dr)[3][NDV], int r) {           // dy rows r of the slices sigma + 1, sigma, sigma - 1 (kd = 0, 1, 2)
+    const bool rowok = r >= 0 && r < H;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int sd = sigma - kd + 1;
+      const bool sok = rowok && sd >= 0 && sd < D;
+      const T* const base = dyv + (size_t)(sok ? n - kd + 1 : n) * plane * 16;
+#pragma unroll
+      for (int it = 0; it < NDV; ++it) {
+        const int i = tid + it * 256;
+        const int v = i & 1, px = i >> 1;
+        const bool ok = sok && i < ndv;
+        dr[kd][it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(base + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * 16 + v * 8));
+      }
+    }
+  };
+  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCI), px = i / (2 * NCI);
+      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
+    }
+  };
+  auto store_d = [&](const uint4 (&dr)[3][NDV], int slot) {
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int it = 0; it < NDV; ++it) {
+        const int i = tid + it * 256;
+        if (i < ndv) *reinterpret_cast<uint4*>(ds + (kd * 4 + slot) * dplane + (i >> 1) * 32 + (i & 1) * 16) = dr[kd][it];
+      }
+  };
+
+  f32x4 acc[3][3][3];                            // [kd][kr][kc]
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) acc[kd][kr][kc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const frag_t onesv = WgFrag<T>::ones();
+  const int g = lane >> 4, li = lane & 15;
+  const int laneoff = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
+  constexpr bool CISPLIT = NCI > 1;
+  const int blk = CISPLIT ? wave : 0;            // this wave's input block
+  const bool active = !CISPLIT || wave < NCI;
+  const int ks0 = CISPLIT ? 0 : wave, ksstep = CISPLIT ? 1 : 4;
+
+  load_x(xrA, r0);
+  load_d(drA, r0 - 1);
+  load_d(drB, r0);
+  store_x(xrA, r0 & 1);
+  store_d(drA, (r0 - 1) & 3);
+  load_d(drA, r0 + 1);
+  store_d(drB, r0 & 3);
+  store_d(drA, (r0 + 1) & 3);
+  load_x(xrA, r0 + 1);
+  load_d(drA, r0 + 2);
+  load_x(xrB, r0 + 2);
+  load_d(drB, r0 + 3);
+  __syncthreads();
+
+  const int nks = ws / 32;
+  auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[3][NDV]) __attribute__((always_inline)) {
+    store_x(xr, (rho + 1) & 1);
+    store_d(dr, (rho + 2) & 3);
+    load_x(xr, rho + 3);
+    load_d(dr, rho + 4);
+    if (active) {
+      const char* const xb = xs + (rho & 1) * xrow + blk * xplane + laneoff;
+      for (int ks = ks0; ks < nks; ks += ksstep) {
+        frag_t bv[3];
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) bv[kc] = wgr_frag<T>(xb + (ks * 32 + kc) * 32);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int kr = 0; kr < 3; ++kr) {
+            const frag_t av = wgr_frag<T>(ds + (kd * 4 + ((rho - kr + 1) & 3)) * dplane + laneoff + ks * 32 * 32);
+            if (kd == 1 && kr == 1 && a.want_bias && blk == 0) accb = mfma16(av, onesv, accb);
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) acc[kd][kr][kc] = mfma16(av, bv[kc], acc[kd][kr][kc]);
+          }
+      }
+    }
+    fi_lds_barrier();
+  };
+  for (int rho = r0; rho < r1; rho += 2) {
+    step(rho, xrA, drA);
+    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+  }
+
+  // ---- red[kd * 9 + t][block][co 16][ci 16]: K-split waves take turns adding; block-owning waves just write
+  constexpr int NACC = 27 * NCI * 256;
+  float* const red = reinterpret_cast<float*>(smem);
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w && active) {
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+          for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* dst = &red[(((kd * 9 + kr * 3 + kc) * NCI + blk) * 16 + g * 4 + r) * 16 + li];
+              *dst = (CISPLIT || w == 0) ? acc[kd][kr][kc][r] : *dst + acc[kd][kr][kc][r];
+            }
+      if (li == 0 && blk == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = &red[NACC + g * 4 + r];
+          *dst = (CISPLIT || w == 0) ? accb[r] : *dst + accb[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // slice[((co * 9 + t) * 3 + kd) * cin + ci], bias behind it (the one-launch form's layout)
+  constexpr int CIN = NCI * 16;
+  float* const slice = a.part + (size_t)blockIdx.x * a.part_stride;
+  for (int e = tid; e < 16 * 27 * CIN; e += 256) {
+    const int ci = e % CIN, kd = (e / CIN) % 3, t = (e / (CIN * 3)) % 9, co = e / (CIN * 27);
+    slice[e] = red[(((kd * 9 + t) * NCI + (ci >> 4)) * 16 + co) * 16 + (ci & 15)];
+  }
+  if (a.want_bias && tid < 16) slice[(size_t)16 * 27 * CIN + tid] = red[NACC + tid];
+}
+
+template <typename T, int NCI, int MAXW>
+static int launch_conv_wgrad_rows3d(const WgRowsArgs& a, int items, hipStream_t st) {
+  size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)12 * a.ws * 32;
+  const size_t red = (size_t)(27 * NCI * 256 + 16) * sizeof(float);
+  if (lds < red) lds = red;
+  hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)items), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -8,3 +8,11 @@ int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hi
   if (nci == 2 && nco == 2) return launch_conv_wgrad_rows<bf16_t, 2, 2>(a, items, st);
   return FI_ERR_UNSUPPORTED;
 }
+
+int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (a.ws > 128) return FI_ERR_UNSUPPORTED;
+  if (nci == 1) return launch_conv_wgrad_rows3d<bf16_t, 1, 128>(a, items, st);
+  if (nci == 2) return launch_conv_wgrad_rows3d<bf16_t, 2, 128>(a, items, st);
+  if (nci == 3) return launch_conv_wgrad_rows3d<bf16_t, 3, 128>(a, items, st);
+  return FI_ERR_UNSUPPORTED;
+}

@@ -293,3 +293,42 @@ def test_row_streaming_wgrad_against_fp64_and_the_tile_kernels(shape, dtype):
     assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)       # fp32 accumulation of ~1e5 .. 1e6 products
     assert (res[0][1] - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
     assert (res[0][0] - res[1][0]).abs().max().item() / scale < 2e-5
+    if cin == 16 or cout == 16:                                # (32 -> 32 stays with the quadrant kernel: measured ahead there)
+        assert not torch.equal(res[0][0], res[1][0])           # another summation order: the row-streaming kernel really ran
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 16, 64, 128, 16, 0), (2, 5, 128, 128, 16, 32), (1, 16, 104, 96, 32, 0), (1, 6, 256, 128, 16, 16)])
+def test_row_streaming_3d_wgrad_against_fp64_and_the_tile_kernels(shape, dtype):
+    """conv_wgrad_rows3d_kernel (thin 3x3x3 layers, Cout = 16: x row (sigma, rho) against the nine gradient rows of slices
+    sigma - 1 .. sigma + 1) against an fp64 conv3d backward and the one-launch tile kernel it replaces: first / last slices of a
+    volume (depth padding), two volumes, 16 / 32 / 48 input channels over two sources, ragged row runs."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    N, D, H, W, c0, c1 = shape
+    cout, cin = 16, c0 + c1
+    g = torch.Generator().manual_seed(D + H + c1)
+    x0 = torch.randn(N, D, H, W, c0, generator=g).to(dtype).to(DEV)
+    x1 = torch.randn(N, D, H, W, c1, generator=g).to(dtype).to(DEV) if c1 else None
+    dy = (torch.randn(N, D, H, W, cout, generator=g) * 0.1).to(dtype).to(DEV)
+    res = []
+    try:
+        for rows in (1, 0):
+            L.lib().fi_wgrad_tuning(rows)
+            dw = torch.zeros(cout, 9, 3, cin, device=DEV)
+            db = torch.zeros(cout, device=DEV)
+            assert L.conv3d_wgrad_fused(x0, x1, dy, dw, db, ksize=3)
+            res.append((dw.double().cpu(), db.double().cpu()))
+    finally:
+        L.lib().fi_wgrad_tuning(-1)
+    x = x0 if x1 is None else torch.cat([x0, x1], 4)
+    xd = x.double().permute(0, 4, 1, 2, 3)
+    wref = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv3d(xd, wref, None, padding=1).backward(dy.double().permute(0, 4, 1, 2, 3))
+    want = wref.grad.permute(0, 3, 4, 2, 1).reshape(cout, 9, 3, cin).cpu()          # [cout][kh][kw][kd][cin] -> [cout][9][3][cin]
+    scale = want.abs().max().item()
+    e_new = (res[0][0] - want).abs().max().item() / scale
+    e_old = (res[1][0] - want).abs().max().item() / scale
+    assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)
+    assert not torch.equal(res[0][0], res[1][0])               # another summation order: the row-streaming kernel really ran
+    assert (res[0][1] - dy.double().sum((0, 1, 2, 3)).cpu()).abs().max().item() < 2e-5 * max(1.0, dy.double().sum((0, 1, 2, 3)).abs().max().item())
