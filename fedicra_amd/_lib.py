@@ -28,7 +28,7 @@ EXPORTS = [
     "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
-    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning",
+    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups",
 ]
 
 
@@ -366,6 +366,14 @@ def conv2d_stats_xcorr(x0, t0, w, bias, stats, *, groups, cout, workspace=None, 
         return False
     _chk(rc, "fi_conv2d_stats_xcorr")
     return True
+
+
+def bn_act_pool_groups(y, coef, slope, z, groups):
+    """fi_bn_act_pool_groups: y raw [N][2H][2W][C], coef fp32 [2][G][C] -> z [N][H][W][C] = maxpool2(act(BN(y))) per group."""
+    N, H2, W2, Cc = _dev(y).shape
+    with _timed("bn_act_pool", (str(y.dtype)[6:], N, H2, W2, Cc), 0.0, y.numel() * _esz(y) + z.numel() * _esz(z)):
+        _chk(lib().fi_bn_act_pool_groups(dt(y.dtype), ptr(y), ptr(coef[0]), ptr(coef[1]), C.c_float(slope), ptr(z), N, H2 // 2,
+                                         W2 // 2, Cc, N // groups, stream()), "fi_bn_act_pool_groups")
 
 
 def bn_finalize_groups(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, shared=False):

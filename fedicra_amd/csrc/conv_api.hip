@@ -287,8 +287,12 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       // or behind and stay where they were
       const long tiles16 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
       // (64-output slabs that are not resident -- 128^2 128->64 -- take the 32-row shape: 251 -> 239 us since the butterfly epilogue)
-      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (a.xf == 1 && ok16 && tiles16 * (cout / 128) >= 1024) ||
-                          (a.xf == 1 && ok32 && cout == 64 && tiles32 >= 1024);
+      // (FI_WS2_PLAIN=1: also the batched launches whose source is already an activation -- the pooled DownBlock inputs that
+      //  fi_bn_act_pool_groups wrote out)
+      static const long ws2_plain = env_long("FI_WS2_PLAIN", 0);
+      const bool xfok = a.xf == 1 || (ws2_plain && a.xf == 0 && a.gimages > 0);
+      const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (xfok && ok16 && tiles16 * (cout / 128) >= 1024) ||
+                          (xfok && ok32 && cout == 64 && tiles32 >= 1024);
       if (ok32 && wanted) {
         int tr = ok16 ? 16 : 32;
         static const long force_tr = env_long("FI_WS2_TR", 0);

@@ -559,6 +559,72 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(2)
 // ------------------------------------------------------------------------------------------------
+// z = maxpool2x2(act(scale_g[c] * y + shift_g[c])) of a RAW convolution output y [N][2H][2W][C] with one coefficient row pair
+// per statistics group (g = n / gimages): what the pooling loader of the fused forward evaluates (conv_impl.h XF == 2: each of the
+// four values rounded to the storage type first, then the scan-order strict maximum), written out ONCE.  The deep DownBlocks of
+// the batched LC forwards stage every input tile once per 64 / 128-channel output slab; with the pooled activation in memory
+// they take the wave-specialised kernels' plain loader instead of the one-tile kernel's four-vectors-per-staged-one.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_pool_groups_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float slope, T* __restrict__ z,
+                                                                 int N, int Ho, int Wo, int C, int gimages) {
+  constexpr int VG = DT<T>::VG;
+  const int CV = C / VG, W = 2 * Wo;
+  const long nvec = (long)N * Ho * Wo * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)((unsigned)i % (unsigned)CV);
+    unsigned p = (unsigned)i / (unsigned)CV;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int g = gimages > 0 ? n / gimages : 0;
+    const float* sc = scale + (size_t)g * C + cv * VG;
+    const float* sh = shift + (size_t)g * C + cv * VG;
+    const T* base = y + ((((size_t)n * 2 * Ho + 2 * oy) * W + 2 * ox) * C + cv * VG);
+    float q[4][VG], m[VG];
+    load_vec<T>(base, q[0]);
+    load_vec<T>(base + C, q[1]);
+    load_vec<T>(base + (size_t)W * C, q[2]);
+    load_vec<T>(base + (size_t)W * C + C, q[3]);
+#pragma unroll
+    for (int j = 0; j < VG; ++j) {
+      float best = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = q[k][j] * sc[j] + sh[j];
+        const float v = to_f32(from_f32<T>(fmaxf(t, t * slope)));      // rounded like fi_bn_act_fwd, THEN compared
+        best = (k == 0 || v > best) ? v : best;
+      }
+      m[j] = best;
+    }
+    store_vec<T>(z + i * VG, m);
+  }
+}
+
+extern "C" int fi_bn_act_pool_groups(int dtype, const void* y, const float* scale, const float* shift, float slope, void* z, int N,
+                                     int Ho, int Wo, int C, int group_images, void* stream) {
+  if (!y || !scale || !shift || !z) return FI_ERR_NULL;
+  if (N < 1 || Ho < 1 || Wo < 1 || C < 1 || group_images < 0 || (group_images > 0 && N % group_images)) return FI_ERR_SHAPE;
+  if (slope < 0.f || slope > 1.f) return FI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * Ho * Wo * (C / vg);
+  if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;
+  const dim3 grid(grid_for(nvec, 256 * 2)), blk(256);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL(bn_act_pool_groups_kernel<float>, grid, blk, 0, st, (const float*)y, scale, shift, slope, (float*)z, N, Ho, Wo, C, group_images);
+  else if (dtype == FI_BF16)
+    hipLaunchKernelGGL(bn_act_pool_groups_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)y, scale, shift, slope, (bf16_t*)z, N, Ho, Wo, C, group_images);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL(bn_act_pool_groups_kernel<f16_t>, grid, blk, 0, st, (const f16_t*)y, scale, shift, slope, (f16_t*)z, N, Ho, Wo, C, group_images);
+  else
+    return FI_ERR_DTYPE;
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H,
                                                           int W, int C) {

@@ -180,9 +180,9 @@ class MyModel(nn.Module):
         self.fedaa_weights = None
         self.ala_epoch_losses: List[float] = []
 
-    def forward(self, x, emb_idx=None, heatmap_only=False):
+    def forward(self, x, emb_idx=None, heatmap_only=False, aux=True):
         if emb_idx is None:
-            return self.model(x)
+            return self.model(x) if aux is True else self.model(x, aux=aux)
         if heatmap_only:                                  # LC models only (networks/unet._UNetLCBase.forward)
             return self.model(x, emb_idx, heatmap_only=True)
         return self.model(x, emb_idx)

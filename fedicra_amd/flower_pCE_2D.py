@@ -63,6 +63,7 @@ class MyClient(BaseClient):
         self._xbuf = self._ybuf = None
         self.last_losses = []
         self.probe_beside = _PROBE_BESIDE                    # the LC forwards on a second stream beside the own forward
+        self.aux_stats_only = os.environ.get("FEDICRA_AUX_STATS", "1") != "0"   # (measurement switch: 0 = the heads in full)
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
 
@@ -156,7 +157,9 @@ class MyClient(BaseClient):
             fork.record(main)
             ops._ctx.bn_events = {}
         try:
-            out = self.model(x)
+            # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
+            # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
+            out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
             if side:
                 probe_stream.wait_event(fork)
                 with torch.cuda.stream(probe_stream), torch.no_grad():

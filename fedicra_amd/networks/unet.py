@@ -302,7 +302,8 @@ def _dsn_head(cin, n_class):
 
 def _run_head(seq, x, probe=False):
     if probe:                       # output unused: only the BatchNorm statistics of the head move (see _UNetLCBase.forward)
-        ops.conv_bn_stats_only(x, None, seq[0], seq[1], seq[3].p, "chan")
+        with torch.no_grad():       # (aux == "stats" reaches here with autograd on: the head's output does not exist, nor its graph)
+            ops.conv_bn_stats_only(x.detach(), None, seq[0], seq[1], seq[3].p, "chan")
         return None
     z = ops.conv_bn_act(x, None, seq[0], seq[1], 0.0, seq[3].p, "chan")      # ReLU = slope 0; Dropout2d
     return ops.conv2d(z, None, seq[4], y_f32=True)
@@ -373,7 +374,7 @@ class Decoder_Head(_DecoderBase):
 
     def _run(self, f, probe=False, aux=True):
         o = self._trunk(f, probe)
-        return o + [_run_head(self.dsn_head, o[2], probe) if aux else None]
+        return o + [_run_head(self.dsn_head, o[2], probe or aux == "stats") if aux else None]
 
 
 class Decoder_MultiHead(_DecoderBase):
@@ -392,8 +393,8 @@ class Decoder_MultiHead(_DecoderBase):
         o = self._trunk(f, probe)
         if not aux:
             return o + [None, None, None]
-        return o + [_run_head(self.dsn_head1, o[2], probe), _run_head(self.dsn_head2, o[3], probe),
-                    _run_head(self.dsn_head3, o[4], probe)]
+        st = probe or aux == "stats"
+        return o + [_run_head(self.dsn_head1, o[2], st), _run_head(self.dsn_head2, o[3], st), _run_head(self.dsn_head3, o[4], st)]
 
 
 def _params(in_chns, class_num, **extra):
@@ -446,7 +447,13 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         self._fi_finish_init()
 
     def forward(self, x, emb_idx=None, heatmap_only=False, aux=True):
-        """``aux=False``: the auxiliary heads are not run and their entries of the returned list are None -- for a caller that
+        """``aux="stats"`` (train mode): the caller does not read the auxiliary outputs -- the pCE trainer uses ``[0]`` and the
+        heat-map only (flower_pCE_2D.py:117-139; the heads' parameters receive no gradient there either) -- so every head runs
+        its convolution as a statistics-only launch followed by the BatchNorm finalize: the running statistics move exactly as
+        in the full forward (same kernel, same epilogue), the host-fed dropout draw is still taken, and the 512-channel tensor
+        is never written, normalised or reduced (12 x 128^2 x 512: conv store + BN/ReLU/Dropout2d pass + 1x1 = 0.2 ms of every
+        iteration).  Their entries of the returned list are None.
+        ``aux=False``: the auxiliary heads are not run and their entries of the returned list are None -- for a caller that
         reads only ``[0]`` on a model whose state is thrown away afterwards (the ALA loop's deep copy, flower_common.py:503,
         566-602: nothing but the heads' BatchNorm statistics of that copy would differ).
         ``heatmap_only`` (train mode, no autograd): the caller reads nothing but the heat-map ``[6]`` -- the LC loss's
@@ -457,6 +464,8 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         which has no state, is skipped.  The skipped entries of the returned list are None."""
         self._fi_refresh_packs(self.compute_dtype())     # all conv operands in one launch, only if weights changed
         probe = bool(heatmap_only) and self.training and not torch.is_grad_enabled()
+        if aux == "stats" and not self.training:          # eval mode: a head nobody reads has no side effect either
+            aux = False
         f, h = self.encoder._run(self._in(x), emb_idx)
         o = self.decoder._run(f, probe, aux)
         hm = [None if t is None else self._out(t) for t in h]

@@ -660,6 +660,8 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
 
 # ----------------------------------------------------------------------------- fused probe forward
 _XCORR = os.environ.get("FI_XCORR", "1") != "0"                # measurement switch: 0 = the direct statistics-only launch
+_POOL_MAT = os.environ.get("FI_POOL_MAT", "1") != "0"          # measurement switch: 0 = pooled sources stay in the loader
+_POOL_MAT_MIN_CIN = int(os.environ.get("FI_POOL_MAT_MIN_CIN", "64"))
 _XCORR_MIN_COUT = int(os.environ.get("FI_XCORR_MIN_COUT", "192"))   # 13 x 64 x 64 vs 9 x 64 x Cout multiply-adds: pays from Cout ~ 2 x 92 on
 
 
@@ -719,6 +721,14 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
     if pool:
         H, W = H // 2, W // 2
     wp = _packed(wk, x0.dtype, 0, cout, ksize * ksize, cin, param=conv.weight)
+    if (pool and _POOL_MAT and r0 is not None and not shared0 and in_drop is None and s1 is None and x0.dtype != torch.float32
+            and cin >= _POOL_MAT_MIN_CIN):
+        # deep DownBlock (64+ channels in): the pooled activation written out once (fi_bn_act_pool_groups: the loader's own
+        # arithmetic), then the plain loader of the wave-specialised kernels instead of transforming and pooling the tile once per
+        # output slab in the one-tile kernel -- 84 x 32^2 128 -> 256: 188 us at 0.11 of its roofline before
+        z = torch.empty((x0.shape[0], H, W, cin), dtype=x0.dtype, device=dev)
+        L.bn_act_pool_groups(x0, r0.coef, r0.slope, z, groups)
+        x0, r0, pool = z, None, False
     t0 = None if r0 is None else L.in_xform(r0.coef, r0.slope, pool=pool, drop=in_drop, seed_group_stride=0x10001)
     t1 = None if r1 is None else L.in_xform(r1.coef, r1.slope)
     if (pool or in_drop is not None) and t0 is None:

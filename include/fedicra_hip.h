@@ -283,6 +283,14 @@ int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void* y, const f
 /* ---------------------------------------------------------------- pooling / resampling ---- */
 /* nn.MaxPool2d(2) (unet.py:40): y[N,H/2,W/2,C]; H, W even. */
 int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+/* z [N][Ho][Wo][C] = maxpool2x2(act(scale_g * y + shift_g)) of a RAW convolution output y [N][2Ho][2Wo][C], one coefficient row
+ * pair [group][C] per statistics group g = n / group_images (0: one group): exactly what the pooling loader of
+ * fi_conv2d_fwd_fused evaluates (each value rounded to the storage type like fi_bn_act_fwd, then the scan-order strict
+ * maximum of fi_maxpool2_fwd), written out once -- for the deep DownBlocks of the batched LC forwards, whose input tile
+ * would otherwise be transformed and pooled once per output slab (ConvBlock + MaxPool2d, /root/reference/code/networks/
+ * unet.py:14-46).  0 <= slope <= 1. */
+int fi_bn_act_pool_groups(int dtype, const void* y, const float* scale, const float* shift, float slope, void* z, int N, int Ho,
+                          int Wo, int C, int group_images, void* stream);
 /* dx = route dy to the first maximum of each window (scan order, strict >), zeros elsewhere. */
 int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate,
                     void* stream);

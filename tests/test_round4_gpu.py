@@ -332,3 +332,32 @@ def test_row_streaming_3d_wgrad_against_fp64_and_the_tile_kernels(shape, dtype):
     assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)
     assert not torch.equal(res[0][0], res[1][0])               # another summation order: the row-streaming kernel really ran
     assert (res[0][1] - dy.double().sum((0, 1, 2, 3)).cpu()).abs().max().item() < 2e-5 * max(1.0, dy.double().sum((0, 1, 2, 3)).abs().max().item())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_own_forward_with_statistics_only_heads_trains_exactly_like_the_full_heads(use_graph):
+    """flower_pCE_2D reads the logits and the heat-map of its own forward only, so on the LC models the auxiliary head runs as
+    a statistics-only launch (UNet_LC.forward(aux="stats")): a FedICRA round (head + body phase) with it must end in the
+    SAME state -- parameters, every BatchNorm running statistic incl. the head's, counters -- and the same losses as with
+    the head computed in full, eager and captured."""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks.unet import UNet_LC
+    from helpers import loader
+    K, cid = 3, 1
+    batches = loader(2, 4, 64, cid=cid, device=DEV)
+    res = []
+    for stats_only in (False, True):
+        args = _args(strategy="FedICRA", model="unet_lc", cid=cid, min_num_clients=K, iters=4, rep_iters=2, alpha=1.0,
+                     use_graph=use_graph)
+        ops.manual_seed(9)
+        net = _mk(UNet_LC, 1, 2, 1, K, K, cid, lc=True)
+        client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+        client.aux_stats_only = stats_only
+        for r in range(3):
+            client._train({"iter_global": 4 * (r + 1), "iters": 4, "eval_iters": 8, "batch_size": 4, "stage": "fit"})
+        res.append((net.flat_state.clone(), net.flat_counters.clone(), list(client.last_losses)))
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2], (res[0][2], res[1][2])
+    assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
