@@ -763,7 +763,7 @@ def main():
     if a.data == "host" and not a.no_resident:
         fedr = Federation(a, rank, world, dev, a.dtype, data="resident")
         kr = min(a.steps, a.round_iters)
-        elr, aggr, _ = fedr.timed(a.warmup, kr, dist)
+        elr, aggr, _ = fedr.timed(max(a.warmup, 2 * a.round_iters), kr, dist)     # (two rounds: the ALA epoch's capture is behind it)
         resident = {"images_per_sec": round(kr * a.batch * world / elr, 2), "steps": kr, "ms_per_aggregation_round": round(aggr, 3),
                     "round_split_ms": fedr.round_split()}
         del fedr
@@ -774,7 +774,7 @@ def main():
         # the reference's own arithmetic (--amp 0): exact-fp32 MFMA parity mode, same rounds, shorter sample
         fed32 = Federation(a, rank, world, dev, "fp32")
         k32 = min(a.steps, a.round_iters)
-        el32, agg32, _ = fed32.timed(a.warmup, k32, dist)
+        el32, agg32, _ = fed32.timed(max(a.warmup, 2 * a.round_iters), k32, dist)
         fp32 = {"images_per_sec": round(k32 * a.batch * world / el32, 2), "steps": k32,
                 "ms_per_aggregation_round": round(agg32, 3)}
         del fed32

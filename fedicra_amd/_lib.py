@@ -368,12 +368,14 @@ def conv2d_stats_xcorr(x0, t0, w, bias, stats, *, groups, cout, workspace=None, 
     return True
 
 
-def bn_act_pool_groups(y, coef, slope, z, groups):
-    """fi_bn_act_pool_groups: y raw [N][2H][2W][C], coef fp32 [2][G][C] -> z [N][H][W][C] = maxpool2(act(BN(y))) per group."""
-    N, H2, W2, Cc = _dev(y).shape
-    with _timed("bn_act_pool", (str(y.dtype)[6:], N, H2, W2, Cc), 0.0, y.numel() * _esz(y) + z.numel() * _esz(z)):
-        _chk(lib().fi_bn_act_pool_groups(dt(y.dtype), ptr(y), ptr(coef[0]), ptr(coef[1]), C.c_float(slope), ptr(z), N, H2 // 2,
-                                         W2 // 2, Cc, N // groups, stream()), "fi_bn_act_pool_groups")
+def bn_act_pool_groups(y, coef, slope, z, groups, pool=True):
+    """fi_bn_act_pool_groups: y raw [N][2H][2W][C] (pool) or [N][H][W][C], coef fp32 [2][G][C] -> z [N][H][W][C] =
+    [maxpool2](act(BN(y))) with group g's coefficient rows for its images."""
+    N, Hi, Wi, Cc = _dev(y).shape
+    Ho, Wo = (Hi // 2, Wi // 2) if pool else (Hi, Wi)
+    with _timed("bn_act_pool" if pool else "bn_act_groups", (str(y.dtype)[6:], N, Hi, Wi, Cc), 0.0, y.numel() * _esz(y) + z.numel() * _esz(z)):
+        _chk(lib().fi_bn_act_pool_groups(dt(y.dtype), ptr(y), ptr(coef[0]), ptr(coef[1]), C.c_float(slope), ptr(z), N, Ho, Wo, Cc,
+                                         N // groups, int(bool(pool)), stream()), "fi_bn_act_pool_groups")
 
 
 def bn_finalize_groups(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, shared=False):

@@ -564,7 +564,9 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
 // four values rounded to the storage type first, then the scan-order strict maximum), written out ONCE.  The deep DownBlocks of
 // the batched LC forwards stage every input tile once per 64 / 128-channel output slab; with the pooled activation in memory
 // they take the wave-specialised kernels' plain loader instead of the one-tile kernel's four-vectors-per-staged-one.
-template <typename T>
+// (POOL = false: the same without the pooling -- act(BN(y)) of every group in ONE launch: the frozen encoder's feature maps of
+// a whole ALA epoch, fi_bn_act_fwd's arithmetic)
+template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_act_pool_groups_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, float slope, T* __restrict__ z,
                                                                  int N, int Ho, int Wo, int C, int gimages) {
@@ -581,29 +583,40 @@ __global__ __launch_bounds__(256) void bn_act_pool_groups_kernel(const T* __rest
     const int g = gimages > 0 ? n / gimages : 0;
     const float* sc = scale + (size_t)g * C + cv * VG;
     const float* sh = shift + (size_t)g * C + cv * VG;
-    const T* base = y + ((((size_t)n * 2 * Ho + 2 * oy) * W + 2 * ox) * C + cv * VG);
-    float q[4][VG], m[VG];
-    load_vec<T>(base, q[0]);
-    load_vec<T>(base + C, q[1]);
-    load_vec<T>(base + (size_t)W * C, q[2]);
-    load_vec<T>(base + (size_t)W * C + C, q[3]);
+    float m[VG];
+    if constexpr (POOL) {
+      const T* base = y + ((((size_t)n * 2 * Ho + 2 * oy) * W + 2 * ox) * C + cv * VG);
+      float q[4][VG];
+      load_vec<T>(base, q[0]);
+      load_vec<T>(base + C, q[1]);
+      load_vec<T>(base + (size_t)W * C, q[2]);
+      load_vec<T>(base + (size_t)W * C + C, q[3]);
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      float best = 0.f;
+      for (int j = 0; j < VG; ++j) {
+        float best = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float t = q[k][j] * sc[j] + sh[j];
-        const float v = to_f32(from_f32<T>(fmaxf(t, t * slope)));      // rounded like fi_bn_act_fwd, THEN compared
-        best = (k == 0 || v > best) ? v : best;
+        for (int k = 0; k < 4; ++k) {
+          const float t = q[k][j] * sc[j] + sh[j];
+          const float v = to_f32(from_f32<T>(fmaxf(t, t * slope)));      // rounded like fi_bn_act_fwd, THEN compared
+          best = (k == 0 || v > best) ? v : best;
+        }
+        m[j] = best;
       }
-      m[j] = best;
+    } else {
+      float q[VG];
+      load_vec<T>(y + i * VG, q);
+#pragma unroll
+      for (int j = 0; j < VG; ++j) {
+        const float t = q[j] * sc[j] + sh[j];
+        m[j] = fmaxf(t, t * slope);
+      }
     }
     store_vec<T>(z + i * VG, m);
   }
 }
 
 extern "C" int fi_bn_act_pool_groups(int dtype, const void* y, const float* scale, const float* shift, float slope, void* z, int N,
-                                     int Ho, int Wo, int C, int group_images, void* stream) {
+                                     int Ho, int Wo, int C, int group_images, int pool, void* stream) {
   if (!y || !scale || !shift || !z) return FI_ERR_NULL;
   if (N < 1 || Ho < 1 || Wo < 1 || C < 1 || group_images < 0 || (group_images > 0 && N % group_images)) return FI_ERR_SHAPE;
   if (slope < 0.f || slope > 1.f) return FI_ERR_UNSUPPORTED;
@@ -613,14 +626,17 @@ extern "C" int fi_bn_act_pool_groups(int dtype, const void* y, const float* scal
   const long nvec = (long)N * Ho * Wo * (C / vg);
   if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;
   const dim3 grid(grid_for(nvec, 256 * 2)), blk(256);
-  if (dtype == FI_F32)
-    hipLaunchKernelGGL(bn_act_pool_groups_kernel<float>, grid, blk, 0, st, (const float*)y, scale, shift, slope, (float*)z, N, Ho, Wo, C, group_images);
-  else if (dtype == FI_BF16)
-    hipLaunchKernelGGL(bn_act_pool_groups_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)y, scale, shift, slope, (bf16_t*)z, N, Ho, Wo, C, group_images);
-  else if (dtype == FI_F16)
-    hipLaunchKernelGGL(bn_act_pool_groups_kernel<f16_t>, grid, blk, 0, st, (const f16_t*)y, scale, shift, slope, (f16_t*)z, N, Ho, Wo, C, group_images);
-  else
+#define FI_BAP(TT, PP) hipLaunchKernelGGL((bn_act_pool_groups_kernel<TT, PP>), grid, blk, 0, st, (const TT*)y, scale, shift, slope, (TT*)z, N, Ho, Wo, C, group_images)
+  if (dtype == FI_F32) {
+    if (pool) FI_BAP(float, true); else FI_BAP(float, false);
+  } else if (dtype == FI_BF16) {
+    if (pool) FI_BAP(bf16_t, true); else FI_BAP(bf16_t, false);
+  } else if (dtype == FI_F16) {
+    if (pool) FI_BAP(f16_t, true); else FI_BAP(f16_t, false);
+  } else {
     return FI_ERR_DTYPE;
+  }
+#undef FI_BAP
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -285,6 +285,99 @@ class MyModel(nn.Module):
         temp.train(net.training)
         return temp
 
+    # ---- the ALA epoch with the encoder hoisted out of the batch loop ------------------------------------------------
+    def _ala_batched_ok(self, temp, use_graph):
+        """The ALA loop trains nothing but the decoder of the copy (flower_common.py:542-546), so inside an epoch its encoder
+        sees the same weights for every batch: its forward over ALL batches of the epoch can run as ONE batched no-grad
+        pass of statistics groups (group = batch: per-batch BatchNorm statistics, per-batch dropout draws; the fused
+        forms of the LC forwards, networks.unet.LCEncoder._probe_batches) instead of len(trainloader) passes of 12 images
+        that leave most of the chip idle.  Applies with the device RNG (parity runs that feed host masks keep the per-batch
+        loop: the reference's draw order), without amp, on a list-like loader of equally shaped batches."""
+        if os.environ.get("FEDICRA_ALA_BATCHED", "1") == "0" or not getattr(self, "ala_batched", True):
+            return False
+        if ops._mask_provider is not None or self.amp or not getattr(self, "ala_skip_aux", True):
+            return False
+        enc = getattr(temp, "encoder", None)
+        if enc is None or not hasattr(enc, "_probe_batches") or getattr(enc, "n_pcs", 0) != 1 or not temp.training:
+            return False
+        if not isinstance(self.trainloader, (list, tuple)) or not (2 <= len(self.trainloader) <= 16):
+            return False
+        if not temp.flat_params.is_cuda or not hasattr(temp.decoder, "_run"):
+            return False
+        dec = temp.decoder
+        if not all(getattr(b, "bilinear", True) for b in (dec.up1, dec.up2, dec.up3, dec.up4)):
+            return False
+        dtp = temp.compute_dtype()
+        if any(c % (4 if dtp == torch.float32 else 8) for c in enc.ft_chns):
+            return False
+        b0 = self.trainloader[0]
+        return all(b["image"].shape == b0["image"].shape and b["label"].shape == b0["label"].shape for b in self.trainloader)
+
+    def _ala_epoch_batched(self, st, temp, tp, tg, old_local, glob, s, e, w, eta, ncls, use_graph):
+        """One ALA epoch (flower_common.py:566-602) -> the last batch's loss (device scalar).  Every batch is staged into ONE
+        static input; the epoch -- encoder pass over all of them, then per batch: decoder forward, pCE, decoder-only backward,
+        mixing update -- is captured into one hipGraph at its second use and replayed from then on."""
+        batches = list(self.trainloader)
+        G = len(batches)
+        dev = temp.flat_params.device
+        ep = st.get("ep")
+        xs0 = batches[0]["image"]
+        n = xs0.shape[0]
+        xshape = (G * n, 1) + tuple(xs0.shape[1:]) if self.args.img_class == "faz" else (G * n,) + tuple(xs0.shape[1:])
+        if ep is None or ep["x"].shape != xshape:
+            ep = st["ep"] = {"x": torch.empty(xshape, dtype=torch.float32, device=dev),
+                             "y": torch.empty((G * n,) + tuple(batches[0]["label"].shape[1:]), dtype=torch.uint8, device=dev),
+                             "graph": None, "warm": False, "loss": None}
+        for b, sampled_batch in enumerate(batches):          # staging: batch b + 1 crosses PCIe while batch b is copied in
+            x, y, staged = self._batch(sampled_batch)
+            ep["x"][b * n:(b + 1) * n].copy_(x, non_blocking=True)
+            ep["y"][b * n:(b + 1) * n].copy_(y, non_blocking=True)
+            if staged:
+                self.batch_stager().release()
+                if b + 1 < G:
+                    self.batch_stager().prefetch(batches[b + 1])
+        hint = getattr(self, "next_batch_hint", None)       # the batch the next training round starts with (set by the client)
+        if hint is not None and dev.type == "cuda" and hint["image"].device.type == "cpu":
+            self.batch_stager().prefetch(hint)
+
+        dtp = temp.compute_dtype()
+
+        def epoch():
+            ops.begin_iteration(dev)
+            temp._fi_refresh_packs(dtp)
+            with torch.no_grad():
+                feats = temp.encoder._probe_batches(temp._in(ep["x"]), G)
+            loss = None
+            for b in range(G):
+                temp.zero_grad()
+                temp._fi_refresh_packs(dtp)                  # the decoder's operands follow the mixing update of batch b - 1
+                o = temp.decoder._run([t[b * n:(b + 1) * n] for t in feats], False, False)
+                loss = ops.ce_loss(o[0], ep["y"][b * n:(b + 1) * n], ncls)
+                loss.backward()
+                ops.flush_wgrad()
+                L.ala_update(w, tp[s:e], tg[s:e], old_local[s:e], glob[s:e], eta, None)
+                ops.bump_weights_epoch()
+            st["iter"].add_(G)                               # fresh dropout masks for every batch of the next epoch
+            return loss
+
+        if not use_graph:
+            return epoch()
+        if not ep["warm"]:
+            ep["loss"] = epoch()
+            ep["warm"] = True
+        elif ep["graph"] is None:
+            torch.cuda.synchronize()
+            ops.reserve_graph_tables(G + 2)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                ep["loss"] = epoch()
+            ep["graph"] = g
+            g.replay()
+        else:
+            ep["graph"].replay()
+        ops.bump_weights_epoch()
+        return ep["loss"]
+
     def set_weights(self, weights, config):
         if self.args.strategy not in ["FedICRA"]:
             self._load_global(weights)                       # flower_common.py:627-633
@@ -348,10 +441,15 @@ class MyModel(nn.Module):
             st["iter"].add_(1)                                # fresh dropout masks for the next batch, replay included
             return loss
 
+        fast = self._ala_batched_ok(temp, use_graph)
         with ops.use_context(st["ctx"]):
             while True:
                 loss = None
-                batches = iter(self.trainloader)              # :566-602, one batch of look-ahead for the H2D staging
+                if fast:
+                    # the frozen encoder of ALL batches of the epoch as one batched pass, then decoder forward / backward /
+                    # mixing update per batch (_ala_epoch_batched)
+                    loss = self._ala_epoch_batched(st, temp, tp, tg, old_local, glob, s, e, w, eta, ncls, use_graph)
+                batches = iter(() if fast else self.trainloader)      # :566-602, one batch of look-ahead for the H2D staging
                 upcoming = next(batches, None)
                 while upcoming is not None:
                     sampled_batch, upcoming = upcoming, next(batches, None)

@@ -107,13 +107,21 @@ class MyClient(BaseClient):
         get = getattr(self.model, "batch_stager", None)
         return get() if callable(get) and self._net().flat_state.is_cuda else None
 
-    def _prefetch_next(self):
+    def _prefetch_next(self, last=False):
         """Start the host -> device copy of the batch the NEXT iteration will take (flower_pCE_2D.py:66-73: same epoch
         list) while this one runs -- the next round's first iteration included.  At an epoch boundary the list is rebuilt
         first: only a list-like trainloader (whose next epoch is known) is looked into, otherwise that copy is serial."""
         stager = self._stager()
         n_b = len(self.trainloader)
         if stager is None or not self.sampled_batches:
+            return
+        if last and self.args.strategy in ["FedICRA"] and isinstance(self.trainloader, (list, tuple)):
+            # the round's last iteration is enqueued: what follows is set_weights with its ALA epoch over the whole loader
+            # (flower_common.py:566-602) -- its batches cross PCIe now, beside the iterations the GPU still has queued, like a
+            # DataLoader's workers run ahead (flower_pCE_2D.py:303-304); the first batch of the NEXT round is announced too
+            self.model.next_batch_hint = self.sampled_batches[self.current_iter % n_b] if self.current_iter % n_b else self.trainloader[0]
+            for b in self.trainloader[:max(0, stager.slots - 3)]:
+                stager.prefetch(b)
             return
         if self.current_iter % n_b == 0:
             if isinstance(self.trainloader, (list, tuple)):
@@ -296,7 +304,7 @@ class MyClient(BaseClient):
                 self.current_iter += 1
                 lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
                 self.current_lr = lr_
-                self._prefetch_next()
+                self._prefetch_next(last=(i_iter == iters - 1))
             yield i_iter
         with self._scope():
             return self._round_result(hist, x, y, rec)

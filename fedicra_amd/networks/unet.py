@@ -290,6 +290,23 @@ class LCEncoder(_FiModule):
         x4, h = self.pcs_list[0]._run(z, emb)
         return feats[:4], x4, h
 
+    def _probe_batches(self, x, G):
+        """The encoder for G DIFFERENT batches (x: all G * B images) under the client's own embedding, as one batched no-grad
+        train-mode pass: every batch is a statistics group -- its own BatchNorm batch statistics, its own dropout draws (the
+        g-th call of each layer), the running statistics moved G times -- with the fused forms of _probe (activations
+        between the convolutions never written, pooling in / before the consumer's loader).  What a decoder with autograd
+        needs is then written out once per level: -> [x0, x1, x2, x3, x4 (after the channel selection)] as activations.
+        Used by the ALA epoch (flower_common.MyModel._ala_epoch_batched), whose copy's encoder is frozen."""
+        r = self.in_conv._probe(x, None, G)
+        feats = [r]
+        for blk in (self.down1, self.down2, self.down3, self.down4):
+            r = blk.maxpool_conv[1]._probe(r, None, G, pool=True)
+            feats.append(r)
+        z = [ops.probe_materialize(f, G) for f in feats]
+        who = self._who((self.cid,), x.shape[0], x.device)
+        x4, _ = self.pcs_list[0]._run(z[4], who)
+        return z[:4] + [x4]
+
     def forward(self, x, emb_idx=None):
         f, h = self._run(self._in(x), emb_idx)
         return [self._out(t) for t in f], [None if t is None else self._out(t) for t in h]

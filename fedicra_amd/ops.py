@@ -791,11 +791,9 @@ def probe_conv(s0, conv, groups):
 
 def probe_materialize(r, groups):
     """z = act(BN(y)) of a raw activation as a tensor (the deepest encoder level, whose consumer is the channel
-    selection): one fi_bn_act_fwd per statistics group."""
+    selection; every level for the ALA epoch's frozen encoder): all statistics groups in one launch."""
     z = torch.empty_like(r.y)
-    n = r.y.shape[0] // groups
-    for g in range(groups):
-        L.bn_act_fwd(r.y[g * n:(g + 1) * n], r.coef[0, g], r.coef[1, g], z[g * n:(g + 1) * n], r.slope, None)
+    L.bn_act_pool_groups(r.y, r.coef, r.slope, z, groups, pool=False)
     return z
 
 

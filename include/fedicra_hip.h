@@ -288,9 +288,11 @@ int fi_maxpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int 
  * fi_conv2d_fwd_fused evaluates (each value rounded to the storage type like fi_bn_act_fwd, then the scan-order strict
  * maximum of fi_maxpool2_fwd), written out once -- for the deep DownBlocks of the batched LC forwards, whose input tile
  * would otherwise be transformed and pooled once per output slab (ConvBlock + MaxPool2d, /root/reference/code/networks/
- * unet.py:14-46).  0 <= slope <= 1. */
+ * unet.py:14-46).  pool == 0: the same without the pooling (y [N][Ho][Wo][C]): act(BN(y)) of every group in one launch,
+ * fi_bn_act_fwd's arithmetic -- the frozen encoder's feature maps for all batches of an ALA epoch (code/flower_common.py:
+ * 566-602).  0 <= slope <= 1. */
 int fi_bn_act_pool_groups(int dtype, const void* y, const float* scale, const float* shift, float slope, void* z, int N, int Ho,
-                          int Wo, int C, int group_images, void* stream);
+                          int Wo, int C, int group_images, int pool, void* stream);
 /* dx = route dy to the first maximum of each window (scan order, strict >), zeros elsewhere. */
 int fi_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate,
                     void* stream);

@@ -209,6 +209,7 @@ def test_ala_epoch_without_the_auxiliary_heads_and_with_half_dgrads_gives_the_sa
         model.start_phase = False
         model.verbose = False
         model.ala_skip_aux = skip_aux
+        model.ala_batched = False                                  # (the per-batch loop on both sides: same dropout draws)
         g = torch.Generator().manual_seed(5)
         glob = DeviceWeights(net.flat_state + 0.02 * torch.randn(net.flat_state.shape, generator=g).to(DEV), net.flat_counters.clone())
         model.set_weights(glob, {"iter_global": 60})

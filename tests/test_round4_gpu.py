@@ -361,3 +361,100 @@ def test_own_forward_with_statistics_only_heads_trains_exactly_like_the_full_hea
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2], (res[0][2], res[1][2])
     assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ ALA epoch, encoder hoisted
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ala_epoch_with_the_encoder_hoisted_equals_the_per_batch_loop(dtype, monkeypatch):
+    """MyModel._ala_epoch_batched (the frozen encoder of all batches of an ALA epoch as ONE batched pass of statistics groups,
+    then decoder forward / backward / mixing update per batch; flower_common.py:566-602) against the per-batch loop it
+    replaces.  With the encoder's dropout switched off the two are the same arithmetic -- the fused forms reproduce the
+    unfused forward bit for bit, a group's BatchNorm statistics are its batch's -- so mixing weights, decoder and epoch
+    losses must agree BIT FOR BIT, eager and captured, over two calls (the second replays the captured epoch)."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import DeviceWeights, MyModel
+    from fedicra_amd.networks import net_factory, unet
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from helpers import loader
+    monkeypatch.setattr(unet, "DROPOUT", [0.0] * 5)
+    outs = []
+    for batched, use_graph in ((False, False), (True, False), (True, True)):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=3, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=4, rep_iters=1, alpha=1.0,
+                                  snapshot_path=None, use_graph=use_graph)
+        torch.manual_seed(2022)
+        ops.manual_seed(7)
+        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
+        set_compute_dtype(net, dtype)
+        batches = loader(3, 4, 64, cid=1, device=DEV)
+        model = MyModel(args, net, batches, batches)
+        model.train()
+        model.start_phase = False
+        model.verbose = False
+        model.ala_batched = batched
+        g = torch.Generator().manual_seed(5)
+        res = []
+        for call in range(3):
+            glob = DeviceWeights(net.flat_state + 0.02 * torch.randn(net.flat_state.shape, generator=g).to(DEV), net.flat_counters.clone())
+            model.set_weights(glob, {"iter_global": 60 + call})
+            torch.cuda.synchronize()
+            res.append((model.fedaa_weights.clone(), net.flat_params.clone(), list(model.ala_epoch_losses)))
+        if batched:
+            assert model._ala.get("ep") is not None and (not use_graph or model._ala["ep"]["graph"] is not None)
+        outs.append(res)
+    # eager and captured batched epochs: the same launches -> bit for bit, in either dtype
+    for (w0, p0, l0), (w1, p1, l1) in zip(outs[1], outs[2]):
+        assert l0 == l1 and torch.equal(w0, w1) and torch.equal(p0, p1)
+    for (w0, p0, l0), (w1, p1, l1) in zip(outs[0], outs[1]):
+        if dtype == "fp32":
+            # exact-fp32 MFMA, one kernel form for 4- and 12-image launches: the same sums in the same order
+            assert l0 == l1, (l0, l1)
+            assert torch.equal(w0, w1) and torch.equal(p0, p1), (float((w0 - w1).abs().max()), float((p0 - p1).abs().max()))
+        else:
+            # bf16: the 12-image launches of the batched pass take other kernel forms (other K-chunk orders in the fp32
+            # accumulators) than the 4-image ones: a feature differs by one bf16 ulp here and there
+            print("bf16 batched vs per-batch ALA: |dloss|", abs(l0[0] - l1[0]), "max |dw|", float((w0 - w1).abs().max()),
+                  "max |dp|", float((p0 - p1).abs().max()))
+            assert abs(l0[0] - l1[0]) < 2e-3 * abs(l0[0])
+            assert float((w0 - w1).abs().mean()) < 2e-3 and float((p0 - p1).abs().max()) < 2e-2
+    assert float((outs[0][0][0] < 1).float().mean()) > 0.01
+
+
+def test_ala_epoch_batched_with_dropout_is_a_valid_epoch_and_captured_equals_eager():
+    """With the encoder's dropout on, the batched epoch draws other masks than the per-batch loop (group g = the g-th call of a
+    layer in ONE iteration instead of call 0 of iteration g): not comparable draw by draw -- but eager and captured runs of
+    the batched epoch must agree bit for bit, the masks must change from epoch to epoch, and the epoch must do what an epoch
+    does (mixing weights move, decoder changes, loss finite and close to the per-batch loop's)."""
+    import argparse
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import DeviceWeights, MyModel
+    from fedicra_amd.networks import net_factory
+    from helpers import loader
+    outs = {}
+    for key, batched, use_graph in (("seq", False, False), ("eager", True, False), ("graph", True, True)):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=3, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=4, rep_iters=1, alpha=1.0,
+                                  snapshot_path=None, use_graph=use_graph)
+        torch.manual_seed(2022)
+        ops.manual_seed(7)
+        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
+        batches = loader(3, 4, 64, cid=1, device=DEV)
+        model = MyModel(args, net, batches, batches)
+        model.train()
+        model.start_phase = False
+        model.verbose = False
+        model.ala_batched = batched
+        g = torch.Generator().manual_seed(5)
+        res = []
+        for call in range(3):
+            glob = DeviceWeights(net.flat_state + 0.02 * torch.randn(net.flat_state.shape, generator=g).to(DEV), net.flat_counters.clone())
+            model.set_weights(glob, {"iter_global": 60 + call})
+            torch.cuda.synchronize()
+            res.append((model.fedaa_weights.clone(), net.flat_params.clone(), list(model.ala_epoch_losses)))
+        outs[key] = res
+    for (w0, p0, l0), (w1, p1, l1) in zip(outs["eager"], outs["graph"]):
+        assert l0 == l1 and torch.equal(w0, w1) and torch.equal(p0, p1)
+    for (w0, p0, l0), (w1, p1, l1) in zip(outs["seq"], outs["eager"]):
+        assert np.isfinite(l1[0]) and abs(l0[0] - l1[0]) < 0.1 * max(abs(l0[0]), 1e-3) + 5e-2, (l0, l1)
+        assert float((w1 < 1).float().mean()) > 0.01
