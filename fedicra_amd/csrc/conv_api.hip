@@ -14,6 +14,8 @@ int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hi
 int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows3d_f16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows_narrow_bf16(int narrow, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows_narrow_f16(int narrow, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_bf16_k1(int th, const WgradArgs& a, hipStream_t st);
@@ -32,6 +34,10 @@ int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& 
 int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws2_bf16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws2_f16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_thin_f32n_bf16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_thin_f32n_f16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_narrow_in_bf16(const ConvArgs& a, hipStream_t st);
+int fi_conv_narrow_in_f16(const ConvArgs& a, hipStream_t st);
 
 // Tile height: the largest of {16, 8, 4} that still gives the 256 CUs >= 2 workgroups each;
 // small feature maps fall through to TH = 4 (more, smaller workgroups).
@@ -106,6 +112,19 @@ static int pick_th(int N, int H, int W, long per_tile_mult) {
 static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* t1, int group_images, int flags,
                          const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
                          double* stats, long stats_group_stride, void* stream, int depth = 0);
+
+// FI_NARROW (default 1) / fi_narrow_tuning: the forms for the layers with a <= 4-channel side -- the first convolution and the
+// logits convolution of the U-Nets, forward, input gradient and filter gradient (conv_narrow.h, conv_thin_kernel<F32N>,
+// conv_wgrad_rows_kernel<XN / DN>); 0 = the general tile kernels (what the parity tests compare against)
+static long g_narrow = -1;
+static bool narrow_on() {
+  static long v = env_long("FI_NARROW", 1);
+  return (g_narrow >= 0 ? g_narrow : v) != 0;
+}
+extern "C" int fi_narrow_tuning(int on) {
+  g_narrow = on;
+  return 0;
+}
 
 extern "C" int fi_conv2d_fwd(const FiConv* d, const void* x0, const void* x1, const void* w, const float* bias,
                              void* y0, void* y1, double* stats, void* stream) {
@@ -240,6 +259,24 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
   a.trace = g_trace;
 #endif
   hipStream_t st = (hipStream_t)stream;
+  if (narrow_on() && !f32 && d->ksize == 3 && depth == 0 && a.xf == 0 && !a.bcast0 && d->c1 == 0 && d->co1 == 0 && y0 && !a.acc0) {
+    const long px = (long)d->N * d->H * d->W;
+    // narrow input side (conv_narrow_in_kernel): the first convolution (1 / 3 -> 16) and the input gradient of the logits
+    // convolution (n_class -> 16); 64-column tiles
+    if (d->c0 <= 4 && (cout == 16 || cout == 8) && !a.y_f32 && d->W >= 32 && d->H >= 8 && px * cout * 2 < (1L << 32)) {
+      a.tilesX = fi_cdiv(d->W, 64);
+      a.tilesY = fi_cdiv(d->H, 16);
+      a.nct = 1;
+      return d->dtype == FI_F16 ? fi_conv_narrow_in_f16(a, st) : fi_conv_narrow_in_bf16(a, st);
+    }
+    // narrow output side with fp32 results (conv_thin_kernel<F32N>): the logits convolution (16 / 32 -> n_class <= 4)
+    if (a.y_f32 && cout <= 4 && (d->c0 == 16 || d->c0 == 32) && d->H >= 8 && px * d->c0 * 2 < (1L << 32) && px * cout * 4 < (1L << 32)) {
+      a.tilesY = fi_cdiv(d->H, 16);
+      a.nct = 1;
+      static const long wgs_env = env_long("FI_THIN_F32N_WGS", 8);
+      return d->dtype == FI_F16 ? fi_conv_thin_f32n_f16(d->c0, (int)wgs_env, a, st) : fi_conv_thin_f32n_bf16(d->c0, (int)wgs_env, a, st);
+    }
+  }
   {
     // persistent form (conv_fwd_v2_kernel): 16-bit storage, 3x3, whole-vector channel counts, plain epilogue, 16-row tiles
     const long v2 = g_tune[0] >= 0 ? g_tune[0] : env_v2(), v2_nf = g_tune[1], v2_ck = g_tune[2], v2_wgs = g_tune[3];
@@ -417,6 +454,7 @@ struct WgradPlan {
   size_t part_stride;
   int rows;             // 1: the row-streaming kernel (wgrad_rows.h) when the caller gives a workspace: sb_rows items, one slice each
   int ws, strips, rpw, chunks, sb_rows;
+  int narrow;           // rows == 1: 1 = <= 4 input channels, 2 = <= 4 gradient channels (conv_wgrad_rows_kernel<NARROW>), the other side 16
 };
 // FI_WGRAD_ROWS (default 1) / fi_wgrad_tuning: the row-streaming kernel on the thin 3x3 layers it covers
 static long g_wgrad_rows = -1;
@@ -456,16 +494,21 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   p->part_stride = (((size_t)cout * d->ksize * d->ksize * cin + cout) + 3) & ~(size_t)3;   // 16-B rows for the reducer
   // thin 3x3 layers on large maps: whole rows streamed through an LDS ring instead of 16 x 16-pixel tiles (wgrad_rows.h)
   p->rows = 0;
-  if (wgrad_rows_on() && depth == 0 && d->dtype != FI_F32 && d->ksize == 3 && (cout == 16 || cout == 32) &&
-      (cin == 16 || cin == 32) && (cin == 16 || cout == 16) && d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->W % 32 == 0 && (d->W <= 256 || d->W % 256 == 0) &&
-      d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 17)) {
+  p->narrow = 0;
+  if (narrow_on() && depth == 0 && d->c1 == 0) {             // first convolution (1 / 3 -> 16), logits convolution (16 -> n_class)
+    if (d->c0 <= 4 && cout == 16) p->narrow = 1;
+    if (d->c0 == 16 && cout <= 4) p->narrow = 2;
+  }
+  const bool thin16 = (cout == 16 || cout == 32) && (cin == 16 || cin == 32) && (cin == 16 || cout == 16) && d->c0 % 16 == 0 && d->c1 % 16 == 0;
+  if (wgrad_rows_on() && depth == 0 && d->dtype != FI_F32 && d->ksize == 3 && (thin16 || p->narrow) && d->W % 32 == 0 &&
+      (d->W <= 256 || d->W % 256 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 17)) {
     p->rows = 1;
     p->ws = d->W <= 256 ? d->W : 256;
     p->strips = d->W / p->ws;
     // ~3 workgroups per CU (16 input channels: 49 KB of LDS each), ~1.5 with 32 (66 KB; measured 67 us at 384 items against
     // 78 at 768 on 12 x 512^2 32 -> 16); a run is at least FI_WGRAD_ROWS_MINR rows (two dy halo rows per run)
     static const long items_env = env_long("FI_WGRAD_ROWS_ITEMS", 0), minr = env_long("FI_WGRAD_ROWS_MINR", 16);
-    const long items_target = items_env > 0 ? items_env : (cin == 16 ? 768 : 384);
+    const long items_target = items_env > 0 ? items_env : ((cin == 16 || p->narrow) ? 768 : 384);
     long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
     if (rpw < minr) rpw = minr;
     if (rpw > d->H) rpw = d->H;
@@ -622,7 +665,10 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
     ra.ws = p.ws, ra.strips = p.strips, ra.rpw = p.rpw, ra.chunks = p.chunks;
     ra.want_bias = dbias != nullptr;
     ra.depth = depth;
-    if (p.rows == 2)
+    ra.cd = cout;
+    if (p.rows == 1 && p.narrow)
+      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_narrow_f16(p.narrow, ra, p.sb, st) : fi_conv_wgrad_rows_narrow_bf16(p.narrow, ra, p.sb, st);
+    else if (p.rows == 2)
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows3d_f16((d->c0 + d->c1) / 16, ra, p.sb, st)
                              : fi_conv_wgrad_rows3d_bf16((d->c0 + d->c1) / 16, ra, p.sb, st);
     else

@@ -1774,7 +1774,10 @@ static int launch_conv_fwd_ws(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 // any cap worth having and are left alone (profiles/r02_h_thin_variants.txt).
 // TWO: the input is a concatenation of two tensors (c1 != 0) -- a compile-time split, so that the single-source loader is
 // straight-line buffer loads (a run-time branch per load measured 1.3-1.7x slower on the 16-channel layers).
-template <typename T, int NF, int CK, int XF, bool TWO>
+// F32N: the logits convolution (out_conv: 16 -> n_class <= 4, /root/reference/code/networks/unet.py:228) -- fp32 outputs, 4 * Cout
+// bytes per pixel, stored by the one k-group of lanes that holds real output channels (the generic one-tile kernel took 72 us for
+// 12 x 512^2 x 16 -> 3 against 47 of this form's 16 -> 16).
+template <typename T, int NF, int CK, int XF, bool TWO, bool F32N = false>
 __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int KS = 3, TH = 16, HALO = 1, XW = 18, XH = 18, KK = 9;
@@ -1835,7 +1838,7 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.x1), 0, a.c1 ? (unsigned)a.N * (unsigned)H * (unsigned)W * (unsigned)a.c1 * esz : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      a.y0, 0, a.y0 ? (unsigned)a.N * (unsigned)H * (unsigned)W * (unsigned)cout * esz : 0u, 0x00020000);
+      a.y0, 0, a.y0 ? (unsigned)a.N * (unsigned)H * (unsigned)W * (unsigned)cout * (F32N ? 4u : esz) : 0u, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
   // ---- staging geometry: a thread owns one vector column (pixel column xpx, channel vector xv) of the halo tile
@@ -2093,7 +2096,30 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
       }
     }
   };
+  // F32N: lane (li, kg == 0) holds output channels 0 .. 3 of pixel column li for each of its wave's four rows
+  auto epilogue_n = [&](const Tile& tc) __attribute__((always_inline)) {
+    const int gx = tc.tx * 16 + li;
+    const bool colok = gx < W && kg == 0;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gy = tc.ty * TH + wave * MF + m;
+      const bool ok = colok && gy < H;
+      const unsigned o = (unsigned)((tc.n * H + gy) * W + gx) * (unsigned)cout * 4u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[m][0][r] + bv[0][r];
+        const float vm = ok ? v : 0.f;
+        ssum[0][r] += vm;
+        ssq[0][r] += vm * v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (ok && r < cout) ? o + 4u * r : OOB, 0, 0);
+      }
+    }
+  };
   auto epilogue = [&](const Tile& tc) __attribute__((always_inline)) {
+    if constexpr (F32N) {
+      epilogue_n(tc);
+      return;
+    }
     // (two copies of the epilogue cost the two-fragment instantiations 10-15 %: they keep the masked form only)
     if (NF == 1 && tc.tx * 16 + 16 <= W && tc.ty * TH + TH <= H)
       epilogue_t(tc, std::true_type());
@@ -2136,6 +2162,18 @@ __global__ __launch_bounds__(256, (NF == 1 ? 3 : 1)) void conv_thin_kernel(ConvA
     stats_flush(grp);
     t = seg_end;
   }
+}
+
+template <typename T, int CK>
+static int launch_conv_thin_f32n(const ConvArgs& a, int wgs_per_cu, hipStream_t st) {
+  constexpr int CKP = FiLdsStride<T, CK>::value;
+  const size_t lds = (size_t)(18 * 18 * CKP) * sizeof(T) + (size_t)4 * 16 * 2 * sizeof(float);
+  const long ntile = (long)a.N * a.tilesX * a.tilesY;
+  long blocks = 256L * wgs_per_cu;
+  if (blocks > ntile) blocks = ntile;
+  hipLaunchKernelGGL((conv_thin_kernel<T, 1, CK, 0, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
 }
 
 template <typename T, int NF, int CK>

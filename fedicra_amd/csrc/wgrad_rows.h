@@ -30,6 +30,7 @@ struct WgRowsArgs {
   int ws, strips, rpw, chunks;     // strip width, strips per row, x rows per item, items per (image, strip)
   int want_bias;
   int depth;               // conv_wgrad_rows3d_kernel: slices per volume (an "image" is a slice)
+  int cd;                  // NARROW == 2: channels of the gradient tensor (<= 4); NARROW == 1: c0 <= 4 is the input's, c1 = 0
 };
 
 template <typename T>
@@ -47,8 +48,13 @@ __device__ __forceinline__ typename DT<T>::frag_t wgr_frag(const char* addr) {
 }
 
 // NCI / NCO: 16-channel blocks of the input / gradient side.  WSP = ws + 2 (x row with its two halo pixels).
-template <typename T, int NCI, int NCO>
+// NARROW (NCI = NCO = 1): one side is a dense tensor of <= 4 channels -- 1: the input (the network's first convolution, 1 / 3 -> 16),
+// 2: the gradient (the logits convolution, 16 -> n_class).  Its rows are staged element by element into the first 8 bytes of each
+// pixel's 32-byte block of the plane; the other 24 stay zero from the start of the workgroup, the MFMA schedule is the same, and
+// only the real rows / columns of the filter gradient are written to the slice (layout [co][9][ci] over the REAL channel counts).
+template <typename T, int NCI, int NCO, int NARROW = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
+  static_assert(NARROW == 0 || (NCI == 1 && NCO == 1), "narrow sides: one block each");
   typedef typename DT<T>::frag_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,7 +72,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   const int cs = strip * ws;
   const T* const x0 = reinterpret_cast<const T*>(a.x0) + (size_t)n * H * W * a.c0;
   const T* const x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * H * W * a.c1;
-  const T* const dyg = reinterpret_cast<const T*>(a.dy) + (size_t)n * H * W * (NCO * 16);
+  const T* const dyg = reinterpret_cast<const T*>(a.dy) + (size_t)n * H * W * (NARROW == 2 ? a.cd : NCO * 16);
+  // narrow sides: 16-bit raw buffer loads over this image's plane (an element the lane does not have: out-of-range offset -> zero;
+  // predicated plain loads would become branches that serialise the round trips)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rnx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(x0), 0, NARROW == 1 ? (unsigned)H * (unsigned)W * (unsigned)a.c0 * 2u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rnd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(dyg), 0, NARROW == 2 ? (unsigned)H * (unsigned)W * (unsigned)a.cd * 2u : 0u, 0x00020000);
+  auto narrow_px = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned pix, int nch, bool ok) __attribute__((always_inline)) {
+    unsigned e[4];                                 // <= 4 elements of pixel `pix` of the plane -> 8 bytes
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e[c] = __builtin_amdgcn_raw_buffer_load_b16(rs, (ok && c < nch) ? (pix * (unsigned)nch + c) * 2u : OOB, 0, 0);
+    return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u);
+  };
 
   // ---- staging: vectors of 8 channels.  x row: (ws + 2) pixels x 2 NCI vectors; dy row: ws pixels x 2 NCO vectors
   constexpr int MAXW = 256;
@@ -75,6 +94,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];      // two register stages: a row's loads are issued two steps before its store
   auto load_x = [&](uint4 (&xr)[NXV], int rho) {                  // x row rho, columns cs - 1 .. cs + ws
     const bool rowok = rho >= 0 && rho < H;
+    if constexpr (NARROW == 1) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int px = tid + it * 256, gx = cs + px - 1;
+        const bool ok = rowok && px < ws + 2 && gx >= 0 && gx < W;
+        xr[it] = narrow_px(rnx, (unsigned)(rho * W + gx), a.c0, ok);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NXV; ++it) {
       const int i = tid + it * 256;
@@ -89,6 +117,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   };
   auto load_d = [&](uint4 (&dr)[NDV], int r) {                    // dy row r, columns cs .. cs + ws - 1
     const bool rowok = r >= 0 && r < H;
+    if constexpr (NARROW == 2) {
+      const bool ok = rowok && tid < ws;
+      dr[0] = narrow_px(rnd, (unsigned)(r * W + cs + tid), a.cd, ok);
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NDV; ++it) {
       const int i = tid + it * 256;
@@ -99,6 +132,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
     }
   };
   auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
+    if constexpr (NARROW == 1) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int px = tid + it * 256;
+        if (px < ws + 2) *reinterpret_cast<uint2*>(xs + slot * xrow + px * 32) = make_uint2(xr[it].x, xr[it].y);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NXV; ++it) {
       const int i = tid + it * 256;
@@ -107,6 +148,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
     }
   };
   auto store_d = [&](const uint4 (&dr)[NDV], int slot) {
+    if constexpr (NARROW == 2) {
+      if (tid < ws) *reinterpret_cast<uint2*>(ds + slot * drow + tid * 32) = make_uint2(dr[0].x, dr[0].y);
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NDV; ++it) {
       const int i = tid + it * 256;
@@ -133,6 +178,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   const int g = lane >> 4, li = lane & 15;
   const int laneoff = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
 
+  if constexpr (NARROW != 0) {                  // the channels a narrow side does not have: zero for the life of the workgroup
+    for (int i = tid * 16; i < 2 * xrow + 4 * drow; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+  }
   // prologue: x row r0 and dy rows r0 - 1, r0, r0 + 1 into the ring; stage A <- (x r0 + 1, dy r0 + 2), stage B <- (x r0 + 2, dy r0 + 3)
   load_x(xrA, r0);
   load_d(drA, r0 - 1);
@@ -221,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   }
   __syncthreads();
   // this item's slice: slice[(co * 9 + t) * cin + ci], bias behind it (conv_wgrad_kernel's layout)
-  constexpr int CIN = NCI * 16, COUT = NCO * 16;
+  const int CIN = NARROW == 1 ? a.c0 : NCI * 16, COUT = NARROW == 2 ? a.cd : NCO * 16;     // (constants unless a side is narrow)
   float* const slice = a.part + (size_t)blockIdx.x * a.part_stride;
   for (int e = tid; e < 9 * COUT * CIN; e += 256) {
     const int ci = e % CIN, t = (e / CIN) % 9, co = e / (CIN * 9);
@@ -230,12 +279,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   if (a.want_bias && tid < COUT) slice[(size_t)COUT * 9 * CIN + tid] = red[NACC + tid];
 }
 
-template <typename T, int NCI, int NCO>
+template <typename T, int NCI, int NCO, int NARROW = 0>
 static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st) {
   size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)4 * NCO * a.ws * 32;
   const size_t red = (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
   if (lds < red) lds = red;
-  hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCI, NCO>), dim3((unsigned)items), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCI, NCO, NARROW>), dim3((unsigned)items), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

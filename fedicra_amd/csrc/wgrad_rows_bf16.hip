@@ -16,3 +16,10 @@ int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream
   if (nci == 3) return launch_conv_wgrad_rows3d<bf16_t, 3, 128>(a, items, st);
   return FI_ERR_UNSUPPORTED;
 }
+
+// narrow = 1: <= 4 input channels (first convolution), 2: <= 4 gradient channels (logits convolution); the other side 16
+int fi_conv_wgrad_rows_narrow_bf16(int narrow, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (narrow == 1) return launch_conv_wgrad_rows<bf16_t, 1, 1, 1>(a, items, st);
+  if (narrow == 2) return launch_conv_wgrad_rows<bf16_t, 1, 1, 2>(a, items, st);
+  return FI_ERR_UNSUPPORTED;
+}

@@ -16,3 +16,10 @@ int fi_conv_wgrad_rows3d_f16(int nci, const WgRowsArgs& a, int items, hipStream_
   if (nci == 3) return launch_conv_wgrad_rows3d<f16_t, 3, 128>(a, items, st);
   return FI_ERR_UNSUPPORTED;
 }
+
+// narrow = 1: <= 4 input channels (first convolution), 2: <= 4 gradient channels (logits convolution); the other side 16
+int fi_conv_wgrad_rows_narrow_f16(int narrow, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (narrow == 1) return launch_conv_wgrad_rows<f16_t, 1, 1, 1>(a, items, st);
+  if (narrow == 2) return launch_conv_wgrad_rows<f16_t, 1, 1, 2>(a, items, st);
+  return FI_ERR_UNSUPPORTED;
+}

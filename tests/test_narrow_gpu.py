@@ -1,0 +1,185 @@
+"""The forms for the layers with a <= 4-channel side (csrc/conv_narrow.h, conv_thin_kernel<F32N>, conv_wgrad_rows_kernel<NARROW>,
+nchw_to_nhwc_narrow_kernel): the U-Nets' first convolution in_chns -> 16 (/root/reference/code/networks/unet.py:82,163) and their
+logits convolution 16 -> n_class (:228) -- forward, input gradient, filter gradient -- against an fp64 convolution of the same
+rounded operands AND against the general tile kernels they replace (fi_narrow_tuning(0)), through the C-ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _both(fn):
+    """fn() under the narrow forms and under the general kernels -> (narrow, general)."""
+    from fedicra_amd import _lib as L
+    out = []
+    try:
+        for on in (1, 0):
+            L.lib().fi_narrow_tuning(on)
+            out.append(fn())
+    finally:
+        L.lib().fi_narrow_tuning(-1)
+    torch.cuda.synchronize()
+    return out
+
+
+def _ulp16(dtype):
+    return 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10          # twice the largest relative rounding error
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 3, 16, 0), (3, 48, 96, 1, 16, 0), (1, 37, 67, 3, 16, 0), (2, 40, 72, 2, 8, 0),
+                                   (6, 64, 128, 3, 16, 2), (1, 130, 200, 4, 16, 0)])
+def test_narrow_input_forward_with_bias_statistics_and_groups(shape, dtype):
+    """conv_narrow_in_kernel: 1 ... 4 input channels -> 8 / 16 outputs; ragged sizes (tile overhang in both directions: masked
+    stores and statistics), statistics groups (fi_conv2d_fwd_fused without a transform: the ALA epoch's batched first layer)."""
+    from fedicra_amd import _lib as L
+    N, H, W, cin, cout, gi = shape
+    g = torch.Generator().manual_seed(H * 7 + W + cin)
+    x = torch.randn(N, H, W, cin, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.3).to(dtype).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    groups = N // gi if gi else 1
+
+    def run():
+        y = torch.full((N, H, W, cout), 7.0, dtype=dtype, device=DEV)
+        stats = torch.zeros(groups, L.STATS_SLOTS, cout, 2, dtype=torch.float64, device=DEV)
+        if gi:
+            L.conv2d_fwd_fused(x, None, None, None, w, b, y, stats, ksize=3, groups=groups, cout=cout)
+        else:
+            L.conv2d_fwd(x, None, w, b, y, None, stats, ksize=3)
+        return y.clone(), stats.sum(1).cpu()
+
+    (y1, s1), (y0, s0) = _both(run)
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    tol = _ulp16(dtype) * want.abs().clamp(min=1.0)
+    assert ((y1.double() - want).abs() <= tol).all()                       # one rounding of the exact value (+ fp32 noise)
+    assert ((y0.double() - want).abs() <= tol).all()
+    assert (y1 != y0).float().mean().item() < 1e-2                         # another summation order: the same bits but for rare ties
+    yd = y1.double().reshape(groups, -1, cout)                             # statistics are taken of the values AS STORED
+    ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1).cpu()
+    assert torch.allclose(s1, ref, rtol=5e-6, atol=5e-3), (s1 - ref).abs().max()
+    yd0 = y0.double().reshape(groups, -1, cout)
+    assert torch.allclose(s0, torch.stack([yd0.sum(1), (yd0 * yd0).sum(1)], -1).cpu(), rtol=5e-6, atol=5e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_narrow_input_forward_is_the_logits_input_gradient(dtype):
+    """The dgrad call of ops._conv_backward for out_conv: dy [N,H,W,n_class] against the flipped / transposed operand
+    (fi_pack_weights mode 1), no bias, no statistics."""
+    from fedicra_amd import _lib as L
+    N, H, W, ncls, cin = 2, 96, 160, 3, 16
+    g = torch.Generator().manual_seed(11)
+    dy = (torch.randn(N, H, W, ncls, generator=g) * 0.1).to(dtype).to(DEV)
+    wk = (torch.randn(ncls, 3, 3, cin, generator=g) * 0.2).to(DEV)          # fp32 master [Cout][kh][kw][Cin]
+    wt = torch.empty(cin * 9 * ncls, dtype=dtype, device=DEV)
+    L.pack_weights(wk, wt, ncls, 9, cin, 1)
+
+    def run():
+        dx = torch.empty(N, H, W, cin, dtype=dtype, device=DEV)
+        L.conv2d_fwd(dy, None, wt, None, dx, None, None, ksize=3, tag="conv_dgrad")
+        return dx.clone()
+
+    d1, d0 = _both(run)
+    wr = wk.to(dtype).double()                                              # the operand's rounding
+    want = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    tol = _ulp16(dtype) * want.abs().clamp(min=0.25)
+    assert ((d1.double() - want).abs() <= tol).all() and ((d0.double() - want).abs() <= tol).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 3), (2, 40, 56, 32, 2), (1, 33, 70, 16, 4), (3, 128, 128, 16, 1)])
+def test_logits_convolution_fp32_outputs(shape, dtype):
+    """conv_thin_kernel<F32N>: 16 / 32 channels -> n_class <= 4 fp32 outputs with bias; ragged sizes."""
+    from fedicra_amd import _lib as L
+    N, H, W, cin, cout = shape
+    g = torch.Generator().manual_seed(H + cout)
+    x = torch.randn(N, H, W, cin, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.2).to(dtype).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+
+    def run():
+        y = torch.full((N, H, W, cout), 7.0, dtype=torch.float32, device=DEV)
+        L.conv2d_fwd(x, None, w, b, y, None, None, ksize=3, y_f32=True)
+        return y.clone()
+
+    y1, y0 = _both(run)
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert (y1.double() - want).abs().max().item() < 2e-5 and (y0.double() - want).abs().max().item() < 2e-5
+    assert not torch.equal(y1, y0) or cin * cout < 32                       # another summation order: the thin form really ran
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(8, 128, 128, 3, 16), (2, 256, 512, 3, 16), (3, 250, 256, 1, 16), (8, 128, 128, 16, 3),
+                                   (1, 512, 512, 16, 2), (2, 264, 256, 16, 4)])
+def test_narrow_filter_gradients_against_fp64_and_the_tile_kernels(shape, dtype):
+    """conv_wgrad_rows_kernel<NARROW>: the first convolution's (<= 4 input channels) and the logits convolution's (<= 4 gradient
+    channels) filter and bias gradients; two strips per row, ragged row chunks, one-image launches."""
+    from fedicra_amd import _lib as L
+    N, H, W, cin, cout = shape
+    g = torch.Generator().manual_seed(H + cin + cout)
+    x = torch.randn(N, H, W, cin, generator=g).to(dtype).to(DEV)
+    dy = (torch.randn(N, H, W, cout, generator=g) * 0.1).to(dtype).to(DEV)
+
+    def run():
+        dw = torch.zeros(cout, 3, 3, cin, device=DEV)
+        db = torch.zeros(cout, device=DEV)
+        L.conv2d_wgrad(x, None, dy, dw, db, ksize=3)
+        return dw.double().cpu(), db.double().cpu()
+
+    (w1, b1), (w0, b0) = _both(run)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(x.double().permute(0, 3, 1, 2), wref, torch.zeros(cout, dtype=torch.float64, device=DEV),
+             padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    want = wref.grad.permute(0, 2, 3, 1).cpu()
+    want_b = dy.double().sum((0, 1, 2)).cpu()
+    scale = want.abs().max().item()
+    assert (w1 - want).abs().max().item() / scale < 2e-5 and (w0 - want).abs().max().item() / scale < 2e-5
+    assert (b1 - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
+    assert (b0 - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
+    assert not torch.equal(w1, w0)                                          # the row-streaming form really ran
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(12, 3, 64, 64), (2, 1, 48, 50), (3, 4, 16, 32), (2, 3, 15, 15)])
+def test_nchw_to_nhwc_of_narrow_inputs_is_a_permute_and_one_rounding(shape, dtype):
+    from fedicra_amd import _lib as L
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out = torch.full((shape[0], shape[2], shape[3], shape[1]), 9.0, dtype=dtype, device=DEV)
+    L.nchw_to_nhwc(x, out)
+    assert torch.equal(out, x.permute(0, 2, 3, 1).to(dtype))
+    base = torch.randn(shape[0] + 2, *shape[1:], generator=torch.Generator().manual_seed(4)).to(DEV)
+    L.nchw_to_nhwc(base[1:-1], out)                                        # a batch view at an offset
+    assert torch.equal(out, base[1:-1].permute(0, 2, 3, 1).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_unet_training_step_is_the_same_with_and_without_the_narrow_forms(dtype):
+    """One UNet forward / backward at 8 x 3 x 128^2 under the narrow forms and under the general kernels: logits to fp32 noise,
+    every parameter gradient to 2e-3 of its largest entry (16-bit activations; the two paths differ by rare one-ulp ties)."""
+    from fedicra_amd import ops
+    from fedicra_amd.networks.unet import UNet, set_compute_dtype
+    from oracle.unet_ref import seeded_state
+    torch.manual_seed(0)
+    x = torch.randn(8, 3, 128, 128, device=DEV)                            # 8 x 128^2 pixels: the row-streaming filter gradients apply
+    y = torch.randint(0, 3, (8, 128, 128), device=DEV, dtype=torch.uint8)
+
+    def run():
+        m = UNet(3, 3)
+        seeded_state(m, 5)
+        m = m.cuda()
+        set_compute_dtype(m, dtype)
+        m.eval()                                                           # no dropout draws, running statistics in the BatchNorms
+        out = m(x)[0]
+        loss = ops.ce_loss(out.permute(0, 2, 3, 1), y, 3)
+        loss.backward()
+        ops.flush_wgrad()
+        return out.detach().float().clone(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    (o1, g1), (o0, g0) = _both(run)
+    assert (o1 - o0).abs().max().item() < 2e-2 * max(1.0, o0.abs().max().item())
+    assert g1.keys() == g0.keys() and len(g1) > 40
+    for k in g1:
+        s = g0[k].abs().max().item()
+        assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * s + 1e-7, k
