@@ -113,14 +113,15 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
                          const void* x0, const void* x1, const void* w, const float* bias, void* y0, void* y1,
                          double* stats, long stats_group_stride, void* stream, int depth = 0);
 
-// FI_NARROW (default 1) / fi_narrow_tuning: the forms for the layers with a <= 4-channel side -- the first convolution and the
+// FI_NARROW (default 7 = all) / fi_narrow_tuning (a bit mask): the forms for the layers with a <= 4-channel side -- the first convolution and the
 // logits convolution of the U-Nets, forward, input gradient and filter gradient (conv_narrow.h, conv_thin_kernel<F32N>,
 // conv_wgrad_rows_kernel<XN / DN>); 0 = the general tile kernels (what the parity tests compare against)
 static long g_narrow = -1;
-static bool narrow_on() {
-  static long v = env_long("FI_NARROW", 1);
-  return (g_narrow >= 0 ? g_narrow : v) != 0;
+static long narrow_mask() {                       // bit 0: narrow-input forward, bit 1: fp32 narrow-output forward, bit 2: filter gradients
+  static long v = env_long("FI_NARROW", 7);
+  return g_narrow >= 0 ? g_narrow : v;
 }
+static bool narrow_on() { return (narrow_mask() & 4) != 0; }
 extern "C" int fi_narrow_tuning(int on) {
   g_narrow = on;
   return 0;
@@ -259,18 +260,18 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
   a.trace = g_trace;
 #endif
   hipStream_t st = (hipStream_t)stream;
-  if (narrow_on() && !f32 && d->ksize == 3 && depth == 0 && a.xf == 0 && !a.bcast0 && d->c1 == 0 && d->co1 == 0 && y0 && !a.acc0) {
+  if (narrow_mask() && !f32 && d->ksize == 3 && depth == 0 && a.xf == 0 && !a.bcast0 && d->c1 == 0 && d->co1 == 0 && y0 && !a.acc0) {
     const long px = (long)d->N * d->H * d->W;
     // narrow input side (conv_narrow_in_kernel): the first convolution (1 / 3 -> 16) and the input gradient of the logits
     // convolution (n_class -> 16); 64-column tiles
-    if (d->c0 <= 4 && (cout == 16 || cout == 8) && !a.y_f32 && d->W >= 32 && d->H >= 8 && px * cout * 2 < (1L << 32)) {
+    if ((narrow_mask() & 1) && d->c0 <= 4 && (cout == 16 || cout == 8) && !a.y_f32 && d->W >= 32 && d->H >= 8 && px * cout * 2 < (1L << 32)) {
       a.tilesX = fi_cdiv(d->W, 64);
       a.tilesY = fi_cdiv(d->H, 16);
       a.nct = 1;
       return d->dtype == FI_F16 ? fi_conv_narrow_in_f16(a, st) : fi_conv_narrow_in_bf16(a, st);
     }
     // narrow output side with fp32 results (conv_thin_kernel<F32N>): the logits convolution (16 / 32 -> n_class <= 4)
-    if (a.y_f32 && cout <= 4 && (d->c0 == 16 || d->c0 == 32) && d->H >= 8 && px * d->c0 * 2 < (1L << 32) && px * cout * 4 < (1L << 32)) {
+    if ((narrow_mask() & 2) && a.y_f32 && cout <= 4 && (d->c0 == 16 || d->c0 == 32) && d->H >= 8 && px * d->c0 * 2 < (1L << 32) && px * cout * 4 < (1L << 32)) {
       a.tilesY = fi_cdiv(d->H, 16);
       a.nct = 1;
       static const long wgs_env = env_long("FI_THIN_F32N_WGS", 8);

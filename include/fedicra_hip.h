@@ -208,11 +208,11 @@ int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, voi
  * (16 / 32 channels a side, 16-bit storage, W % 32 == 0, a workspace given) take the row-streaming kernel (csrc/wgrad_rows.h),
  * -1 = the FI_WGRAD_ROWS environment default (1). */
 int fi_wgrad_tuning(int rows);
-/* Measurement / test hook: on = 0 keeps the layers with a <= 4-channel side (the U-Nets' first convolution in_chns -> 16,
+/* Measurement / test hook (a bit mask; 7 = all forms): on = 0 keeps the layers with a <= 4-channel side (the U-Nets' first convolution in_chns -> 16,
  * /root/reference/code/networks/unet.py:82,163, and their logits convolution 16 -> n_class, :228) on the general tile kernels;
- * 1 lets them take the narrow forms -- fi_conv2d_fwd: C <= 4 inputs -> 8 / 16 outputs (also the logits convolution's input
- * gradient) and 16 / 32 inputs -> <= 4 fp32 outputs; fi_conv2d_wgrad*: either side <= 4 channels against 16 (row-streaming,
- * workspace given); 3x3, 16-bit storage, one source.  -1 = the FI_NARROW environment default (1). */
+ * bit 0 = fi_conv2d_fwd with C <= 4 inputs -> 8 / 16 outputs (also the logits convolution's input gradient), bit 1 = fi_conv2d_fwd with
+ * 16 / 32 inputs -> <= 4 fp32 outputs, bit 2 = fi_conv2d_wgrad* with either side <= 4 channels against 16 (row-streaming,
+ * workspace given); 3x3, 16-bit storage, one source.  -1 = the FI_NARROW environment default (7). */
 int fi_narrow_tuning(int on);
 
 /* weight repack from the fp32 master [Cout][k*k][Cin]:

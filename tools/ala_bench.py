@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--in-chns", type=int, default=1)
+    ap.add_argument("--graph-only", action="store_true", help="skip the eager leg (profiling runs)")
+    ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     from fedicra_amd.flower_common import DeviceWeights, MyModel
     from fedicra_amd.networks import net_factory
@@ -30,7 +32,7 @@ def main():
     for i in range(a.batches):
         img, weak, _ = phantom_batch(a.batch, a.size, a.in_chns, ncls, cid=2, index=i)
         batches.append({"image": torch.from_numpy(img).to(dev), "label": torch.from_numpy(weak).to(dev)})
-    for use_graph in (False, True):
+    for use_graph in ((True,) if a.graph_only else (False, True)):
         args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=2, min_num_clients=8, num_classes=ncls,
                                   img_class="faz" if a.in_chns == 1 else "odoc", base_lr=0.01, max_iterations=30000, iters=6,
                                   rep_iters=3, alpha=1.0, snapshot_path=None, use_graph=use_graph)
@@ -42,7 +44,7 @@ def main():
         model.start_phase = False
         sys.stdout = open(os.devnull, "w")
         ts = []
-        for r in range(5):
+        for r in range(a.rounds):
             glob = DeviceWeights(net.flat_state + 0.01 * torch.randn_like(net.flat_state), net.flat_counters.clone())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
