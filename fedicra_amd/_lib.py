@@ -28,7 +28,7 @@ EXPORTS = [
     "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
-    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning",
+    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning",
 ]
 
 
@@ -512,6 +512,27 @@ def upsample2x_fwd(x, y):
     N, h, w, Cc = _dev(x).shape
     with _timed("upsample_fwd", (str(x.dtype)[6:],) + tuple(x.shape), 0, 5 * x.numel() * _esz(x)):
         _chk(lib().fi_upsample2x_fwd(dt(x.dtype), ptr(x), ptr(y), N, h, w, Cc, stream()), "fi_upsample2x_fwd")
+
+
+def conv1x1_up2x_fwd(x, t0, w, bias, y, *, groups=1):
+    """fi_conv1x1_up2x_fwd: y [N,2h,2w,cout] = bilinear x2 of conv1x1(act(BN(x)) or x).  Returns False (nothing launched) when the
+    shape is not covered: the caller makes the two launches."""
+    _dev(x)
+    N, h, wd, cin = x.shape
+    cout = y.shape[3]
+    px = N * h * wd
+    with _timed("conv_up_fwd", (str(x.dtype)[6:], N, h, wd, cin, cout, 1) + (("fused",) if t0 is not None else ()),
+                2.0 * px * cin * cout, x.numel() * _esz(x) + y.numel() * _esz(y) + cin * cout * _esz(x)):
+        rc = lib().fi_conv1x1_up2x_fwd(dt(x.dtype), N, h, wd, cin, cout, None if t0 is None else C.byref(t0), int(N // groups),
+                                       ptr(x), ptr(w), ptr(bias), ptr(y), stream())
+    if rc == FI_ERR_UNSUPPORTED:
+        return False
+    _chk(rc, "fi_conv1x1_up2x_fwd")
+    return True
+
+
+def upfuse_tuning(rows):
+    _chk(lib().fi_upfuse_tuning(int(rows)), "fi_upfuse_tuning")
 
 
 def upsample2x_bwd(dy, dx, accumulate=False):

@@ -214,6 +214,11 @@ __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t dr
   return fi_rand32(seed, idx) >= drop_thresh;
 }
 
+// l0 * a + l1 * b with ONE defined rounding sequence (a product, then a fused multiply-add): the bilinear up-sampling kernels
+// (ops.hip: flat and row forms; upfuse.hip: behind the 1x1 convolution) all interpolate through this, along x and then along y,
+// so that they agree bit for bit instead of as hipcc happens to contract each kernel's expression.
+__device__ __forceinline__ float fi_lerp2(float l0, float a, float l1, float b) { return __builtin_fmaf(l1, b, l0 * a); }
+
 static inline int fi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #define FI_CHECK_LAUNCH()                         \

@@ -822,14 +822,14 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
     lin_coord(ox, w, sw, x0, x1, lx0, lx1);
     const T* b = x + (size_t)n * h * w * C + cv * VG;
     float a00[VG], a01[VG], a10[VG], a11[VG], o[VG];
-    load_vec<T>(b + ((size_t)y0 * w + x0) * C, a00);
-    load_vec<T>(b + ((size_t)y0 * w + x1) * C, a01);
-    load_vec<T>(b + ((size_t)y1 * w + x0) * C, a10);
-    load_vec<T>(b + ((size_t)y1 * w + x1) * C, a11);
+    VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(b + ((size_t)y0 * w + x0) * C), a00);
+    VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(b + ((size_t)y0 * w + x1) * C), a01);
+    VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(b + ((size_t)y1 * w + x0) * C), a10);
+    VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(b + ((size_t)y1 * w + x1) * C), a11);
 #pragma unroll
     for (int j = 0; j < VG; ++j)
-      o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
-    store_vec<T>(y + i * VG, o);
+      o[j] = fi_lerp2(ly0, fi_lerp2(lx0, a00[j], lx1, a01[j]), ly1, fi_lerp2(lx0, a10[j], lx1, a11[j]));
+    *reinterpret_cast<typename DT<T>::vec_t*>(y + i * VG) = VecWords<T>::pack(o);
   }
 }
 
@@ -859,14 +859,14 @@ __global__ __launch_bounds__(256) void upsample_fwd_rows_kernel(const T* __restr
       lin_coord(ox, w, sw, x0, x1, lx0, lx1);
       const int o0 = x0 * C + cv * VG, o1 = x1 * C + cv * VG;
       float a00[VG], a01[VG], a10[VG], a11[VG], o[VG];
-      load_vec<T>(r0 + o0, a00);
-      load_vec<T>(r0 + o1, a01);
-      load_vec<T>(r1 + o0, a10);
-      load_vec<T>(r1 + o1, a11);
+      VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(r0 + o0), a00);
+      VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(r0 + o1), a01);
+      VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(r1 + o0), a10);
+      VecWords<T>::unpack(*reinterpret_cast<const typename DT<T>::vec_t*>(r1 + o1), a11);
 #pragma unroll
       for (int j = 0; j < VG; ++j)
-        o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
-      store_vec<T>(yo + (size_t)i * VG, o);
+        o[j] = fi_lerp2(ly0, fi_lerp2(lx0, a00[j], lx1, a01[j]), ly1, fi_lerp2(lx0, a10[j], lx1, a11[j]));
+      *reinterpret_cast<typename DT<T>::vec_t*>(yo + (size_t)i * VG) = VecWords<T>::pack(o);
     }
   }
 }

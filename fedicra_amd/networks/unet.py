@@ -143,7 +143,7 @@ class UpBlock(_FiModule):
 
     def _run(self, x1, x2):
         if self.bilinear:
-            up = ops.upsample2x(ops.conv2d(x1, None, self.conv1x1))
+            up = ops.conv1x1_up(x1, self.conv1x1)
         else:
             from .. import extra_ops
             up = extra_ops.conv_transpose2x(x1, self.up)
@@ -360,7 +360,7 @@ class _DecoderBase(_FiModule):
         """Decoder of the batched no-grad forward: nothing is returned -- what it leaves behind are the BatchNorm running
         statistics of every block and head, moved `groups` times as the separate forwards would."""
         def up(blk, lo, skip, store=True):
-            u = ops.upsample2x(ops.probe_conv(lo, blk.conv1x1, groups))
+            u = ops.probe_conv_up(lo, blk.conv1x1, groups)
             return blk.conv._probe(skip, u, groups, store=store)
         read = {idx for _, idx in self._heads()}
         o = [None, up(self.up1, x4, skips[3])]

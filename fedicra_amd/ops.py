@@ -507,6 +507,66 @@ class _Upsample(Function):
         return dx
 
 
+_UPFUSE = os.environ.get("FI_UPFUSE", "1") != "0"              # measurement switch: 0 = conv1x1 and up-sampling as two launches
+
+
+class _ConvUp(Function):
+    """u = Upsample2x(conv1x1(x) + bias): UpBlock's first half (unet.py:57-59,65-67) as ONE forward launch
+    (fi_conv1x1_up2x_fwd: the low-resolution convolution output lives in LDS only).  Backward is the two ops' own:
+    fi_upsample2x_bwd, then the 1x1 convolution's input / filter gradients."""
+
+    @staticmethod
+    def forward(ctx, x0, weight, bias, mod):
+        wk = _krsc(weight)
+        cout, cin = wk.shape[0], wk.shape[3]
+        N, h, w, _ = x0.shape
+        wp = _packed(wk, x0.dtype, 0, cout, 1, cin, param=weight)
+        u = torch.empty((N, 2 * h, 2 * w, cout), dtype=x0.dtype, device=x0.device)
+        if not (_UPFUSE and x0.dtype != torch.float32 and L.conv1x1_up2x_fwd(x0, None, wp, bias, u)):
+            y = torch.empty((N, h, w, cout), dtype=x0.dtype, device=x0.device)
+            L.conv2d_fwd(x0, None, wp, bias, y, None, None, ksize=1)
+            L.upsample2x_fwd(y, u)
+        ctx.save_for_backward(x0, wk)
+        ctx.mod, ctx.ksize = mod, 1
+        ctx.need_x0, ctx.need_x1 = ctx.needs_input_grad[0], False
+        ctx.need_w = ctx.needs_input_grad[1]
+        ctx.need_b = bias is not None and ctx.needs_input_grad[2]
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        x0, wk = ctx.saved_tensors
+        N, h, w, _ = x0.shape
+        dy = torch.empty((N, h, w, wk.shape[0]), dtype=du.dtype, device=du.device)
+        L.upsample2x_bwd(du.contiguous(), dy)
+        if dy.dtype != x0.dtype:
+            t = torch.empty(dy.shape, dtype=x0.dtype, device=dy.device)
+            L.cast(dy, t)
+            dy = t
+        dx0, _, gw, gb = _conv_backward(ctx, dy, x0, None, wk, ctx.mod)
+        return dx0, gw, gb, None
+
+
+def conv1x1_up(x, mod):
+    """UpBlock.up(UpBlock.conv1x1(x)) (bilinear decoder)."""
+    return _ConvUp.apply(x, mod.weight, mod.bias, mod)
+
+
+def probe_conv_up(s0, conv, groups):
+    """The same in the batched no-grad forward, of a possibly raw source."""
+    r0 = s0 if isinstance(s0, RawAct) else None
+    x = r0.y if r0 is not None else s0
+    wk = _krsc(conv.weight)
+    cout, cin = wk.shape[0], wk.shape[3]
+    N, h, w, _ = x.shape
+    if _UPFUSE and x.dtype != torch.float32 and not (r0 is not None and r0.shared):
+        u = torch.empty((N, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
+        t0 = None if r0 is None else L.in_xform(r0.coef, r0.slope)
+        if L.conv1x1_up2x_fwd(x, t0, _packed(wk, x.dtype, 0, cout, 1, cin, param=conv.weight), conv.bias, u, groups=groups):
+            return u
+    return upsample2x(probe_conv(s0, conv, groups))
+
+
 class _CELoss(Function):
     """CrossEntropyLoss(ignore_index) on fp32 NHWC logits [N,H,W,C]; labels uint8 [N,H,W]."""
 

@@ -309,6 +309,17 @@ int fi_maxpool2_bwd_add(int dtype, const void* x, const void* dy, const void* ad
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet.py:58-59): [N,h,w,C]->[N,2h,2w,C] */
 int fi_upsample2x_fwd(int dtype, const void* x, void* y, int N, int h, int w, int C, void* stream);
 int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, int C, int accumulate, void* stream);
+/* UpBlock's first half as ONE launch (csrc/upfuse.hip; /root/reference/code/networks/unet.py:57-59,65-67: self.conv1x1 then
+ * self.up): y [N,2h,2w,cout] = fi_upsample2x_fwd(conv1x1(z) + bias), z = x [N,h,w,cin] as it is (t0 == NULL or t0->scale == NULL) or
+ * act(BN(x)) per statistics group as in fi_conv2d_fwd_fused (no pool / dropout).  The low-resolution convolution output is
+ * rounded to the storage type as the separate launch stores it, but lives in LDS only; the interpolation is
+ * fi_upsample2x_fwd's, operand for operand.  wmat = the forward operand [cout][cin] (fi_pack_weights mode 0), bias may be NULL.
+ * 16-bit storage and (cin, cout) in {(32,16), (64,32), (128,64), (256,128), (32,32), (64,64)}; FI_ERR_UNSUPPORTED otherwise
+ * (the caller makes the two launches).  Backward: fi_upsample2x_bwd, then the 1x1 convolution's own. */
+int fi_conv1x1_up2x_fwd(int dtype, int N, int h, int w, int cin, int cout, const FiInXform* t0, int group_images, const void* x,
+                        const void* wmat, const float* bias, void* y, void* stream);
+/* Measurement / test hook: input rows convolved per workgroup of fi_conv1x1_up2x_fwd (2 * rows output rows; 0 = the per-shape default: 3, or 6 for the 256 -> 128 level). */
+int fi_upfuse_tuning(int rows);
 
 /* 3D surface (unet_3D, /root/reference/code/networks/unet_3D.py:20-94): volumes are dense NDHWC, i.e. D consecutive NHWC
  * slices -- Conv3d and InstanceNorm3d are run slice-wise through fi_conv2d_* / fi_bn_* by the host mirror.
