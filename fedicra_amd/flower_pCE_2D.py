@@ -63,6 +63,9 @@ class MyClient(BaseClient):
         self._xbuf = self._ybuf = None
         self.last_losses = []
         self.probe_beside = _PROBE_BESIDE                    # the LC forwards on a second stream beside the own forward
+        # ... and their decoder half (BatchNorm statistics only: nothing the iteration reads) on beside the loss and the backward
+        # pass, joined before the optimizer step (measurement switch: 0 = joined before the LC loss, as in round 3)
+        self.probe_tail_beside = os.environ.get("FEDICRA_PROBE_TAIL", "1") != "0"
         self.aux_stats_only = os.environ.get("FEDICRA_AUX_STATS", "1") != "0"   # (measurement switch: 0 = the heads in full)
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
@@ -145,7 +148,7 @@ class MyClient(BaseClient):
         opt = self.optimizer
         ops.begin_iteration(x.device)
         opt.zero_grad()
-        batched, probe_stream = None, None
+        batched, probe_stream, probe_tail, enc_done = None, None, None, None
         others = [c for c in range(args.min_num_clients) if c != args.cid]
         net = self.model.model
         side = (self.probe_beside and args.strategy in ["FedICRA"] and hasattr(net, "probe_heatmaps") and x.is_cuda
@@ -170,8 +173,9 @@ class MyClient(BaseClient):
             out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
             if side:
                 probe_stream.wait_event(fork)
+                enc_done = torch.cuda.Event() if self.probe_tail_beside else None
                 with torch.cuda.stream(probe_stream), torch.no_grad():
-                    batched = net.probe_heatmaps(x, others)
+                    batched = net.probe_heatmaps(x, others, enc_done=enc_done)
                 if batched is None:
                     # the batched form does not apply to this model (probe_heatmaps' own preconditions): the second stream
                     # has already been forked into the capture by wait_event(fork) -- JOIN it before dropping it, a capture
@@ -188,7 +192,14 @@ class MyClient(BaseClient):
             heatmaps = out[6]
             acc = 0
             if probe_stream is not None:
-                torch.cuda.current_stream().wait_stream(probe_stream)
+                if enc_done is not None:
+                    # the heat-maps are complete once the probe's ENCODER is (the LC loss reads nothing else); its decoder only
+                    # moves BatchNorm statistics and keeps running beside the loss and the backward pass -- joined before the
+                    # optimizer touches the weights it reads
+                    torch.cuda.current_stream().wait_event(enc_done)
+                    probe_tail = probe_stream
+                else:
+                    torch.cuda.current_stream().wait_stream(probe_stream)
             else:
                 with torch.no_grad():                                                # all K-1 forwards as one batch
                     batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
@@ -213,10 +224,14 @@ class MyClient(BaseClient):
                 loss = torch.add(loss, loss_lc, alpha=args.alpha)
         if self.amp:                                         # :143-146
             self.scaler.scale(loss).backward()
+            if probe_tail is not None:
+                torch.cuda.current_stream().wait_stream(probe_tail)
             self.scaler.step(opt)
             self.scaler.update()
         else:
             loss.backward()
+            if probe_tail is not None:
+                torch.cuda.current_stream().wait_stream(probe_tail)
             opt.step()
         opt.advance_lr()
         rec.loss, rec.loss_ce, rec.loss_lc, rec.logits = loss.detach(), loss_ce.detach(), \

@@ -490,7 +490,7 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         return [out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + [out(t) for t in o[5:]]
 
 
-    def probe_heatmaps(self, x, emb_ids):
+    def probe_heatmaps(self, x, emb_ids, enc_done=None):
         """The heat-maps ``self(x, e)[6][-1]`` for every e in emb_ids -- FedICRA's LC loss asks for them once per OTHER client
         in every iteration (flower_pCE_2D.py:128-139: no-grad, train mode) -- from ONE batched pass: the K-1 forwards run
         as statistics groups of the same launches (fi_conv2d_fwd_fused / fi_bn_finalize_groups), the activations between
@@ -511,8 +511,13 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         xin = self._in(x)
         G, B = len(emb_ids), xin.shape[0]
         skips, x4, h = enc._probe(xin, list(emb_ids))
+        maps = [self._out(h[g * B:(g + 1) * B]) for g in range(G)]
+        if enc_done is not None:
+            # everything the CALLER reads exists now; what follows only moves the decoder's BatchNorm statistics -- a caller that
+            # runs this on a side stream may wait for this event instead of the whole stream (flower_pCE_2D._iteration)
+            enc_done.record()
         dec._probe(skips, x4, G)
-        return [self._out(h[g * B:(g + 1) * B]) for g in range(G)]
+        return maps
 
 
 class UNet_LC(_UNetLCBase):

@@ -153,3 +153,38 @@ def test_probe_path_moves_the_same_statistics():
     for a, b in zip(h0, h1):
         assert torch.equal(a, b)                       # the heat-maps come out of the encoder: untouched by the decoder's form
     assert torch.allclose(s0, s1, rtol=5e-3, atol=1e-3), float((s0 - s1).abs().max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_probe_decoder_beside_the_backward_pass_leaves_the_same_state(use_graph):
+    """The LC forwards' decoder half only moves BatchNorm statistics; flower_pCE_2D._iteration lets it run on beside the LC loss
+    and the backward pass and joins it before the optimizer step.  Against the join before the LC loss: the same losses, the
+    same parameters / running statistics / counters after two rounds of head- and body-phase iterations, eager and captured."""
+    import argparse
+    import numpy as np
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks import net_factory
+    from helpers import loader
+    res = []
+    for tail in (False, True):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=4, num_classes=2,
+                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=5, rep_iters=2, alpha=1.0,
+                                  snapshot_path=None, use_graph=use_graph)
+        torch.manual_seed(2022)
+        ops.manual_seed(11)
+        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
+        batches = loader(3, 4, 64, cid=1, device=DEV)
+        client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
+        assert client.probe_beside
+        client.probe_tail_beside = tail
+        cfg = {"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
+        client._train(cfg)
+        client._train(cfg)
+        torch.cuda.synchronize()
+        res.append((list(client.last_losses), net.flat_state.clone(), net.flat_counters.clone()))
+    (l0, s0, c0), (l1, s1, c1) = res
+    assert torch.equal(c0, c1)
+    assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=2e-5), float((s0 - s1).abs().max())
