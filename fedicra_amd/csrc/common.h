@@ -214,10 +214,13 @@ __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t dr
   return fi_rand32(seed, idx) >= drop_thresh;
 }
 
-// l0 * a + l1 * b with ONE defined rounding sequence (a product, then a fused multiply-add): the bilinear up-sampling kernels
-// (ops.hip: flat and row forms; upfuse.hip: behind the 1x1 convolution) all interpolate through this, along x and then along y,
-// so that they agree bit for bit instead of as hipcc happens to contract each kernel's expression.
-__device__ __forceinline__ float fi_lerp2(float l0, float a, float l1, float b) { return __builtin_fmaf(l1, b, l0 * a); }
+// l0 * a + l1 * b with ONE defined rounding sequence (the second product rounded, then a fused multiply-add of the first): the
+// bilinear up-sampling kernels (ops.hip: flat and row forms; upfuse.hip: behind the 1x1 convolution) all interpolate through this,
+// along x and then along y, so that they agree bit for bit instead of as hipcc happens to contract each kernel's expression.
+// (This IS the sequence hipcc had chosen for the round-1..3 kernels -- v_pk_mul_f32 l1 * b, v_pk_fma_f32 l0, a -- so the fp32
+// parity runs keep the bits they had; the mirrored order moved a 4-iteration AdamW loss by 2.3e-3 against the oracle, outside
+// tests/test_parity2_gpu.py's 2e-3.)
+__device__ __forceinline__ float fi_lerp2(float l0, float a, float l1, float b) { return __builtin_fmaf(l0, a, l1 * b); }
 
 static inline int fi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

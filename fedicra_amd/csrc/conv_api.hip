@@ -15,6 +15,8 @@ int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hip
 int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows3d_f16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows_narrow_bf16(int narrow, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows64_bf16(int tco, int tci, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows64_f16(int tco, int tci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows_narrow_f16(int narrow, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k1(int th, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_quad_f32_k3(int th, const WgradArgs& a, hipStream_t st);
@@ -456,12 +458,18 @@ struct WgradPlan {
   int rows;             // 1: the row-streaming kernel (wgrad_rows.h) when the caller gives a workspace: sb_rows items, one slice each
   int ws, strips, rpw, chunks, sb_rows;
   int narrow;           // rows == 1: 1 = <= 4 input channels, 2 = <= 4 gradient channels (conv_wgrad_rows_kernel<NARROW>), the other side 16
+  int tco, tci, nct, nit;   // rows == 3 (conv_wgrad_rows64_kernel): channel tile in 16-channel blocks, tiles per side
 };
-// FI_WGRAD_ROWS (default 1) / fi_wgrad_tuning: the row-streaming kernel on the thin 3x3 layers it covers
+// FI_WGRAD_ROWS (default 1) / fi_wgrad_tuning bit 0: the row-streaming kernel on the thin 3x3 layers it covers;
+// FI_WGRAD_ROWS64 (default 1) / bit 1: its 64 x 64-channel-tile form on the channel-rich 3x3 layers
 static long g_wgrad_rows = -1;
 static bool wgrad_rows_on() {
   static long v = env_long("FI_WGRAD_ROWS", 1);
-  return (g_wgrad_rows >= 0 ? g_wgrad_rows : v) != 0;
+  return g_wgrad_rows >= 0 ? (g_wgrad_rows & 1) != 0 : v != 0;
+}
+static bool wgrad_rows64_on() {
+  static long v = env_long("FI_WGRAD_ROWS64", 1);
+  return g_wgrad_rows >= 0 ? (g_wgrad_rows & 2) != 0 : v != 0;
 }
 extern "C" int fi_wgrad_tuning(int rows) {
   g_wgrad_rows = rows;
@@ -512,6 +520,35 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     const long items_target = items_env > 0 ? items_env : ((cin == 16 || p->narrow) ? 768 : 384);
     long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
     if (rpw < minr) rpw = minr;
+    if (rpw > d->H) rpw = d->H;
+    p->rpw = (int)rpw;
+    p->chunks = fi_cdiv(d->H, p->rpw);
+    p->sb_rows = d->N * p->strips * p->chunks;
+  }
+  // channel-rich 3x3 layers on 64 ... 256-wide maps: the same streaming with 64 x 64 (64 x 32 / 32 x 64) channel tiles.  Workgroups
+  // = items x channel tiles; every ITEM costs one |dw| slice of workspace traffic, so the run length follows the tile count
+  // (FI_WGRAD_ROWS64_WGS workgroups in all, a run of at least 8 rows)
+  if (wgrad_rows64_on() && depth == 0 && p->quad && !p->rows && d->dtype != FI_F32 && d->ksize == 3 && cout % 32 == 0 && cin % 32 == 0 &&
+      (cout % 64 == 0 || cin % 64 == 0) && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->W % 32 == 0 && d->W >= 64 &&
+      (d->W <= 128 || d->W % 128 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 15)) {
+    static const long wgs_env = env_long("FI_WGRAD_ROWS64_WGS", 320), tile_env = env_long("FI_WGRAD_ROWS64_TILE", 0);
+    // tile (gradient x input side, 16-channel blocks): 32 x 64 wherever the input side allows it, else 64 x 32 -- 216 / 228 registers,
+    // two workgroups per CU.  The 64 x 64 tile (348 registers: ONE wave per SIMD, nothing hides its LDS latency) measured level on
+    // one-tile layers and behind on the others (profiles/r04_wgbench_rows64.txt: 128^2 128 -> 64 68 us against 55, 64^2 128 -> 128
+    // 49 against 40); FI_WGRAD_ROWS64_TILE=44 keeps it for measurements
+    p->tci = cin % 64 == 0 ? 4 : 2;
+    p->tco = p->tci == 4 ? 2 : 4;
+    if (tile_env == 44 && cout % 64 == 0 && cin % 64 == 0) p->tco = p->tci = 4;
+    if (tile_env == 42 && cout % 64 == 0) p->tco = 4, p->tci = 2;
+    p->rows = 3;
+    p->nct = cout / (p->tco * 16);
+    p->nit = cin / (p->tci * 16);
+    p->ws = d->W <= 128 ? d->W : 128;
+    p->strips = d->W / p->ws;
+    long items_target = wgs_env / ((long)p->nct * p->nit);
+    if (items_target < (long)d->N * p->strips) items_target = (long)d->N * p->strips;
+    long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
+    if (rpw < 8) rpw = 8;
     if (rpw > d->H) rpw = d->H;
     p->rpw = (int)rpw;
     p->chunks = fi_cdiv(d->H, p->rpw);
@@ -667,7 +704,10 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
     ra.want_bias = dbias != nullptr;
     ra.depth = depth;
     ra.cd = cout;
-    if (p.rows == 1 && p.narrow)
+    ra.cout = cout, ra.nct = p.nct, ra.nit = p.nit;
+    if (p.rows == 3)
+      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows64_f16(p.tco, p.tci, ra, p.sb, st) : fi_conv_wgrad_rows64_bf16(p.tco, p.tci, ra, p.sb, st);
+    else if (p.rows == 1 && p.narrow)
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_narrow_f16(p.narrow, ra, p.sb, st) : fi_conv_wgrad_rows_narrow_bf16(p.narrow, ra, p.sb, st);
     else if (p.rows == 2)
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows3d_f16((d->c0 + d->c1) / 16, ra, p.sb, st)

@@ -31,6 +31,7 @@ struct WgRowsArgs {
   int want_bias;
   int depth;               // conv_wgrad_rows3d_kernel: slices per volume (an "image" is a slice)
   int cd;                  // NARROW == 2: channels of the gradient tensor (<= 4); NARROW == 1: c0 <= 4 is the input's, c1 = 0
+  int cout, nct, nit;      // conv_wgrad_rows64_kernel: gradient channels, gradient / input channel tiles per item
 };
 
 template <typename T>
@@ -474,6 +475,207 @@ static int launch_conv_wgrad_rows3d(const WgRowsArgs& a, int items, hipStream_t 
   const size_t red = (size_t)(27 * NCI * 256 + 16) * sizeof(float);
   if (lds < red) lds = red;
   hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)items), dim3(256), lds, st, a);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same scheme for the CHANNEL-RICH 3x3 layers (32 ... 256 channels a side on 64^2 ... 256^2 maps: the decoder and the deep
+// encoder levels).  The 16 x 16-quadrant tile kernel (conv_wgrad_quad_kernel) spends 3.5-7 us per 256-pixel tile of which its 72
+// MFMAs are 0.5: a fresh 1 KB fragment per MFMA and wave is 256 B/clk of LDS reads against the 128 the LDS delivers, every tile
+// costs two barriers and a global round trip, and a 32 x 32 channel tile re-reads each tensor Cout / 32 (Cin / 32) times.  Here a
+// workgroup owns a 64 x 64 (or 32 x 64 / 64 x 32) channel tile of an item (a run of x rows of one image strip, as above): per
+// 32-pixel K step a wave reads 3 x OB gradient and 3 x IB input operands for 9 x OB x IB MFMAs -- (2, 2) blocks per wave: a third of
+// a fragment per MFMA, 85 B/clk for the four waves at the matrix pipe's full rate -- rows arrive as contiguous segments through
+// the same two register stages and LDS ring with ONE barrier per row, and every wave owns its channel blocks for the whole run: no
+// cross-wave sum, accumulators (9 x OB x IB x 4 registers = 144 for the 64 x 64 tile) go straight to the item's partial slice in
+// conv_wgrad_kernel's layout.  An item's channel tiles sit next to each other in the launch order of ONE XCD, so the rows they
+// share come out of that XCD's L2.
+template <typename T, int TCO, int TCI, int MAXW>
+__global__ __launch_bounds__(256) void conv_wgrad_rows64_kernel(WgRowsArgs a) {
+  typedef typename DT<T>::frag_t frag_t;
+  constexpr int WO = (TCO == 4 && TCI == 4) ? 2 : (TCO == 4 ? 4 : 1), WI = 4 / WO;     // wave grid over the channel tile
+  constexpr int OB = TCO / WO, IB = TCI / WI;                                          // 16-channel blocks per wave
+  static_assert(OB >= 1 && IB >= 1 && OB * WO == TCO && IB * WI == TCI, "tile / wave grid");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wo = wave / WI, wi = wave % WI;
+  const int H = a.H, W = a.W, ws = a.ws;
+  const int xplane = (ws + 2) * 32, dplane = ws * 32;
+  const int xrow = TCI * xplane, drow = TCO * dplane;
+  char* const xs = smem;                        // [2][TCI][ws + 2][16]
+  char* const ds = smem + 2 * xrow;             // [4][TCO][ws][16]
+  // workgroup -> (item, gradient tile, input tile): an XCD (blockIdx % 8) takes a contiguous run of the logical order
+  const int ntiles = a.nct * a.nit;
+  const int total = a.N * a.strips * a.chunks * ntiles, per_xcd = (total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= total) return;
+  const int tile = logical % ntiles;
+  int item = logical / ntiles;
+  const int slice_idx = item;
+  const int cit = tile % a.nit, cot = tile / a.nit;
+  const int chunk = item % a.chunks;
+  item /= a.chunks;
+  const int strip = item % a.strips, n = item / a.strips;
+  const int r0 = chunk * a.rpw, r1 = min(r0 + a.rpw, H);
+  const int cs = strip * ws;
+  const int cin = a.c0 + a.c1, cout = a.cout;
+  const int cib = cit * TCI * 16, cob = cot * TCO * 16;
+  const T* const x0 = reinterpret_cast<const T*>(a.x0) + (size_t)n * H * W * a.c0;
+  const T* const x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * H * W * a.c1;
+  const T* const dyg = reinterpret_cast<const T*>(a.dy) + (size_t)n * H * W * cout + cob;
+
+  constexpr int NXV = ((MAXW + 2) * 2 * TCI + 255) / 256, NDV = (MAXW * 2 * TCO + 255) / 256;
+  const int nxv = (ws + 2) * 2 * TCI, ndv = ws * 2 * TCO;
+  uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];
+  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
+    const bool rowok = rho >= 0 && rho < H;
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * TCI), px = i / (2 * TCI);
+      const int gx = cs + px - 1, ch = cib + v * 8;
+      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
+      const bool first = ch < a.c0;
+      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
+                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
+      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+    }
+  };
+  auto load_d = [&](uint4 (&dr)[NDV], int r) {
+    const bool rowok = r >= 0 && r < H;
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * TCO), px = i / (2 * TCO);
+      const bool ok = rowok && i < ndv;
+      const T* src = dyg + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * cout + v * 8;
+      dr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+    }
+  };
+  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * TCI), px = i / (2 * TCI);
+      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
+    }
+  };
+  auto store_d = [&](const uint4 (&dr)[NDV], int slot) {
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * TCO), px = i / (2 * TCO);
+      if (i < ndv) *reinterpret_cast<uint4*>(ds + slot * drow + (v >> 1) * dplane + px * 32 + (v & 1) * 16) = dr[it];
+    }
+  };
+
+  f32x4 acc[3][3][OB][IB];
+  f32x4 accb[OB];
+#pragma unroll
+  for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int i = 0; i < IB; ++i) acc[kr][kc][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < OB; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const frag_t onesv = WgFrag<T>::ones();
+  const bool bias_wave = a.want_bias && cit == 0 && wi == 0;
+
+  const int g = lane >> 4, li = lane & 15;
+  const int laneoff = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
+
+  load_x(xrA, r0);
+  load_d(drA, r0 - 1);
+  load_d(drB, r0);
+  store_x(xrA, r0 & 1);
+  store_d(drA, (r0 - 1) & 3);
+  load_d(drA, r0 + 1);
+  store_d(drB, r0 & 3);
+  store_d(drA, (r0 + 1) & 3);
+  load_x(xrA, r0 + 1);
+  load_d(drA, r0 + 2);
+  load_x(xrB, r0 + 2);
+  load_d(drB, r0 + 3);
+  __syncthreads();
+
+  const int nks = ws / 32;
+  auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[NDV]) __attribute__((always_inline)) {
+    store_x(xr, (rho + 1) & 1);
+    store_d(dr, (rho + 2) & 3);
+    load_x(xr, rho + 3);
+    load_d(dr, rho + 4);
+    const char* const xb = xs + (rho & 1) * xrow + wi * IB * xplane + laneoff;
+    const char* db[3];
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr) db[kr] = ds + ((rho - kr + 1) & 3) * drow + wo * OB * dplane + laneoff;
+    for (int ks = 0; ks < nks; ++ks) {
+      frag_t av[3][OB], bv[3][IB];
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) av[kr][o] = wgr_frag<T>(db[kr] + o * dplane + ks * 32 * 32);
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+        for (int i = 0; i < IB; ++i) bv[kc][i] = wgr_frag<T>(xb + i * xplane + (ks * 32 + kc) * 32);
+      if (bias_wave) {
+#pragma unroll
+        for (int o = 0; o < OB; ++o) accb[o] = mfma16(av[1][o], onesv, accb[o]);
+      }
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+          for (int o = 0; o < OB; ++o)
+#pragma unroll
+            for (int i = 0; i < IB; ++i) acc[kr][kc][o][i] = mfma16(av[kr][o], bv[kc][i], acc[kr][kc][o][i]);
+    }
+    fi_lds_barrier();
+  };
+  for (int rho = r0; rho < r1; rho += 2) {
+    step(rho, xrA, drA);
+    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+  }
+
+  // ---- this wave's blocks of the item's slice: slice[(co * 9 + t) * cin + ci], D[row = co = g * 4 + r][col = ci = li]
+  float* const slice = a.part + (size_t)slice_idx * a.part_stride;
+#pragma unroll
+  for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+          const int gci = cib + (wi * IB + i) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gco = cob + (wo * OB + o) * 16 + g * 4 + r;
+            slice[((size_t)gco * 9 + kr * 3 + kc) * cin + gci] = acc[kr][kc][o][i][r];
+          }
+        }
+  if (bias_wave && li == 0) {
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slice[(size_t)cout * 9 * cin + cob + (wo * OB + o) * 16 + g * 4 + r] = accb[o][r];
+  }
+}
+
+template <typename T, int TCO, int TCI>
+static int launch_conv_wgrad_rows64(const WgRowsArgs& a, int items, hipStream_t st) {
+  const size_t lds = (size_t)2 * TCI * (a.ws + 2) * 32 + (size_t)4 * TCO * a.ws * 32;
+  const void* kern = reinterpret_cast<const void*>(&conv_wgrad_rows64_kernel<T, TCO, TCI, 128>);
+  static bool allowed = fi_allow_big_lds(kern);
+  if (!allowed || lds > 160 * 1024 || a.ws > 128) return FI_ERR_UNSUPPORTED;
+  const long total = (long)items * a.nct * a.nit;
+  hipLaunchKernelGGL((conv_wgrad_rows64_kernel<T, TCO, TCI, 128>), dim3((unsigned)(((total + 7) / 8) * 8)), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -23,3 +23,11 @@ int fi_conv_wgrad_rows_narrow_bf16(int narrow, const WgRowsArgs& a, int items, h
   if (narrow == 2) return launch_conv_wgrad_rows<bf16_t, 1, 1, 2>(a, items, st);
   return FI_ERR_UNSUPPORTED;
 }
+
+// channel-rich layers: (gradient, input) channel tile in 16-channel blocks -- (4, 4), (2, 4), (4, 2)
+int fi_conv_wgrad_rows64_bf16(int tco, int tci, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (tco == 4 && tci == 4) return launch_conv_wgrad_rows64<bf16_t, 4, 4>(a, items, st);
+  if (tco == 2 && tci == 4) return launch_conv_wgrad_rows64<bf16_t, 2, 4>(a, items, st);
+  if (tco == 4 && tci == 2) return launch_conv_wgrad_rows64<bf16_t, 4, 2>(a, items, st);
+  return FI_ERR_UNSUPPORTED;
+}

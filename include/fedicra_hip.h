@@ -204,9 +204,10 @@ int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1
 int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
                             void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
 int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, void* stream);
-/* Measurement / test hook: rows = 0 keeps every filter gradient on the tile kernels, 1 lets the thin 3x3 layers on large maps
- * (16 / 32 channels a side, 16-bit storage, W % 32 == 0, a workspace given) take the row-streaming kernel (csrc/wgrad_rows.h),
- * -1 = the FI_WGRAD_ROWS environment default (1). */
+/* Measurement / test hook (a bit mask): rows = 0 keeps every filter gradient on the tile kernels, bit 0 lets the thin 3x3 layers on
+ * large maps (16 / 32 channels a side, 16-bit storage, W % 32 == 0, a workspace given) take the row-streaming kernel
+ * (csrc/wgrad_rows.h), bit 1 the channel-rich 3x3 layers (32 ... 256 channels a side, one side a multiple of 64, 64 <= W, W <= 128
+ * or W % 128 == 0) its 64 x 64-channel-tile form; -1 = the FI_WGRAD_ROWS / FI_WGRAD_ROWS64 environment defaults (1 / 1). */
 int fi_wgrad_tuning(int rows);
 /* Measurement / test hook (a bit mask; 7 = all forms): on = 0 keeps the layers with a <= 4-channel side (the U-Nets' first convolution in_chns -> 16,
  * /root/reference/code/networks/unet.py:82,163, and their logits convolution 16 -> n_class, :228) on the general tile kernels;

@@ -255,6 +255,49 @@ def test_trained_dice_of_five_seeds_lies_inside_the_references_own_spread(golden
 
 
 # ------------------------------------------------------------------------------------------------ row-streaming thin-layer wgrad
+# ------------------------------------------------------------------------------------------------ row-streaming channel-rich wgrad
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(12, 64, 64, 128, 0, 128), (8, 64, 64, 128, 128, 128), (3, 128, 128, 64, 64, 64), (2, 128, 128, 64, 0, 64),
+                                   (2, 256, 256, 32, 32, 32), (2, 128, 128, 32, 0, 64), (1, 250, 256, 64, 0, 64), (8, 72, 64, 64, 0, 128),
+                                   (6, 64, 96, 24, 40, 64), (8, 64, 64, 256, 0, 256)])
+def test_row_streaming_channel_rich_wgrad_against_fp64_and_the_tile_kernels(shape, dtype, monkeypatch):
+    """conv_wgrad_rows64_kernel (csrc/wgrad_rows.h: 64 x 64 / 32 x 64 / 64 x 32 channel tiles of a run of image rows, every wave its
+    own channel blocks) against an fp64 convolution backward of the same rounded operands and the quadrant tile kernel it
+    replaces (fi_wgrad_tuning(0)): several tiles a side, a second source that splits a channel tile, two strips per row, ragged
+    runs, 96-wide rows; weight and bias gradients."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    N, H, W, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(H + c1 + cout)
+    x0 = torch.randn(N, H, W, c0, generator=g).to(dtype).to(DEV)
+    x1 = torch.randn(N, H, W, c1, generator=g).to(dtype).to(DEV) if c1 else None
+    dy = (torch.randn(N, H, W, cout, generator=g) * 0.1).to(dtype).to(DEV)
+    cin = c0 + c1
+    res = []
+    try:
+        for rows in (2, 0):
+            L.lib().fi_wgrad_tuning(rows)
+            dw = torch.zeros(cout, 3, 3, cin, device=DEV)
+            db = torch.zeros(cout, device=DEV)
+            L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=3)
+            res.append((dw.double().cpu(), db.double().cpu()))
+    finally:
+        L.lib().fi_wgrad_tuning(-1)
+    x = x0 if x1 is None else torch.cat([x0, x1], 3)
+    xd = x.double().permute(0, 3, 1, 2)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(xd, wref, torch.zeros(cout, dtype=torch.float64, device=DEV), padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    want = wref.grad.permute(0, 2, 3, 1).cpu()
+    want_b = dy.double().sum((0, 1, 2)).cpu()
+    scale = want.abs().max().item()
+    e_new = (res[0][0] - want).abs().max().item() / scale
+    e_old = (res[1][0] - want).abs().max().item() / scale
+    assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)
+    assert (res[0][1] - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
+    assert (res[0][0] - res[1][0]).abs().max().item() / scale < 2e-5
+    assert not torch.equal(res[0][0], res[1][0])               # another summation order: the row-streaming kernel really ran
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 256, 256, 16, 0, 16), (1, 512, 512, 16, 16, 16), (3, 250, 512, 32, 0, 16),
                                    (2, 264, 256, 16, 0, 32), (4, 256, 128, 16, 16, 32), (1, 1024, 256, 16, 0, 16)])

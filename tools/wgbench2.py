@@ -25,15 +25,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--reps", type=int, default=6)
-    ap.add_argument("--rows", type=int, default=-1, help="fi_wgrad_tuning: 0 = tile kernels only, 1 = row-streaming kernel where it applies")
+    ap.add_argument("--rows", type=int, default=-1, help="fi_wgrad_tuning bit mask: 0 = tile kernels only, 1 = row-streaming kernel on the thin layers, "
+                    "2 = its 64 x 64-channel-tile form on the channel-rich layers, -1 = the environment defaults")
+    ap.add_argument("--full", type=int, default=0, help="1: time fi_conv2d_wgrad (stage 1 + the single-tensor reduce) instead of stage 1 alone")
+    ap.add_argument("--min-c", type=int, default=0, help="only layers with at least this many channels on both sides")
     a = ap.parse_args()
     L.lib().fi_wgrad_tuning(a.rows)
     tot = ideal = 0.0
     for h, c0, c1, cout, ks, calls in LAYERS:
+        if min(c0 + c1, cout) < a.min_c:
+            continue
         x0 = torch.randn(a.batch, h, h, c0, device="cuda").to(torch.bfloat16)
         x1 = torch.randn(a.batch, h, h, c1, device="cuda").to(torch.bfloat16) if c1 else None
         dy = torch.randn(a.batch, h, h, cout, device="cuda").to(torch.bfloat16)
-        us = timeit(lambda: L.conv2d_wgrad_partial(x0, x1, dy, True, ksize=ks), a.reps)
+        if a.full:
+            dw = torch.zeros(cout, ks, ks, c0 + c1, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            us = timeit(lambda: L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=ks), a.reps)
+        else:
+            us = timeit(lambda: L.conv2d_wgrad_partial(x0, x1, dy, True, ksize=ks), a.reps)
         gf = 2.0 * a.batch * h * h * (c0 + c1) * cout * ks * ks / 1e9
         by = a.batch * h * h * (c0 + c1 + cout) * 2.0
         idl = max(gf * 1e9 / 2.5e15, by / 8e12) * 1e6
@@ -41,7 +51,8 @@ def main():
         ideal += idl * calls
         print(f"{a.batch} x {h:3d}^2 {c0 + c1:3d}->{cout:3d} k{ks}: {us:8.1f} us  ideal {idl:6.1f}  frac {idl / us:5.2f}  x{calls}")
     print(f"TOTAL {tot:.0f} us per iteration, ideal {ideal:.0f}, frac {ideal / tot:.3f}  "
-          f"(FI_WGRAD_BLOCKS={os.environ.get('FI_WGRAD_BLOCKS', '512')} THIN={os.environ.get('FI_WGRAD_BLOCKS_THIN', '-')} rows={a.rows})")
+          f"(FI_WGRAD_BLOCKS={os.environ.get('FI_WGRAD_BLOCKS', '512')} THIN={os.environ.get('FI_WGRAD_BLOCKS_THIN', '-')} rows={a.rows} full={a.full} "
+          f"ROWS64_WGS={os.environ.get('FI_WGRAD_ROWS64_WGS', '-')} TILE={os.environ.get('FI_WGRAD_ROWS64_TILE', '-')})")
 
 
 main()
