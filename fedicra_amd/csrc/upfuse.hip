@@ -263,14 +263,15 @@ int launch(const UpFuseArgs& a0, hipStream_t st) {
   auto lds_bytes = [&](int R) {
     return (long)(R + 2) * a.w * COUT * 2 + (long)COUT * (CIN * 2 + 16) + 2L * CIN * 4 + COUT * 4 + 2L * R * 16;
   };
-  // rows per workgroup (tools/upfbench.py, profiles/r04_upfbench.txt): 3 wherever the filter is small -- 40 KB of LDS, three
-  // workgroups per CU, one of them always storing (84 x 256^2 32 -> 16: 206 us against 216 at 6; 12 images: 35 against 40) --
-  // and 6 for the 256 -> 128 level (its 68 KB filter allows one workgroup per CU either way: 52 against 65 us) unless that
+  // rows per workgroup (tools/upfbench.py, profiles/r04_upfbench.txt): 3 on the two wide levels -- 40 KB of LDS, three workgroups
+  // per CU, one of them always storing (84 x 256^2 32 -> 16: 206 us against 216 at 6; 12 images: 35 against 40) -- and 6 from 128
+  // input channels on, where phase 1 is the heavier half and the two halo rows cost more than the occupancy buys (64^2 128 -> 64:
+  // 71 us against 76-82; 32^2 256 -> 128, one workgroup per CU beside its 68 KB filter either way: 52 against 65), unless that
   // leaves CUs without a workgroup
-  const bool bigw = (long)COUT * (CIN * 2 + 16) > 32 * 1024;
-  int R = g_rows > 0 ? g_rows : (bigw && (long)a.N * ((a.h + 5) / 6) >= 256 ? 6 : 3);
+  const bool deep = CIN >= 128;
+  int R = g_rows > 0 ? g_rows : (deep && (long)a.N * ((a.h + 5) / 6) >= 256 ? 6 : 3);
   if (R > a.h) R = a.h;
-  const long budget = bigw ? 156 * 1024 : 78 * 1024;
+  const long budget = deep ? 156 * 1024 : 78 * 1024;
   while (R > 1 && lds_bytes(R) > budget) --R;
   if (lds_bytes(R) > budget) return FI_ERR_UNSUPPORTED;
   if (2 * R > 256) return FI_ERR_UNSUPPORTED;            // the row table is filled by one thread per output row

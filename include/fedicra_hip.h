@@ -319,7 +319,7 @@ int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int h, int w, 
  * (the caller makes the two launches).  Backward: fi_upsample2x_bwd, then the 1x1 convolution's own. */
 int fi_conv1x1_up2x_fwd(int dtype, int N, int h, int w, int cin, int cout, const FiInXform* t0, int group_images, const void* x,
                         const void* wmat, const float* bias, void* y, void* stream);
-/* Measurement / test hook: input rows convolved per workgroup of fi_conv1x1_up2x_fwd (2 * rows output rows; 0 = the per-shape default: 3, or 6 for the 256 -> 128 level). */
+/* Measurement / test hook: input rows convolved per workgroup of fi_conv1x1_up2x_fwd (2 * rows output rows; 0 = the per-shape default: 3, or 6 from 128 input channels on). */
 int fi_upfuse_tuning(int rows);
 
 /* 3D surface (unet_3D, /root/reference/code/networks/unet_3D.py:20-94): volumes are dense NDHWC, i.e. D consecutive NHWC

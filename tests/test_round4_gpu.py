@@ -501,3 +501,33 @@ def test_ala_epoch_batched_with_dropout_is_a_valid_epoch_and_captured_equals_eag
     for (w0, p0, l0), (w1, p1, l1) in zip(outs["seq"], outs["eager"]):
         assert np.isfinite(l1[0]) and abs(l0[0] - l1[0]) < 0.1 * max(abs(l0[0]), 1e-3) + 5e-2, (l0, l1)
         assert float((w1 < 1).float().mean()) > 0.01
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_ce_four_pixel_path_equals_the_pixel_loop(C):
+    """fi_ce_fwd / fi_ce_bwd take four pixels per thread (vector loads) when M % 4 == 0 and C is 2 or 3, the pixel loop otherwise:
+    the same per-pixel arithmetic -- gradients bit for bit, the loss to fp64 summation order -- incl. ignored pixels, 16-bit
+    gradient storage and a count that makes the two launches differ only in the path taken."""
+    from fedicra_amd import _lib as L
+    g = torch.Generator().manual_seed(C)
+    M = 4 * 5000
+    logits = (torch.randn(1, M + 1, 1, C, generator=g) * 3).to(DEV)
+    labels = torch.randint(0, C + 1, (1, M + 1, 1), generator=g).to(torch.uint8).to(DEV)       # C = ignore_index
+    labels[0, M, 0] = C                                                                         # the extra pixel is ignored
+    out = []
+    for n in (M, M + 1):                                                                        # vector path, pixel loop
+        lg, lb = logits[:, :n].contiguous(), labels[:, :n].contiguous()
+        acc = torch.zeros(2 * L.CE_SLOTS, dtype=torch.float64, device=DEV)
+        L.ce_fwd(lg, lb, C, acc)
+        loss = torch.empty(1, device=DEV)
+        L.ce_finalize(acc, loss)
+        dl = torch.empty_like(lg)
+        L.ce_bwd(lg, lb, C, acc, None, dl)
+        dh = torch.empty(lg.shape, dtype=torch.bfloat16, device=DEV)
+        L.ce_bwd(lg, lb, C, acc, None, dh)
+        out.append((loss.item(), dl[:, :M].clone(), dh[:, :M].clone(), acc.reshape(-1, 2).sum(0).cpu()))
+    (l0, d0, h0, a0), (l1, d1, h1, a1) = out
+    assert a0[1] == a1[1] and abs(a0[0] - a1[0]) <= 1e-9 * abs(a1[0]) and abs(l0 - l1) <= 1e-6 * abs(l1)
+    assert torch.equal(d0, d1) and torch.equal(h0, h1) and torch.equal(h0, d0.to(torch.bfloat16))
+    want = torch.nn.functional.cross_entropy(logits[0, :M, 0].double().cpu(), labels[0, :M, 0].long().cpu(), ignore_index=C)
+    assert abs(l0 - want.item()) < 1e-5
