@@ -527,11 +527,11 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
   }
   // channel-rich 3x3 layers on 64 ... 256-wide maps: the same streaming with 64 x 64 (64 x 32 / 32 x 64) channel tiles.  Workgroups
   // = items x channel tiles; every ITEM costs one |dw| slice of workspace traffic, so the run length follows the tile count
-  // (FI_WGRAD_ROWS64_WGS workgroups in all, a run of at least 8 rows)
+  // (at most FI_WGRAD_ROWS64_WGS workgroups in all, a run of at least 8 rows)
   if (wgrad_rows64_on() && depth == 0 && p->quad && !p->rows && d->dtype != FI_F32 && d->ksize == 3 && cout % 32 == 0 && cin % 32 == 0 &&
       (cout % 64 == 0 || cin % 64 == 0) && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->W % 32 == 0 && d->W >= 64 &&
       (d->W <= 128 || d->W % 128 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 15)) {
-    static const long wgs_env = env_long("FI_WGRAD_ROWS64_WGS", 320), tile_env = env_long("FI_WGRAD_ROWS64_TILE", 0);
+    static const long wgs_env = env_long("FI_WGRAD_ROWS64_WGS", 512), tile_env = env_long("FI_WGRAD_ROWS64_TILE", 0);
     // tile (gradient x input side, 16-channel blocks): 32 x 64 wherever the input side allows it, else 64 x 32 -- 216 / 228 registers,
     // two workgroups per CU.  The 64 x 64 tile (348 registers: ONE wave per SIMD, nothing hides its LDS latency) measured level on
     // one-tile layers and behind on the others (profiles/r04_wgbench_rows64.txt: 128^2 128 -> 64 68 us against 55, 64^2 128 -> 128
@@ -545,9 +545,12 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     p->nit = cin / (p->tci * 16);
     p->ws = d->W <= 128 ? d->W : 128;
     p->strips = d->W / p->ws;
-    long items_target = wgs_env / ((long)p->nct * p->nit);
-    if (items_target < (long)d->N * p->strips) items_target = (long)d->N * p->strips;
-    long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
+    // one full wave of workgroups (two per CU) and no second, partial one: the run length is the shortest that keeps
+    // items x tiles <= FI_WGRAD_ROWS64_WGS (profiles/r04_wgbench_rows64_wgs.txt: 456-512 workgroups 546 us per body-phase iteration,
+    // 312-384: 594, 624-672: 585)
+    long chunks_max = wgs_env / ((long)p->nct * p->nit * d->N * p->strips);
+    if (chunks_max < 1) chunks_max = 1;
+    long rpw = (d->H + chunks_max - 1) / chunks_max;
     if (rpw < 8) rpw = 8;
     if (rpw > d->H) rpw = d->H;
     p->rpw = (int)rpw;

@@ -13,6 +13,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A rendezvous port nobody holds right now (a pid-derived constant collided with a socket of the previous test still in
+    TIME_WAIT once in a while: one spurious failure in ~20 runs of this file)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_library_exports_every_declared_symbol():
     from fedicra_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -189,7 +198,7 @@ print("rank", rank, "ok")
 def test_weighted_allreduce_gloo_multiprocess(tmp_path, world):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 1000 + world)
+    port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
@@ -391,7 +400,7 @@ def test_weighted_allreduce_constant_term_counts_the_clients_no_rank_hosts():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 400
+    port = _free_port()
     ps = [ctx.Process(target=_const_term_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()

@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # conv_fwd = every forward / dgrad form of the convolution (one-tile conv_fwd_kernel, conv_fwd_v2_kernel, conv_fwd_ws*_kernel
 # and conv_thin_kernel): the same launch set bench.py's roofline object prices as the family "conv_fwd"
 FAMILIES = [("wgrad_reduce", "wgrad_reduce"), ("conv_wgrad", "conv_wgrad"), ("conv_fwd", "conv_fwd"), ("conv_thin", "conv_fwd"),
+            ("conv_narrow", "conv_fwd"), ("conv1x1_up2x", "conv_up_fwd"), ("xcorr_partial", "conv_stats_xcorr"),
             ("bn_act_bwd_apply", "bn_bwd_apply"), ("bn_act_bwd_reduce", "bn_bwd_reduce"), ("bn_fused_fwd", "bn_fwd"),
             ("bn_act_fwd", "bn_fwd"), ("maxpool_bwd", "maxpool_bwd"), ("maxpool_fwd", "maxpool_fwd"),
             ("upsample_bwd", "upsample_bwd"), ("upsample_fwd", "upsample_fwd"), ("pack_weights", "pack_weights"),
