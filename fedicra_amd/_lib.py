@@ -60,7 +60,7 @@ class FiError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 2             # include/fedicra_hip.h FI_ABI_VERSION
+ABI_VERSION = 3             # include/fedicra_hip.h FI_ABI_VERSION
 
 
 def source_hash():

@@ -48,8 +48,10 @@ extern "C" {
  * written against, so a stale or foreign libfedicra_hip.so fails at load, not by passing a pointer in the wrong slot.
  *   1: rounds 1-2 (fi_ala_update gained `skip` without a bump -- the reason for this note)
  *   2: round 3 (FiConv.w16 / w16_rows + fi_pack_weights modes 2 / 3 and the 8-column pack table, fi_conv_weight_chunk16,
- *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check) */
-#define FI_ABI_VERSION 2
+ *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check)
+ *   3: round 4 (new entry points: fi_conv2d_stats_xcorr*, fi_bn_act_pool_groups, fi_conv1x1_up2x_fwd, fi_wgrad_tuning / fi_narrow_tuning /
+ *      fi_upfuse_tuning; fi_wgrad_tuning's argument became a bit mask) */
+#define FI_ABI_VERSION 3
 int fi_abi_version(void);
 
 /* ---------------------------------------------------------------- convolution ------------
