@@ -59,6 +59,40 @@ def _w_taps(weight, dtype, mode):
     return _cached(weight, dtype, ("taps", mode), build)
 
 
+def _w_all(weight, dtype, mode):
+    """The one-launch forms' operands straight from the parameter, ONE cast-and-permute copy each (two for the dgrad side: the flip
+    materialises) instead of per depth tap a slice copy, fi_pack_weights and a stack -- 16 small launches per layer and iteration
+    that were a ninth of a unet_3D step (profiles/r04_z_c4_bench_kernel_stats.csv: 107 pack + 123 copy + 34 cat launches).
+    mode 0: [Cout][kH*kW][kD][Cin] = weight[co][ci][t][r][s] (fi_pack_weights mode 0 per tap, stacked over the taps);
+    mode 1: [Cin][kH*kW][kD][Cout] with all three filter axes reversed (mode 1 per tap, the taps stacked in reverse).
+    Values: the same round-to-nearest cast fi_pack_weights makes."""
+    def build():
+        cout, cin, kd, kh, kw = weight.shape
+        w = weight.detach()
+        if mode == 0:
+            out = torch.empty((cout, kh * kw, kd, cin), dtype=dtype, device=weight.device)
+            out.view(cout, kh, kw, kd, cin).copy_(w.permute(0, 3, 4, 2, 1))
+        else:
+            out = torch.empty((cin, kh * kw, kd, cout), dtype=dtype, device=weight.device)
+            out.view(cin, kh, kw, kd, cout).copy_(w.flip(2, 3, 4).permute(1, 3, 4, 2, 0))
+        return out
+    return _cached(weight, dtype, ("all", mode), build)
+
+
+_const_cache = {}
+
+
+def _norm_consts(cout, dev):
+    """(ones, zeros, running-mean scratch, running-var scratch) of an affine-free InstanceNorm: the same four vectors for every
+    layer of that width (momentum 0 leaves the scratch statistics as they are) -- four fill launches per convolution otherwise."""
+    key = (dev.index, cout, torch.cuda.is_current_stream_capturing())
+    c = _const_cache.get(key)
+    if c is None:
+        c = _const_cache[key] = (torch.ones(cout, device=dev), torch.zeros(cout, device=dev), torch.zeros(cout, device=dev),
+                                 torch.ones(cout, device=dev))
+    return c
+
+
 def _fused_ok(dt, ydt, kd, ksize, x0, x1, cout):
     """Shapes fi_conv3d_*_fused covers (the library re-checks and answers FI_ERR_UNSUPPORTED otherwise)."""
     if dt == torch.float32 or ydt != dt or kd != 3 or ksize != 3:
@@ -76,31 +110,30 @@ class _Conv3d(Function):
         N, D, H, W, _ = x0.shape
         cout, cin, kd, ksize, _ = weight.shape
         dev, dt = x0.device, x0.dtype
-        wp = _w_taps(weight, dt, 0)
         ydt = torch.float32 if (y_f32 and not norm) else dt
-        stats = torch.zeros((N, L.STATS_SLOTS * cout * 2), dtype=torch.float64, device=dev) if norm else None
+        # per-sample statistics accumulators out of the iteration's zeroed arena (one memset per iteration, not a fill per layer)
+        nst = L.STATS_SLOTS * cout * 2
+        stats = ops._ctx.arena.take(N * nst, dev).view(N, nst) if norm else None
         x0c, x1c = x0.contiguous(), None if x1 is None else x1.contiguous()
         y = None
         if _fused_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
             # ONE implicit GEMM over all slices of all volumes, the depth taps as channel groups of its contraction: y is
             # written once (the per-tap form below reads and rewrites it twice more)
             y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
-            w_all = _cached(weight, dt, "all0", lambda: torch.stack([t.view(cout, ksize * ksize, cin) for t in wp],
-                                                                     dim=2).contiguous())               # [Cout][9][3][Cin]
-            if not L.conv3d_fwd_fused(x0c, x1c, w_all, bias, y, stats, ksize=ksize):
+            if not L.conv3d_fwd_fused(x0c, x1c, _w_all(weight, dt, 0), bias, y, stats, ksize=ksize):      # [Cout][9][3][Cin]
                 y = None
         if y is None:
             y = torch.zeros((N, D, H, W, cout), dtype=ydt, device=dev)
             # every (sample, depth tap) 2D launch is issued by ONE C-ABI call (fi_conv3d_fwd)
-            L.conv3d_fwd(x0c, x1c, wp, bias, y, stats, ksize=ksize, y_f32=ydt == torch.float32 and dt != torch.float32)
+            L.conv3d_fwd(x0c, x1c, _w_taps(weight, dt, 0), bias, y, stats, ksize=ksize,
+                         y_f32=ydt == torch.float32 and dt != torch.float32)
         if not norm:
             ctx.save_for_backward(x0, x1, weight)
             ctx.norm, ctx.has_bias = False, bias is not None
             return y
         z = torch.empty_like(y)
         coef = torch.empty((N, 4, cout), dtype=torch.float32, device=dev)
-        one, zero = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-        rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)        # scratch: no running statistics
+        one, zero, rm, rv = _norm_consts(cout, dev)                 # (rm, rv: scratch -- no running statistics)
         for n in range(N):
             L.bn_fused_fwd(y[n], z[n], stats[n], one, zero, rm, rv, None, 0.0, 1e-5, True, coef[n], 0.0, None)
         ctx.save_for_backward(x0, x1, weight, y, coef)
@@ -120,7 +153,7 @@ class _Conv3d(Function):
         if ctx.norm:
             dy = torch.empty_like(y)
             for n in range(N):
-                sums = torch.zeros(L.STATS_SLOTS * cout * 2, dtype=torch.float64, device=dev)
+                sums = ops._ctx.arena.take(L.STATS_SLOTS * cout * 2, dev)
                 L.bn_act_bwd_reduce(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, 0.0, None)
                 L.bn_act_bwd_apply(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, True, dy[n], None,
                                    None, 0.0, None)
@@ -129,20 +162,17 @@ class _Conv3d(Function):
         need_x0, need_x1 = ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1]
         dx0 = dx1 = gw = gb = None
         if need_x0 or need_x1:
-            wt = _w_taps(weight, dt, 1)
             dyc = dy.contiguous()
             done = False
             if _fused_ok(dt, dt, kd, ksize, dyc, None, c0) and (x1 is None or x1.shape[4] % 8 == 0):
                 d0 = torch.empty_like(x0)
                 d1 = None if x1 is None else torch.empty_like(x1)
                 # the depth taps reversed: input slice d + j - 1 of dy meets the filter's depth tap 2 - j
-                wt_all = _cached(weight, dt, "all1", lambda: torch.stack([t.view(cin, ksize * ksize, cout) for t in wt[::-1]],
-                                                                          dim=2).contiguous())
-                done = L.conv3d_dgrad_fused(dyc, wt_all, d0, d1, ksize=ksize)
+                done = L.conv3d_dgrad_fused(dyc, _w_all(weight, dt, 1), d0, d1, ksize=ksize)
             if not done:
                 d0 = torch.zeros_like(x0)
                 d1 = None if x1 is None else torch.zeros_like(x1)
-                L.conv3d_dgrad(dyc, wt, d0, d1, ksize=ksize)
+                L.conv3d_dgrad(dyc, _w_taps(weight, dt, 1), d0, d1, ksize=ksize)
             dx0 = d0 if need_x0 else None
             dx1 = d1 if need_x1 else None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
@@ -151,7 +181,9 @@ class _Conv3d(Function):
             gw = None
             if kd == 3 and ksize == 3:
                 # ONE launch over all slices of all volumes, the depth taps as channel groups of the input side
-                gall = torch.zeros((cout, ksize, ksize, kd, cin), dtype=torch.float32, device=dev)       # [Cout][9][3][Cin]
+                # (zeros out of the iteration's arena -- fp64 words viewed as fp32; the tensor dies with the permuted copy below)
+                ng = cout * ksize * ksize * kd * cin
+                gall = ops._ctx.arena.take((ng + 1) // 2, dev).view(torch.float32)[:ng].view(cout, ksize, ksize, kd, cin)   # [Cout][9][3][Cin]
                 if L.conv3d_wgrad_fused(x0c, x1c, dyc, gall, gb, ksize=ksize):
                     gw = gall.permute(0, 4, 3, 1, 2).contiguous()      # [Cout,Cin,kD,kH,kW]
                 elif gb is not None:
@@ -216,7 +248,7 @@ class _Dropout(Function):
         # channel = True: Dropout3d, one draw per (sample, channel) -- the per-sample view gives the kernel its sample index
         v = x.reshape(x.shape[0], -1, 1, C) if channel else x.reshape(-1, 1, 1, C)
         spec = ops._drop_spec(p, "chan" if channel else "elem", v.shape[0], v.shape[1], 1, C, x.device, owner=owner)
-        one, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+        one, zero = _norm_consts(C, x.device)[:2]
         z = torch.empty_like(v)
         L.bn_act_fwd(v, one, zero, z, 1.0, spec)
         ctx.spec, ctx.C, ctx.vshape = spec, C, tuple(v.shape)
@@ -226,7 +258,7 @@ class _Dropout(Function):
     def backward(ctx, dz):
         C = ctx.C
         v = dz.contiguous().reshape(ctx.vshape)
-        one, zero = torch.ones(C, device=dz.device), torch.zeros(C, device=dz.device)
+        one, zero = _norm_consts(C, dz.device)[:2]
         out = torch.empty_like(v)
         L.bn_act_fwd(v, one, zero, out, 1.0, ctx.spec)
         return out.reshape(dz.shape), None, None, None
