@@ -106,7 +106,8 @@ class _Conv3d(Function):
     """y = conv3d(cat(x0, x1)) + bias, optionally followed by InstanceNorm3d(affine=False) + ReLU."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, norm, y_f32):
+    def forward(ctx, x0, x1, weight, bias, norm, y_f32, mod=None):
+        ctx.mod = mod
         N, D, H, W, _ = x0.shape
         cout, cin, kd, ksize, _ = weight.shape
         dev, dt = x0.device, x0.dtype
@@ -176,23 +177,35 @@ class _Conv3d(Function):
             dx0 = d0 if need_x0 else None
             dx1 = d1 if need_x1 else None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gb = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            # Gradient targets like the 2D path's (ops._grad_target): a parameter of a flat-store model accumulates straight into
+            # its slice of the flat gradient buffer -- the bias through the kernel's own `+=`, the filter through ONE add that reads
+            # the kernel's [Cout][9][3][Cin] layout -- and autograd gets None; a fresh gradient tensor, a fill, a permuted copy and
+            # the optimizer's gather copy per parameter otherwise (40 device copies + 19 fills per unet_3D iteration).
+            mod = ctx.mod
+            wt_, _, gw = ops._grad_target(mod.weight) if mod is not None else (torch.zeros_like(weight, dtype=torch.float32),) * 2 + (None,)
+            if mod is None:
+                gw = wt_
+            db = gb = None
+            if ctx.has_bias:
+                if mod is not None:
+                    db, _, gb = ops._grad_target(mod.bias)
+                else:
+                    db = gb = torch.zeros(cout, dtype=torch.float32, device=dev)
             x0c, x1c, dyc = x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous()
-            gw = None
+            done = False
             if kd == 3 and ksize == 3:
                 # ONE launch over all slices of all volumes, the depth taps as channel groups of the input side
-                # (zeros out of the iteration's arena -- fp64 words viewed as fp32; the tensor dies with the permuted copy below)
+                # (zeros out of the iteration's arena -- fp64 words viewed as fp32; the tensor dies with the add below)
                 ng = cout * ksize * ksize * kd * cin
                 gall = ops._ctx.arena.take((ng + 1) // 2, dev).view(torch.float32)[:ng].view(cout, ksize, ksize, kd, cin)   # [Cout][9][3][Cin]
-                if L.conv3d_wgrad_fused(x0c, x1c, dyc, gall, gb, ksize=ksize):
-                    gw = gall.permute(0, 4, 3, 1, 2).contiguous()      # [Cout,Cin,kD,kH,kW]
-                elif gb is not None:
-                    gb.zero_()
-            if gw is None:
+                if L.conv3d_wgrad_fused(x0c, x1c, dyc, gall, db, ksize=ksize):        # (declines before it launches anything)
+                    wt_.add_(gall.permute(0, 4, 3, 1, 2))              # -> [Cout,Cin,kD,kH,kW]
+                    done = True
+            if not done:
                 gwk = torch.zeros((kd, cout, ksize, ksize, cin), dtype=torch.float32, device=dev)
-                L.conv3d_wgrad(x0c, x1c, dyc, gwk, gb, ksize=ksize)
-                gw = gwk.permute(1, 4, 0, 2, 3).contiguous()           # [Cout,Cin,kD,kH,kW]
-        return dx0, dx1, gw, gb, None, None
+                L.conv3d_wgrad(x0c, x1c, dyc, gwk, db, ksize=ksize)
+                wt_.add_(gwk.permute(1, 4, 0, 2, 3))                   # -> [Cout,Cin,kD,kH,kW]
+        return dx0, dx1, gw, gb, None, None, None
 
 
 class _MaxPool3d(Function):
@@ -269,7 +282,7 @@ def conv3d(x0, x1, conv, norm=False, y_f32=False):
     k = conv.kernel_size
     if not (k[0] == k[1] == k[2] and k[0] in (1, 3) and conv.padding == (k[0] // 2,) * 3 and conv.stride == (1, 1, 1)):
         raise NotImplementedError("conv3d: only 3x3x3/pad 1 and 1x1x1, stride 1 (all the unet_3D surface uses)")
-    return _Conv3d.apply(x0, x1, conv.weight, conv.bias, bool(norm), bool(y_f32))
+    return _Conv3d.apply(x0, x1, conv.weight, conv.bias, bool(norm), bool(y_f32), conv)
 
 
 def maxpool3d(x):
