@@ -207,3 +207,63 @@ def test_one_launch_conv3d_equals_the_per_tap_form(dtype, case):
         if a is not None:
             d = (b.float() - a.float()).abs()
             assert bool((d <= 4 * ulp * (a.float().abs() + 1.0)).all()), float(d.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_one_launch_operands_from_the_parameter_equal_the_stacked_per_tap_packs(dtype):
+    """ops3d._w_all (one cast-and-permute copy of the Conv3d parameter) against the construction it replaces: fi_pack_weights of
+    every depth tap (mode 0 forward, mode 1 dgrad) stacked over the taps -- in reverse for the dgrad operand.  Bit for bit."""
+    from fedicra_amd import _lib as L
+    from fedicra_amd import ops3d
+    torch.manual_seed(4)
+    for cout, cin in ((16, 48), (32, 16), (24, 8)):
+        w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, 3, device="cuda"))
+        packs = {0: [], 1: []}
+        for mode in (0, 1):
+            for t in range(3):
+                wk = w.detach()[:, :, t].permute(0, 2, 3, 1).contiguous().float()
+                dst = torch.empty(cout * 9 * cin, dtype=dtype, device="cuda")
+                L.pack_weights(wk, dst, cout, 9, cin, mode)
+                packs[mode].append(dst)
+        want0 = torch.stack([t.view(cout, 9, cin) for t in packs[0]], dim=2).contiguous()
+        want1 = torch.stack([t.view(cin, 9, cout) for t in packs[1][::-1]], dim=2).contiguous()
+        assert torch.equal(ops3d._w_all(w, dtype, 0), want0)
+        assert torch.equal(ops3d._w_all(w, dtype, 1), want1)
+
+
+def test_flat_store_model_takes_its_3d_gradients_in_the_sinks():
+    """A unet_3D on the flat store: after backward every parameter's .grad IS its slice of the flat gradient buffer (no foreign
+    tensor for the optimizer to gather), and the gradients equal those of a second backward accumulated on top (x 2)."""
+    from fedicra_amd import ops
+    from fedicra_amd.networks.net_factory_3d import net_factory_3d
+    from fedicra_amd.networks.unet import set_compute_dtype
+    torch.manual_seed(1)
+    net = net_factory_3d("unet_3D", 1, 2).cuda().train()
+    set_compute_dtype(net, "bf16")
+    for m in net.modules():                                               # (every forward draws fresh dropout masks: off for the x 2 check)
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            m.p = 0.0
+    x = torch.rand(1, 1, 32, 32, 32, device="cuda")
+    y = (torch.rand(1, 32, 32, 32, device="cuda") > 0.5).to(torch.uint8)
+
+    def backward():
+        ops.begin_iteration(torch.device("cuda"))
+        out = net(x).permute(0, 2, 3, 4, 1)
+        N, D, H, W, C = out.shape
+        ops.ce_loss(out.reshape(N * D, H, W, C), y.reshape(N * D, H, W), 255).backward()
+
+    net.zero_grad()
+    backward()
+    torch.cuda.synchronize()
+    sinks = 0
+    for p in net.parameters():
+        if p.grad is not None and getattr(p, "_fi_gview", None) is not None:
+            assert p.grad.data_ptr() == p._fi_gview.data_ptr()
+            sinks += 1
+    assert sinks > 30
+    g1 = net.flat_grads.clone()
+    backward()                                                            # accumulates
+    torch.cuda.synchronize()
+    g2 = net.flat_grads.clone()
+    assert float(g1.abs().max()) > 0
+    assert torch.allclose(g2, 2 * g1, rtol=2e-2, atol=1e-3 * float(g1.abs().max()))     # (atomic statistics sums: not bit-identical runs)
