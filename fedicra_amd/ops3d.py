@@ -182,15 +182,19 @@ class _Conv3d(Function):
             # the kernel's [Cout][9][3][Cin] layout -- and autograd gets None; a fresh gradient tensor, a fill, a permuted copy and
             # the optimizer's gather copy per parameter otherwise (40 device copies + 19 fills per unet_3D iteration).
             mod = ctx.mod
-            wt_, _, gw = ops._grad_target(mod.weight) if mod is not None else (torch.zeros_like(weight, dtype=torch.float32),) * 2 + (None,)
-            if mod is None:
-                gw = wt_
+            need_w, need_b = ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3]
+            if need_w and mod is not None:
+                wt_, _, gw = ops._grad_target(mod.weight)
+            else:                                   # (a frozen filter must not be handed a gradient: scratch, dropped)
+                wt_ = torch.zeros_like(weight, dtype=torch.float32)
+                gw = wt_ if need_w else None
             db = gb = None
             if ctx.has_bias:
-                if mod is not None:
+                if need_b and mod is not None:
                     db, _, gb = ops._grad_target(mod.bias)
                 else:
-                    db = gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+                    db = torch.zeros(cout, dtype=torch.float32, device=dev)
+                    gb = db if need_b else None
             x0c, x1c, dyc = x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous()
             done = False
             if kd == 3 and ksize == 3:
