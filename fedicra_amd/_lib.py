@@ -28,7 +28,7 @@ EXPORTS = [
     "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
-    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning",
+    "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning", "fi_pack_weights3d_multi",
 ]
 
 
@@ -433,6 +433,11 @@ CE_SLOTS = 16        # FI_CE_SLOTS
 def wgrad_reduce_multi(table, n, nblocks):
     with _timed("wgrad_reduce", (n,), 0, 0):
         _chk(lib().fi_wgrad_reduce_multi(ptr(_dev(table)), int(n), int(nblocks), stream()), "fi_wgrad_reduce_multi")
+
+
+def pack_weights3d_multi(table, ntensors, nblocks, dtype):
+    """fi_pack_weights3d_multi: table int64 [ntensors][6] on the device (ops3d._MultiPack3D builds it)."""
+    _chk(lib().fi_pack_weights3d_multi(ptr(_dev(table)), int(ntensors), int(nblocks), dt(dtype), stream()), "fi_pack_weights3d_multi")
 
 
 def pack_weights(src, dst, cout, kk, cin, mode):

@@ -59,6 +59,74 @@ def _w_taps(weight, dtype, mode):
     return _cached(weight, dtype, ("taps", mode), build)
 
 
+class _MultiPack3D:
+    """Every eligible Conv3d weight that asked for a one-launch operand so far, their persistent operand buffers and the device
+    table fi_pack_weights3d_multi reads: ONE launch rebuilds both operands of all of them when any went stale (the optimizer step
+    of an iteration makes all of them stale at once) instead of three cast / flip / permute launches per layer."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.ents = []              # [weakref(weight), forward operand, dgrad operand, the parameter's address in the table]
+        self.index = {}             # id(weight) -> position
+        self.table = None
+        self.nblocks = 0
+
+    @staticmethod
+    def eligible(weight):
+        if weight.dim() != 5 or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
+            return False
+        cout, cin, kd, kh, kw = weight.shape
+        return kd == kh == kw == 3 and cin >= 8 and cout >= 8
+
+    def ensure(self, weight):
+        """True when `weight` and everything else registered can be packed by the table as it stands; rebuilds the table (dead
+        weights dropped, moved ones re-addressed, `weight` added) when not -- except inside a stream capture, where a host -> device
+        copy is not allowed: False then, and the caller builds this operand the per-layer way."""
+        import weakref
+        pos = self.index.get(id(weight))
+        fresh = (pos is not None and self.ents[pos][0]() is weight
+                 and all(e[0]() is not None and e[0]().data_ptr() == e[3] for e in self.ents))
+        if fresh:
+            return True
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        live = [e for e in self.ents if e[0]() is not None and e[0]().device == weight.device]
+        if not any(e[0]() is weight for e in live):
+            cout, cin = weight.shape[0], weight.shape[1]
+            live.append([weakref.ref(weight), torch.empty((cout, 9, 3, cin), dtype=self.dtype, device=weight.device),
+                         torch.empty((cin, 9, 3, cout), dtype=self.dtype, device=weight.device), 0])
+        rows, nb = [], 0
+        for e in live:
+            w = e[0]()
+            e[3] = w.data_ptr()
+            rows.append([e[3], e[1].data_ptr(), e[2].data_ptr(), w.shape[0], w.shape[1], nb])
+            nb += -(-(w.shape[0] * w.shape[1]) // 256)
+        self.ents = live
+        self.index = {id(e[0]()): i for i, e in enumerate(live)}
+        self.table = torch.tensor(rows, dtype=torch.int64).to(weight.device)
+        self.nblocks = nb
+        return True
+
+    def refresh(self):
+        """Repack everything registered and install the operands in the pack cache under the keys _cached() looks up now."""
+        import weakref
+        L.pack_weights3d_multi(self.table, len(self.ents), self.nblocks, self.dtype)
+        cap = torch.cuda.is_current_stream_capturing()
+        for wr, d0, d1, _ in self.ents:
+            w = wr()
+            key = (w._version, ops.weights_epoch(), self.dtype, w.data_ptr(), cap)
+            ent = _pack_cache.get(id(w))
+            if ent is None or ent[0]() is not w or ent[1] != key:
+                ent = (weakref.ref(w), key, {})
+                _pack_cache[id(w)] = ent
+            ent[2][("all", 0)] = d0
+            ent[2][("all", 1)] = d1
+
+
+_multi3d = {}                  # dtype -> _MultiPack3D
+_MULTI3D = __import__("os").environ.get("FI_PACK3D_MULTI", "1") != "0"      # measurement switch: 0 = per-layer torch copies
+
+
 def _w_all(weight, dtype, mode):
     """The one-launch forms' operands straight from the parameter, ONE cast-and-permute copy each (two for the dgrad side: the flip
     materialises) instead of per depth tap a slice copy, fi_pack_weights and a stack -- 16 small launches per layer and iteration
@@ -76,6 +144,15 @@ def _w_all(weight, dtype, mode):
             out = torch.empty((cin, kh * kw, kd, cout), dtype=dtype, device=weight.device)
             out.view(cin, kh, kw, kd, cout).copy_(w.flip(2, 3, 4).permute(1, 3, 4, 2, 0))
         return out
+    if _MULTI3D and dtype != torch.float32 and _MultiPack3D.eligible(weight):
+        key = (weight._version, ops.weights_epoch(), dtype, weight.data_ptr(), torch.cuda.is_current_stream_capturing())
+        ent = _pack_cache.get(id(weight))
+        if ent is None or ent[0]() is not weight or ent[1] != key or ("all", mode) not in ent[2]:
+            mp = _multi3d.get(dtype)
+            if mp is None:
+                mp = _multi3d[dtype] = _MultiPack3D(dtype)
+            if mp.ensure(weight):
+                mp.refresh()                         # this weight is stale: so is every other one -- all of them in one launch
     return _cached(weight, dtype, ("all", mode), build)
 
 

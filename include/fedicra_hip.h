@@ -50,7 +50,7 @@ extern "C" {
  *   2: round 3 (FiConv.w16 / w16_rows + fi_pack_weights modes 2 / 3 and the 8-column pack table, fi_conv_weight_chunk16,
  *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check)
  *   3: round 4 (new entry points: fi_conv2d_stats_xcorr*, fi_bn_act_pool_groups, fi_conv1x1_up2x_fwd, fi_wgrad_tuning / fi_narrow_tuning /
- *      fi_upfuse_tuning; fi_wgrad_tuning's argument became a bit mask) */
+ *      fi_upfuse_tuning, fi_pack_weights3d_multi; fi_wgrad_tuning's argument became a bit mask) */
 #define FI_ABI_VERSION 3
 int fi_abi_version(void);
 
@@ -333,6 +333,12 @@ int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* dx, int N, 
  * [N,d,h,w,C] -> [N,2d,2h,2w,C];  backward = exact adjoint (gather over the 4x4x4 candidate outputs). */
 int fi_upsample3d2x_fwd(int dtype, const void* x, void* y, int N, int d, int h, int w, int C, void* stream);
 int fi_upsample3d2x_bwd(int dtype, const void* dy, void* dx, int N, int d, int h, int w, int C, void* stream);
+/* Both one-launch operands of every 3x3x3 convolution of a model in ONE launch (the 3D path's fi_pack_weights_multi; Conv3d weights of
+ * /root/reference/code/networks/unet_3D.py:20-94 / networks/utils.py:99-123): table = device rows of 6 int64 { fp32 parameter
+ * [Cout][Cin][3][3][3], forward operand [Cout][9][3][Cin] (fi_conv3d_fwd_fused), dgrad operand [Cin][9][3][Cout] with all three filter
+ * axes reversed (fi_conv3d_dgrad_fused), Cout, Cin, first block }, a block = 256 (co, ci) pairs of its tensor; nblocks = their sum.
+ * 16-bit storage types; values rounded as fi_pack_weights rounds. */
+int fi_pack_weights3d_multi(const long long* table, int ntensors, int nblocks, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- losses ------------------
  * CrossEntropyLoss(ignore_index) (/root/reference/code/flower_pCE_2D.py:57,124): logits fp32 NHWC
