@@ -105,7 +105,8 @@ class Federation:
             # clients 'world'..7 are hosted by nobody: their term of the weighted sum is n_k x (initial state), a constant
             n_abs = sum(all_n[world:])
             absent = (DeviceWeights(net.flat_state.clone(), net.flat_counters.clone()), n_abs)
-        self.agg = WeightedAllReduce(all_n[cid], device=dev, constant_term=absent, timing=True)
+        self.agg = WeightedAllReduce(all_n[cid], device=dev, constant_term=absent, timing=True,
+                                     always_collective=bool(getattr(a, "rccl_single_rank", False)))
         self.backend = None
         if world > 1:
             # communicator creation (seconds, once) must not land inside a timed region, whatever --warmup is
@@ -153,8 +154,13 @@ class Federation:
     def timed(self, warmup, steps, dist, windows=1):
         """W untimed warm-up steps, then `windows` back-to-back windows of EXACTLY `steps` steps, each bracketed by barrier +
         synchronize on both sides and reduced with MAX over ranks.  -> (elapsed of the MEDIAN window, its mean aggregation
-        round in ms, [elapsed of every window]).  The event lists round_split() reads are those of the median window."""
-        self.run_steps(warmup)
+        round in ms, [elapsed of every window]).  The event lists round_split() reads are those of the median window.
+        The warm-up is rounded UP to whole rounds and to at least two of them (self.warmup_run): a captured step exists from
+        the third use of its freeze phase on and the ALA epoch's graph from the second round on, so a 5-step warm-up left
+        three captures inside the first timed window (round 4: 1 187 against 1 386 images/s)."""
+        ri = self.a.round_iters
+        self.warmup_run = max(-(-int(warmup) // ri) * ri, 2 * ri)
+        self.run_steps(self.warmup_run)
         res = []
         for _ in range(max(1, windows)):
             torch.cuda.synchronize()
@@ -197,7 +203,14 @@ class Federation:
 # --workload c4: BASELINE.json configs[3] -- 4 clients, 3D U-Net 128^3 CT patches, bf16, one client per MI355X
 # ---------------------------------------------------------------------------------------------------------------------
 C4_CLIENTS = 4
+C5_CLIENTS = 8
 C4_FWD_GF = 289.14          # conv FLOPs of one forward of unet_3D(1,2) at 128^3, per volume
+
+
+def client_sizes_3d(k):
+    """n_k of the k sites: the FAZ site sizes / batch the 2D federation uses, cycled."""
+    base = [21, 13, 17, 59, 3]
+    return [base[i % len(base)] for i in range(k)]
 
 
 class Volumes:
@@ -206,24 +219,39 @@ class Volumes:
     the 2D client loop carried over: zero-grad, forward, CE, backward, SGD(momentum 0.9, wd 1e-4 -- the reference's 3D trainers'
     optimizer) with the poly LR, and FedAvg every ``round_iters`` steps (pre-scaled flat state -> weighted all-reduce -> load)."""
 
-    def __init__(self, a, rank, world, dev, dtype):
+    def __init__(self, a, rank, world, dev, dtype, kind="c4"):
         from fedicra_amd.comm import WeightedAllReduce
         from fedicra_amd.flower_common import DeviceWeights
         from fedicra_amd.networks.net_factory_3d import net_factory_3d
         from fedicra_amd.networks.unet import set_compute_dtype
-        from fedicra_amd.optim import FusedSGD
-        self.a, self.rank, self.world, self.dev = a, rank, world, dev
+        from fedicra_amd.optim import FusedAdamW, FusedSGD
+        self.a, self.rank, self.world, self.dev, self.kind, self.dtype_name = a, rank, world, dev, kind, dtype
+        self.federation = C4_CLIENTS if kind == "c4" else C5_CLIENTS
         torch.manual_seed(2022)
-        self.net = net_factory_3d("unet_3D", 1, 2).to(dev).train()
-        set_compute_dtype(self.net, dtype)
+        self.scaler = None
+        if kind == "c4":
+            self.net = net_factory_3d("unet_3D", 1, 2).to(dev).train()
+            set_compute_dtype(self.net, dtype)
+        else:
+            # configs[4]: "3D U-Net + per-client adapter heads, fp16": unet_3D_lc (channel selection on the deepest block +
+            # an auxiliary Conv3d head, networks/unet_3D.py) in the reference's autocast dtype with its GradScaler
+            # (flower_pCE_2D.py:47-48,143-146), AdamW like the 2D clients (:55)
+            from fedicra_amd.amp import GradScaler
+            from fedicra_amd.networks.unet_3D import unet_3D_lc
+            self.net = unet_3D_lc(n_classes=2, in_channels=1, client_num=C5_CLIENTS, client_id=rank).to(dev)
+            self.net.set_compute_dtype(dtype).train()
+            self.scaler = GradScaler()
         g = torch.Generator().manual_seed(2022 + 1000 * rank)
         S = a.size
         self.batches = [(torch.rand(a.batch, 1, S, S, S, generator=g).to(dev),
                          (torch.rand(a.batch, S, S, S, generator=g) > 0.5).to(torch.uint8).to(dev)) for _ in range(2)]
-        self.opt = FusedSGD(self.net, lr=0.01, base_lr=0.01, max_iterations=30000)
-        n_all = [21, 13, 17, 59][:C4_CLIENTS]
+        if kind == "c4":
+            self.opt = FusedSGD(self.net, lr=0.01, base_lr=0.01, max_iterations=30000)
+        else:
+            self.opt = FusedAdamW(self.net, lr=0.01, base_lr=0.01, max_iterations=30000)
+        n_all = client_sizes_3d(self.federation)
         absent = None
-        if world < C4_CLIENTS:
+        if world < self.federation:
             absent = (DeviceWeights(self.net.flat_state.clone(), self.net.flat_counters.clone()), sum(n_all[world:]))
         self.agg = WeightedAllReduce(n_all[rank], device=dev, constant_term=absent, timing=True)
         self.backend = None
@@ -244,11 +272,18 @@ class Volumes:
         ops.begin_iteration(self.dev)
         self.opt.zero_grad()
         out = self.net(x)                                        # NCDHW view of fp32 NDHWC logits
+        if isinstance(out, (list, tuple)):                       # unet_3D_lc returns UNet_LC's list; the step reads [0]
+            out = out[0]
         lg = out.permute(0, 2, 3, 4, 1)
         N, D, H, W, Cc = lg.shape
         loss = ops.ce_loss(lg.reshape(N * D, H, W, Cc), y.reshape(N * D, H, W), 255)
-        loss.backward()
-        self.opt.step()
+        if self.scaler is not None:                              # fp16: scale -> backward -> unscale / inf check -> step -> update
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.opt.step()
         self.opt.advance_lr()
 
     def step(self):
@@ -345,7 +380,7 @@ class Volumes:
         table = os.environ.get("FEDICRA_BENCH_TABLE")
         if table:
             with open(table, "w") as f:
-                f.write(f"# per-launch-shape roofline of one unet_3D training iteration (2 instrumented iterations, HIP events, {dtype_name})\n")
+                f.write(f"# per-launch-shape roofline of one {self.kind} training iteration (2 instrumented iterations, HIP events, {dtype_name})\n")
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
                     us = v["ms"] / v["calls"] * 1e3
                     idl = max(v["flops"] / pk_f, v["bytes"] / pk_b) / v["calls"] * 1e6
@@ -357,8 +392,11 @@ class Volumes:
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
                 "share_of_timed_launch_time": round(dom["ms"] / total_ms, 4),
                 "min_roofline_frac": round(dom["ideal"] / max(dom["ms"], 1e-9), 4),
+                "min_roofline_frac_all_conv": round(sum(v["ideal"] for k, v in fam.items() if k.startswith("conv")) /
+                                                    max(sum(v["ms"] for k, v in fam.items() if k.startswith("conv")), 1e-9), 4),
+                "conv_flops_per_step": sum(v["flops"] for k, v in fam.items() if k.startswith("conv")) / 2.0,
                 "kernel_time_breakdown_ms_per_step": {k: round(v["ms"] / 2.0, 3) for k, v in sorted(fam.items())},
-                "profile_command": "python bench.py --workload c4 --roofline-only  (profiles/*_c4_*)"}
+                "profile_command": f"python bench.py --workload {self.kind} --roofline-only  (profiles/*_{self.kind}_*)"}
 
 
 def cpu_baseline_c4(a):
@@ -386,43 +424,98 @@ def cpu_baseline_c4(a):
                       f"iteration on 1x1x{S}^3, scaled by the voxel ratio {vox_ratio:.0f} to a {a.size}^3 volume"}
 
 
+def volumes_line(a, vol, elapsed, agg_ms, world, roof):
+    """The JSON line of a 3D workload (configs[3] / configs[4]); `roof` = Volumes.roofline() or None."""
+    kind, fed_n = vol.kind, vol.federation
+    value = a.steps * a.batch * world / elapsed
+    step_s = (elapsed - agg_ms * 1e-3 * len(vol.agg_events)) / a.steps               # training part of a step
+    f_train = 3.0 * C4_FWD_GF * (a.size / 128.0) ** 3 * a.batch                      # GF per step (dgrad + wgrad for every conv)
+    if roof is not None and roof.get("conv_flops_per_step"):
+        f_train = roof["conv_flops_per_step"] / 1e9                                  # the launches' own algorithmic count
+    captured = any(not isinstance(g, str) for g in vol.graphs.values())
+    model = "unet_3D(n_classes=2, in_channels=1)" if kind == "c4" else "unet_3D_lc (unet_3D + channel selection + adapter head), fp16 + GradScaler"
+    optim = "SGD momentum 0.9" if kind == "c4" else "GradScaler + AdamW"
+    line = {"metric": f"volumes/sec/client (3D U-Net 128^3 local training, configs[{3 if kind == 'c4' else 4}]) ; ms/aggregation round in config",
+            "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[vol.dtype_name], "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{3 if kind == 'c4' else 4}]: {fed_n} clients FedAvg, {model}, "
+                                   f"{a.batch}x1x{a.size}^3 patches per batch, one client per MI355X ({world} hosted); step = one "
+                                   f"local iteration (fwd, CE, bwd, {optim}, poly LR), "
+                                   f"{'one hipGraph per resident batch buffer' if captured else 'eager launches'}; round = "
+                                   f"{a.round_iters} steps + weighted all-reduce + load, all timed; data resident in HBM",
+                       "clients_hosted": world, "federation": fed_n, "global_batch": a.batch * world,
+                       "volumes_per_sec_per_client": round(value / world, 3), "ms_per_aggregation_round": round(agg_ms, 3),
+                       "conv_tflops_per_gpu": round(f_train / step_s / 1e3, 2),
+                       "frac_of_mfma_peak": round(f_train / step_s / 1e3 / MFMA_PEAK[vol.dtype_name], 4),
+                       "frac_of_mfma_peak_is": "algorithmic conv FLOPs of a step / time of the training steps (aggregation excluded)",
+                       "hipgraph": captured, "hipgraph_error": vol.graph_error, "parallelism": f"fed-dp{world}"}}
+    if vol.scaler is not None:
+        line["config"]["grad_scale_after"] = float(vol.scaler.get_scale())
+    if world > 1:
+        sp = vol.agg.split_ms() or {}
+        line["config"].update({"rccl_ranks": world if vol.backend == "nccl" else 0, "dist_backend": vol.backend,
+                               "allreduce_us_per_round": round(sp.get("collective", 0.0) * 1e3, 1)})
+    if roof is not None:
+        line["roofline"] = roof
+    return line
+
+
+def volumes_leg(a, rank, world, dev, dist, kind, steps=20, warmup=12):
+    """configs[3] / configs[4] beside the headline: a short run of the 3D client OUTSIDE the c3 timed
+    region -- `warmup` untimed steps (both resident batch buffers captured), `steps` timed ones incl. their FedAvg rounds, then
+    the instrumented eager iterations of its roofline -- condensed to one object for config.c4 / config.c5."""
+    import copy
+    b = copy.copy(a)
+    b.size, b.batch, b.steps, b.warmup = 128, 2, steps, warmup
+    dtype = "bf16" if kind == "c4" else "fp16"
+    t0 = time.perf_counter()
+    vol = Volumes(b, rank, world, dev, dtype, kind=kind)
+    elapsed, agg_ms = vol.timed(b.warmup, b.steps, dist)
+    try:
+        roof = vol.roofline(dtype)
+    except Exception as e:  # noqa: BLE001
+        roof = {"error": repr(e)[:300]}
+    line = volumes_line(b, vol, elapsed, agg_ms, world, roof if "error" not in roof else None)
+    c = line["config"]
+    out = {"workload": c["workload"], "volumes_per_sec": line["value"], "ms_per_step": line["ms_per_step"], "dtype": line["dtype"],
+           "steps": b.steps, "warmup": b.warmup, "ms_per_aggregation_round": c["ms_per_aggregation_round"],
+           "conv_tflops_per_gpu": c["conv_tflops_per_gpu"], "frac_of_mfma_peak": c["frac_of_mfma_peak"],
+           "hipgraph": c["hipgraph"], "hipgraph_error": c["hipgraph_error"]}
+    if "grad_scale_after" in c:
+        out["grad_scale_after"] = c["grad_scale_after"]
+    if "error" in roof:
+        out["roofline_error"] = roof["error"]
+    else:
+        out.update({"min_roofline_frac": roof["min_roofline_frac"], "min_roofline_frac_all_conv": roof["min_roofline_frac_all_conv"],
+                    "dominant_kernel": roof["kernel"], "dominant_frac": roof["frac"], "dominant_bound": roof["bound"],
+                    "kernel_time_breakdown_ms_per_step": roof["kernel_time_breakdown_ms_per_step"]})
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    del vol
+    torch.cuda.empty_cache()
+    return out
+
+
 def main_c4(a, rank, local, world, dev, dist):
-    assert world <= C4_CLIENTS, "configs[3] is a federation of 4 clients, one per GPU"
-    vol = Volumes(a, rank, world, dev, a.dtype)
+    kind = a.workload
+    dtype = a.dtype if kind == "c4" else ("fp16" if a.dtype == "bf16" else a.dtype)     # configs[4] names fp16
+    assert world <= (C4_CLIENTS if kind == "c4" else C5_CLIENTS), "one client per GPU"
+    vol = Volumes(a, rank, world, dev, dtype, kind=kind)
     if a.roofline_only:
-        roof = vol.roofline(a.dtype)
+        roof = vol.roofline(dtype)
         if rank == 0:
             print(json.dumps({"roofline": roof}), flush=True)
         return
     elapsed, agg_ms = vol.timed(a.warmup, a.steps, dist)
-    value = a.steps * a.batch * world / elapsed
     if rank == 0:
-        step_s = (elapsed - agg_ms * 1e-3 * len(vol.agg_events)) / a.steps
-        f_train = 3.0 * C4_FWD_GF * (a.size / 128.0) ** 3 * a.batch                  # GF per step (dgrad + wgrad for every conv)
-        line = {"metric": "volumes/sec/client (3D U-Net 128^3 local training, configs[3]) ; ms/aggregation round in config",
-                "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
-                "config": {"workload": f"BASELINE.json configs[3]: {C4_CLIENTS} clients FedAvg, unet_3D(n_classes=2, in_channels=1), "
-                                       f"{a.batch}x1x{a.size}^3 patches per batch, one client per MI355X ({world} hosted); step = one "
-                                       f"local iteration (fwd, CE, bwd, SGD momentum 0.9, poly LR), eager launches; round = "
-                                       f"{a.round_iters} steps + weighted all-reduce + load, all timed; data resident in HBM",
-                           "clients_hosted": world, "federation": C4_CLIENTS, "global_batch": a.batch * world,
-                           "volumes_per_sec_per_client": round(value / world, 3), "ms_per_aggregation_round": round(agg_ms, 3),
-                           "conv_tflops_per_gpu": round(f_train / step_s / 1e3, 2),
-                           "frac_of_mfma_peak": round(f_train / step_s / 1e3 / MFMA_PEAK[a.dtype], 4),
-                           "hipgraph": any(not isinstance(g, str) for g in vol.graphs.values()), "hipgraph_error": vol.graph_error,
-                           "parallelism": f"fed-dp{world}"}}
-        if world > 1:
-            sp = vol.agg.split_ms() or {}
-            line["config"].update({"rccl_ranks": world if vol.backend == "nccl" else 0, "dist_backend": vol.backend,
-                                   "allreduce_us_per_round": round(sp.get("collective", 0.0) * 1e3, 1)})
+        roof = None
         if not a.no_roofline:
             try:
-                line["roofline"] = vol.roofline(a.dtype)
+                roof = vol.roofline(dtype)
             except Exception as e:  # noqa: BLE001
-                line["roofline"] = {"error": repr(e)}
-        if world == 1 and not a.no_cpu_baseline:
+                roof = {"error": repr(e)}
+        line = volumes_line(a, vol, elapsed, agg_ms, world, roof)
+        if world == 1 and not a.no_cpu_baseline and kind == "c4":
             line["cpu_baseline"] = cpu_baseline_c4(a)
         print(json.dumps(line), flush=True)
 
@@ -553,13 +646,26 @@ def roofline_pass(client, a, dtype_name):
     client.args.iters = iters
     cfg = {"iter_global": 60, "iters": iters, "eval_iters": 10 * iters, "batch_size": a.batch, "stage": "fit"}
     client.args.iters = 4
-    client._train(dict(cfg, iters=4))                    # warm the eager path (both phases)
+    L.profile_begin(subtract_overhead=False)             # (counted, not priced: the launches a rocprofv3 run of this process sees too)
+    client._train(dict(cfg, iters=4))                    # warm the eager path (both phases: 1 head + 3 body iterations)
+    warm = L.profile_end().summary()
     client.args.iters = iters
     L.profile_begin(subtract_overhead=False)
     client._train(cfg)
     kp = L.profile_end()
     prof = kp.summary()
     total_ms = sum(v["ms"] for v in prof.values())
+    fam_of = lambda k: "conv_fwd" if k[0] == "conv_dgrad" else k[0]
+    # every launch of THIS PROCESS per family (warm-up + instrumented iterations): the population a PMC pass over
+    # `bench.py --roofline-only` counts, so that tools/pmc_traffic.py can divide totals by totals (the per-launch
+    # means of the 10 instrumented iterations and of the 14 a counter pass sees are different head : body mixes)
+    process_totals = {}
+    for part in (warm, prof):
+        for k, v in part.items():
+            t = process_totals.setdefault(fam_of(k), {"launches": 0, "algorithmic_bytes": 0.0, "algorithmic_flops": 0.0})
+            t["launches"] += v["calls"]
+            t["algorithmic_bytes"] += v["bytes"]
+            t["algorithmic_flops"] += v["flops"]
     # dominant kernel = the kernel FAMILY (one __global__ template: conv_fwd also serves dgrad) with the largest
     # share of GPU time; its launches are priced together: achieved = sum(algorithmic work) / sum(duration),
     # i.e. per-launch algorithmic work / average launch duration.
@@ -574,13 +680,25 @@ def roofline_pass(client, a, dtype_name):
     # frac = sum of those ideal times / sum of measured times (SURVEY section 8d "per-layer min(MFMA, HBM)")
     pk_f, pk_b = MFMA_PEAK[dtype_name] * 1e12, HBM_PEAK_GBS * 1e9
 
-    def ideal_ms(v):
-        return max(v["flops"] / pk_f, v["bytes"] / pk_b) * 1e3
+    def ideal_ms(v, executed=True):
+        # an algebraic form (the statistics-only head from the input's autocorrelation, csrc/xcorr.hip) is priced with the
+        # work it EXECUTES: crediting it with the convolution it replaces made that one launch "0.90 of the MFMA peak"
+        # and lifted the all-conv figure by 0.03; the reference-credited variant is printed beside it
+        f = v.get("xflops", v["flops"]) if executed else v["flops"]
+        return max(f / pk_f, v["bytes"] / pk_b) * 1e3
 
     fam_keys = [k for k in prof if (("conv_fwd" if k[0] == "conv_dgrad" else k[0]) == fname)]
     conv_keys = [k for k in prof if k[0].startswith("conv")]
     min_roof_fam = sum(ideal_ms(prof[k]) for k in fam_keys) / max(sum(prof[k]["ms"] for k in fam_keys), 1e-9)
     min_roof_conv = sum(ideal_ms(prof[k]) for k in conv_keys) / max(sum(prof[k]["ms"] for k in conv_keys), 1e-9)
+    min_roof_conv_ref = sum(ideal_ms(prof[k], False) for k in conv_keys) / max(sum(prof[k]["ms"] for k in conv_keys), 1e-9)
+    # the K-1 batched LC forwards (84-image launches): the chain that is the critical path of every iteration
+    gi = a.batch * (FEDERATION - 1)
+    probe_keys = [k for k in conv_keys if len(k) > 2 and k[2] == gi]
+    min_roof_probe = sum(ideal_ms(prof[k]) for k in probe_keys) / max(sum(prof[k]["ms"] for k in probe_keys), 1e-9)
+    probe_ms_per_step = sum(prof[k]["ms"] for k in probe_keys) / float(iters)
+    ideal_ms_per_step = sum(ideal_ms(v) for v in prof.values()) / float(iters)
+    alg_bytes_per_step = sum(v["bytes"] for v in prof.values()) / float(iters)
     calls = dom["calls"]
     avg_ms = dom["ms"] / calls
     flops, nbytes = dom["flops"] / calls, dom["bytes"] / calls
@@ -608,8 +726,14 @@ def roofline_pass(client, a, dtype_name):
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
             "share_of_gpu_time": round(dom["ms"] / total_ms, 4),
             "min_roofline_frac": round(min_roof_fam, 4), "min_roofline_frac_all_conv": round(min_roof_conv, 4),
-            "min_roofline_note": "sum over launches of max(flops / MFMA peak, bytes / HBM peak) / sum of measured durations; "
+            "min_roofline_frac_all_conv_reference_flops": round(min_roof_conv_ref, 4),
+            "min_roofline_frac_probe_chain": round(min_roof_probe, 4), "probe_chain_ms_per_step": round(probe_ms_per_step, 4),
+            "ideal_ms_per_step": round(ideal_ms_per_step, 4), "algorithmic_bytes_per_step": alg_bytes_per_step,
+            "min_roofline_note": "sum over launches of max(EXECUTED flops / MFMA peak, bytes / HBM peak) / sum of measured durations "
+                                 "(an algebraic form is priced with the work it executes; ..._reference_flops credits it with the "
+                                 "layer it replaces); probe_chain = the 84-image launches of the K-1 LC forwards; "
                                  "per-shape table: profiles/*_per_layer_roofline.txt",
+            "process_totals": process_totals,
             "instrumented_iterations": f"{iters - 3} head-phase + 3 body-phase (the timed mix), LC forwards in line: every launch timed alone",
             "hip_launches_per_step": round(sum(v["calls"] for v in prof.values()) / float(iters), 1),
             "conv_flops_per_step": conv_flops / float(iters),
@@ -637,6 +761,9 @@ def roofline_pass(client, a, dtype_name):
             fam_pmc = d["families"].get(fname)
             if fam_pmc and "hbm_bytes_per_launch" in fam_pmc:
                 roof["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+                # totals over the SAME launch population (every launch of the counted process), not a ratio of two means
+                roof["traffic_over_algorithmic"] = fam_pmc.get("traffic_over_algorithmic")
+                roof["traffic_population"] = fam_pmc.get("population")
                 roof["traffic_head"] = d.get("source_hash")
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, bytes per launch)" % os.path.basename(pmc_path)
                 m = fam_pmc.get("mfma")
@@ -658,10 +785,14 @@ def roofline_pass(client, a, dtype_name):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
                 us = v["ms"] / v["calls"] * 1e3
                 idl = ideal_ms(v) / v["calls"] * 1e3
-                bound = "mfma" if v["flops"] / pk_f >= v["bytes"] / pk_b else "hbm"
+                xf = v.get("xflops", v["flops"])
+                bound = "mfma" if xf / pk_f >= v["bytes"] / pk_b else "hbm"
                 f.write(f"{'/'.join(map(str, k)):60s} {v['calls']:5d} {us:9.1f} {idl:9.1f} {idl / max(us, 1e-9):6.3f} "
-                        f"{v['flops'] / v['calls'] / (us * 1e-6) / 1e12:8.1f} {v['bytes'] / v['calls'] / (us * 1e-6) / 1e9:8.1f} {bound}\n")
-            f.write(f"# family {fname}: min-roofline frac {min_roof_fam:.4f}; all conv launches: {min_roof_conv:.4f}\n")
+                        f"{xf / v['calls'] / (us * 1e-6) / 1e12:8.1f} {v['bytes'] / v['calls'] / (us * 1e-6) / 1e9:8.1f} {bound}\n")
+            f.write(f"# TF/s and ideal_us from the flops a launch EXECUTES (conv_stats_xcorr: the autocorrelation form, not the convolution it replaces)\n")
+            f.write(f"# family {fname}: min-roofline frac {min_roof_fam:.4f}; all conv launches: {min_roof_conv:.4f} "
+                    f"(crediting algebraic forms with the replaced layer: {min_roof_conv_ref:.4f}); probe chain (84-image launches): "
+                    f"{min_roof_probe:.4f}, {probe_ms_per_step:.3f} ms per step; ideal {ideal_ms_per_step:.3f} ms per step\n")
     if os.environ.get("FEDICRA_BENCH_VERBOSE"):
         top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:60]
         for k, v in top:
@@ -697,7 +828,7 @@ def main():
     ap.add_argument("--windows", type=int, default=5,
                     help="timed windows of --steps steps each, back to back after ONE warm-up; value = the median window")
     ap.add_argument("--no-dice", action="store_true", help="skip the Dice-vs-CPU-reference leg (config.dice)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
                     help="c3 (default): BASELINE configs[2], the configuration the metric is quoted on; c4: configs[3], the 3D path "
                          "(4 clients, unet_3D, 2x1x128^3 bf16) with the same JSON shape in volumes/s")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
@@ -715,6 +846,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode rate reported beside the headline")
+    ap.add_argument("--no-3d", action="store_true", help="skip the configs[3] / configs[4] legs (config.c4 / config.c5)")
+    ap.add_argument("--no-rccl", action="store_true",
+                    help="N = 1 only: do not create the single-rank RCCL process group through which the round's weighted "
+                         "all-reduce is issued (config.rccl_single_rank)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the instrumented eager iterations of the roofline object (the command rocprofv3 is pointed at "
                          "for profiles/*_roofline_kernel_stats.csv and the PMC traffic passes: same launch mix)")
@@ -725,6 +860,7 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(a))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from fedicra_amd.comm import init_process_group_from_env
     rank, local, world = init_process_group_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -735,7 +871,26 @@ def main():
 
     from fedicra_amd import _lib
     _lib.lib()
-    if a.workload == "c4":
+    # N = 1: the round's exchange still goes through RCCL -- a process group of ONE rank (the sum over one rank is the identity,
+    # the result is bit-identical to the no-group path: tests/test_round5_gpu.py), so that the communicator, the side stream,
+    # the event fence and their interplay with the captured steps execute on the one GPU the driver's N = 1 run has
+    a.rccl_single_rank, rccl_note = False, None
+    if world == 1 and a.workload == "c3" and not a.no_rccl and not a.roofline_only:
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            probe = torch.ones(8, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert float(probe.sum().item()) == 8.0
+            a.rccl_single_rank = True
+        except Exception as e:  # noqa: BLE001 -- the headline number must not depend on it; the line says what happened
+            rccl_note = repr(e)[:300]
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    if a.workload in ("c4", "c5"):
         main_c4(a, rank, local, world, dev, dist)
         if world > 1:
             dist.barrier()
@@ -794,6 +949,9 @@ def main():
                                    f"all timed",
                        "clients_hosted": world, "federation": FEDERATION, "global_batch": a.batch * world,
                        "images_per_sec_per_client": round(value / world, 2),
+                       "warmup_steps_run": fed.warmup_run,
+                       "warmup_note": "--warmup rounded up to whole rounds, at least two (captures of both freeze phases and of "
+                                      "the ALA epoch lie behind them)",
                        "value_is": f"median of {len(win_rates)} back-to-back timed windows of {a.steps} steps each",
                        "value_windows": win_rates, "value_min": min(win_rates), "value_max": max(win_rates),
                        "ms_per_aggregation_round": round(agg_ms, 3),
@@ -811,6 +969,13 @@ def main():
             line["config"].update({"rccl_ranks": world if fed.backend == "nccl" else 0, "dist_backend": fed.backend,
                                    "allreduce_us_per_round": round(split["collective"] * 1e3, 1),
                                    "overlap_hidden_ms": split["overlap_hidden"]})
+        else:
+            line["config"]["rccl_single_rank"] = {
+                "executed": bool(a.rccl_single_rank), "backend": dist.get_backend() if dist.is_initialized() else None,
+                "all_reduce_calls_issued": fed.agg.collectives_issued, "error": rccl_note,
+                "allreduce_us_per_round": round(split["collective"] * 1e3, 1),
+                "what": "the round's weighted all-reduce (flat fp32 state + int64 counters) issued through a ONE-rank RCCL "
+                        "process group on the side stream, event-fenced against the training stream, inside the timed rounds"}
         if not a.no_roofline:
             try:
                 roof = roofline_pass(fed.client, a, a.dtype)
@@ -819,10 +984,24 @@ def main():
                 tf = roof["conv_flops_per_step"] / step_s / 1e12          # same head : body mix on both sides of the ratio
                 line["config"]["conv_tflops_per_gpu"] = round(tf, 2)
                 line["config"]["frac_of_mfma_peak"] = round(tf / MFMA_PEAK[a.dtype], 4)
+                line["config"]["frac_of_mfma_peak_is"] = ("reference-defined conv FLOPs of a step / time of the TRAINING steps "
+                                                          "(the aggregation rounds' time excluded); whole-round figure beside it")
+                tf_round = roof["conv_flops_per_step"] * a.steps / elapsed / 1e12    # the ALA epoch's time in, its conv work not counted
+                line["config"]["frac_of_mfma_peak_whole_round"] = round(tf_round / MFMA_PEAK[a.dtype], 4)
                 line["config"]["executed_tflops_per_gpu"] = round(roof["executed_flops_per_step"] / step_s / 1e12, 2)
                 line["config"]["executed_frac_of_mfma_peak"] = round(roof["executed_flops_per_step"] / step_s / 1e12 / MFMA_PEAK[a.dtype], 4)
             except Exception as e:  # noqa: BLE001  (never lose the headline number to the instrumented pass)
                 line["roofline"] = {"error": repr(e)}
+        if world == 1 and not a.no_3d:
+            # configs[3] / configs[4] in front of the driver: short legs outside the c3 timed region, on the
+            # single-GPU line only (a multi-GPU launch measures the c3 federation's scaling and nothing else)
+            del fed
+            torch.cuda.empty_cache()
+            for kind in ("c4", "c5"):
+                try:
+                    line["config"][kind] = volumes_leg(a, rank, world, dev, dist, kind)
+                except Exception as e:  # noqa: BLE001
+                    line["config"][kind] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_dice:
             try:
                 line["config"]["dice"] = dice_leg(with_cpu=not a.no_cpu_baseline)
@@ -833,6 +1012,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

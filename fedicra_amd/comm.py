@@ -28,13 +28,17 @@ from .flower_common import DeviceWeights
 
 class WeightedAllReduce:
     def __init__(self, num_examples: int, device: Optional[torch.device] = None, group=None, constant_term=None,
-                 timing: bool = False):
+                 timing: bool = False, always_collective: bool = False):
         """`constant_term` = (DeviceWeights, n): a fixed contribution n * state to the weighted sum, added by rank 0 --
         clients of the federation that no rank hosts (bench.py with fewer GPUs than clients).  `timing`: HIP events on the
         side stream around pre-scale / all-reduce / divide and on the training stream around the fence (bench.py's round
-        split; `splits` collects one dict of event pairs per round)."""
+        split; `splits` collects one dict of event pairs per round).  `always_collective`: issue the two all-reduces even
+        when the process group has ONE rank (a sum over one rank is the identity, so the result is bit-identical to the
+        no-group path) -- the RCCL call path (communicator, side stream, event fence, its interplay with the captured
+        training step) then executes on a single MI355X: tests/test_round5_gpu.py and bench.py's N = 1 line."""
         self.group = group
         self.timing = bool(timing)
+        self.always_collective = bool(always_collective) and dist.is_initialized()
         self.splits = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -62,6 +66,7 @@ class WeightedAllReduce:
         self._cnt = None
         self._done = None
         self.counter_mean = None
+        self.collectives_issued = 0                            # all-reduce calls handed to torch.distributed so far
 
     # ---------------------------------------------------------------------------------------------
     def start(self, weights):
@@ -90,9 +95,10 @@ class WeightedAllReduce:
                     self._cnt.add_(self.constant[0].counters, alpha=self.constant[1])
                 if ev:
                     ev[1].record(self.side)
-                if self.world > 1:
+                if self.world > 1 or self.always_collective:
                     dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                     dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
+                    self.collectives_issued += 2
                 if ev:
                     ev[2].record(self.side)
                 L.scale(self._send, self._send, float(self.total), divide=True)
@@ -110,9 +116,10 @@ class WeightedAllReduce:
             if self.constant is not None:
                 self._send.add_(self.constant[0].state * float(self.constant[1]))
                 self._cnt.add_(self.constant[0].counters, alpha=self.constant[1])
-            if self.world > 1:
+            if self.world > 1 or self.always_collective:
                 dist.all_reduce(self._send, op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)
+                self.collectives_issued += 2
             self._send.div_(float(self.total))
 
     def finish(self) -> DeviceWeights:

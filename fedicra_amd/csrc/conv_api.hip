@@ -671,6 +671,7 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   if (d->c1 > 0 && !x1) return FI_ERR_NULL;
   const int cin = (depth > 0 ? 3 : 1) * (d->c0 + d->c1), cout = d->co0;
   if (!workspace) p.rows = 0;                               // (atomic accumulation: the tile kernels)
+  const int sb_tile = p.sb;                                 // slices of the tile kernels' plan: what a declined rows launch falls back to
   if (p.rows) p.sb = p.sb_rows;
   if (workspace && workspace_bytes < (long)(p.part_stride * p.sb * sizeof(float))) return FI_ERR_SHAPE;
   WgradArgs a;
@@ -697,7 +698,7 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
   a.trace = g_trace;
 #endif
   hipStream_t st = (hipStream_t)stream;
-  int r;
+  int r = FI_ERR_UNSUPPORTED;
   if (p.rows) {
     WgRowsArgs ra;
     ra.x0 = x0, ra.x1 = x1 ? x1 : x0, ra.dy = dy;
@@ -718,6 +719,17 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
     else
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_f16(cin / 16, cout / 16, ra, p.sb, st)
                              : fi_conv_wgrad_rows_bf16(cin / 16, cout / 16, ra, p.sb, st);
+    if (r == FI_ERR_UNSUPPORTED) {
+      // a row-streaming launcher declined (LDS beyond what the device grants: ADVICE r4): nothing was launched -- the tile
+      // kernels' plan takes the layer (its slice count fits the same workspace: fi_conv2d_wgrad_workspace sizes for both)
+      p.rows = 0;
+      p.sb = sb_tile;
+      a.spatialBlocks = sb_tile;
+      if (workspace && workspace_bytes < (long)(p.part_stride * p.sb * sizeof(float))) return FI_ERR_SHAPE;
+    }
+  }
+  if (p.rows) {
+    // (launched above)
   } else if (p.quad) {
     if (d->dtype == FI_F32)
       r = d->ksize == 3 ? fi_conv_wgrad_quad_f32_k3(p.th, a, st) : fi_conv_wgrad_quad_f32_k1(p.th, a, st);

@@ -285,6 +285,9 @@ static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st
   size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)4 * NCO * a.ws * 32;
   const size_t red = (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
   if (lds < red) lds = red;
+  // more than 64 KB (NCI = 2 at 256-wide strips: 65 792 B) must be allowed per kernel, like every other big-LDS launcher
+  static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<T, NCI, NCO, NARROW>));
+  if (lds > 160 * 1024 || (lds > 64 * 1024 && !allowed)) return FI_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCI, NCO, NARROW>), dim3((unsigned)items), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
@@ -474,6 +477,8 @@ static int launch_conv_wgrad_rows3d(const WgRowsArgs& a, int items, hipStream_t 
   size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)12 * a.ws * 32;
   const size_t red = (size_t)(27 * NCI * 256 + 16) * sizeof(float);
   if (lds < red) lds = red;
+  static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows3d_kernel<T, NCI, MAXW>));
+  if (lds > 160 * 1024 || (lds > 64 * 1024 && !allowed)) return FI_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)items), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;

@@ -39,6 +39,20 @@ class _Resident:
         return self.images.shape[0]
 
 
+_h5mini_noted = False
+
+
+def _note_h5mini():
+    """Said once per process: the data files are read by the bundled subset decoder, not by h5py."""
+    global _h5mini_noted
+    if not _h5mini_noted:
+        _h5mini_noted = True
+        import logging
+        logging.getLogger("fedicra_amd").warning(
+            "h5py is not installed: reading the HDF5 data files with the bundled read-only subset decoder "
+            "(fedicra_amd.dataloaders.h5mini; anything outside the subset raises H5Error)")
+
+
 class BaseDataSets:
     """dataset.py:63-187.  ``data_list`` holds ``{'image', 'label'}`` numpy pairs exactly like the reference; train
     labels come from ``sup_type`` (e.g. 'scribble'), validation labels from 'mask' (:86-96)."""
@@ -56,6 +70,7 @@ class BaseDataSets:
             import h5py as h5
         except ImportError:                                        # this image: the bundled decoder of the files' HDF5
             from . import h5mini as h5                             # subset (raises H5Error on anything outside it)
+            _note_h5mini()
         for case in self.sample_list:
             with h5.File(self._base_dir + "/{}".format(case), "r") as h5f:
                 image = h5f["image"][:]

@@ -31,20 +31,47 @@ class H5Error(ValueError):
     """The file uses an HDF5 feature outside the subset above, or is damaged."""
 
 
+_MAX_NODES = 1 << 20          # B-tree / continuation blocks visited per object: far above any real file, bounds a damaged one
+
+
 def _u(b, o, n):
     if o < 0 or o + n > len(b):
         raise H5Error("read of {} bytes at {} past the end of the file ({} bytes)".format(n, o, len(b)))
     return int.from_bytes(b[o:o + n], "little")
 
 
+def _span(b, o, n):
+    """b[o:o+n], bounds-checked (a plain slice silently shortens, a plain index raises IndexError)."""
+    if o < 0 or n < 0 or o + n > len(b):
+        raise H5Error("read of {} bytes at {} past the end of the file ({} bytes)".format(n, o, len(b)))
+    return b[o:o + n]
+
+
+def _guard(fn):
+    """Whatever a damaged file makes the decoder trip over surfaces as H5Error -- the promise of the module docstring."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except H5Error:
+            raise
+        except (IndexError, ValueError, OverflowError, MemoryError, zlib.error, UnicodeDecodeError) as e:
+            raise H5Error("damaged or unsupported HDF5 structure: {}: {}".format(type(e).__name__, e)) from e
+    return wrapped
+
+
 class Dataset:
     """One data set: ``shape``, ``dtype`` and numpy-style reads of the whole array (``ds[:]``, ``ds[()]``, ``ds[...]``;
     any other index is applied to the decoded array)."""
 
+    @_guard
     def __init__(self, f, name, addr):
         self._f, self.name = f, name
         self.shape = self.dtype = self._layout = None
         self._filters = []
+        self._cache = None
         for mtype, m in f._messages(addr):
             if mtype == 0x0001:
                 self.shape = self._dataspace(m)
@@ -128,6 +155,7 @@ class Dataset:
                 raw = a[:nel * es].reshape(es, nel).T.tobytes() + a[nel * es:].tobytes()
         return raw
 
+    @_guard
     def _read(self):
         b, shape, dtype = self._f._b, self.shape, self.dtype
         count = int(np.prod(shape, dtype=np.int64)) if shape else 1
@@ -151,12 +179,15 @@ class Dataset:
         if root == _UNDEF:
             return out
         key = 8 + 8 * (rank + 1)                                 # chunk size, filter mask, rank+1 offsets
-        todo = [root]
+        todo, seen = [root], set()
         while todo:
             addr = todo.pop()
-            if b[addr:addr + 4] != b"TREE" or b[addr + 4] != 1:
+            if addr in seen or len(seen) >= _MAX_NODES:          # a cyclic (damaged) tree must not loop forever
+                raise H5Error("chunk B-tree of '{}' revisits node {} (cyclic or oversized)".format(self.name, addr))
+            seen.add(addr)
+            if _span(b, addr, 4) != b"TREE" or _u(b, addr + 4, 1) != 1:
                 raise H5Error("chunk B-tree node expected at {}".format(addr))
-            level, n = b[addr + 5], _u(b, addr + 6, 2)
+            level, n = _u(b, addr + 5, 1), _u(b, addr + 6, 2)
             p = addr + 24
             for _ in range(n):
                 csize, mask = _u(b, p, 4), _u(b, p + 4, 4)
@@ -168,7 +199,7 @@ class Dataset:
                     continue
                 if child + csize > len(b):
                     raise H5Error("chunk of '{}' runs past the end of the file".format(self.name))
-                raw = self._unfilter(b[child:child + csize], mask)
+                raw = self._unfilter(_span(b, child, csize), mask)
                 if len(raw) < ccount * dtype.itemsize:
                     raise H5Error("chunk of '{}' decodes to {} bytes, {} expected".format(
                         self.name, len(raw), ccount * dtype.itemsize))
@@ -178,7 +209,9 @@ class Dataset:
         return out
 
     def __getitem__(self, index):
-        a = self._read()
+        if self._cache is None:                                  # decoded once per Dataset object (h5py hands out fresh arrays:
+            self._cache = self._read()                           # so does this -- copies of the cached decode)
+        a = self._cache.copy()
         whole = index is Ellipsis or (isinstance(index, tuple) and not index) or \
             (isinstance(index, slice) and index == slice(None))
         if whole:
@@ -192,6 +225,7 @@ class Dataset:
 class File:
     """``File(path, 'r')``: the root group's data sets by name (``f['image']``, ``'mask' in f``, ``f.keys()``)."""
 
+    @_guard
     def __init__(self, path, mode="r"):
         if mode != "r":
             raise H5Error("h5mini only reads (mode 'r'), got mode {!r}".format(mode))
@@ -200,9 +234,9 @@ class File:
         self.filename = path
         if b[:8] != _SIG:
             raise H5Error("{}: no HDF5 signature at offset 0".format(path))
-        if b[8] != 0:
+        if _u(b, 8, 1) != 0:
             raise H5Error("{}: superblock version {} (only version 0 is decoded)".format(path, b[8]))
-        if (b[13], b[14]) != (8, 8):
+        if (_u(b, 13, 1), _u(b, 14, 1)) != (8, 8):
             raise H5Error("{}: {}-byte offsets / {}-byte lengths (only 8 / 8)".format(path, b[13], b[14]))
         if _u(b, 24, 8) != 0:
             raise H5Error("{}: non-zero base address".format(path))
@@ -235,21 +269,27 @@ class File:
                     e["btree"], e["heap"] = _u(m, 0, 8), _u(m, 8, 8)
         if "btree" not in e:
             raise H5Error("{}: the root group has no symbol table (new-style groups are not decoded)".format(self.filename))
-        if b[e["heap"]:e["heap"] + 4] != b"HEAP":
+        if _span(b, e["heap"], 4) != b"HEAP":
             raise H5Error("local heap expected at {}".format(e["heap"]))
         names = _u(b, e["heap"] + 24, 8)                         # address of the heap's data segment
-        links, todo = {}, [e["btree"]]
+        links, todo, seen = {}, [e["btree"]], set()
         while todo:
             addr = todo.pop()
-            if b[addr:addr + 4] == b"SNOD":
+            if addr in seen or len(seen) >= _MAX_NODES:          # a cyclic (damaged) tree must not loop forever
+                raise H5Error("group B-tree revisits node {} (cyclic or oversized)".format(addr))
+            seen.add(addr)
+            if _span(b, addr, 4) == b"SNOD":
                 for i in range(_u(b, addr + 6, 2)):
                     s = self._entry(addr + 8 + 40 * i)
                     start = names + s["name"]
-                    links[b[start:b.index(b"\0", start)].decode("utf-8")] = s["header"]
+                    end = b.find(b"\0", start) if 0 <= start < len(b) else -1
+                    if end < 0:
+                        raise H5Error("link name at {} is not terminated".format(start))
+                    links[b[start:end].decode("utf-8")] = s["header"]
                 continue
-            if b[addr:addr + 4] != b"TREE" or b[addr + 4] != 0:
+            if _span(b, addr, 4) != b"TREE" or _u(b, addr + 4, 1) != 0:
                 raise H5Error("group B-tree node expected at {}".format(addr))
-            level, n = b[addr + 5], _u(b, addr + 6, 2)
+            level, n = _u(b, addr + 5, 1), _u(b, addr + 6, 2)
             for i in range(n):                                   # key0 child0 key1 child1 ... : children at odd slots
                 child = _u(b, addr + 24 + 16 * i + 8, 8)
                 todo.append(child)                               # level 0 children are symbol-table nodes
@@ -259,18 +299,21 @@ class File:
     def _messages(self, addr):
         """(type, body) of every message of a version-1 object header, following continuation blocks."""
         b = self._b
-        if b[addr:addr + 4] == b"OHDR":
+        if _span(b, addr, 4) == b"OHDR":
             raise H5Error("version-2 object header at {} (only version 1 is decoded)".format(addr))
-        if b[addr] != 1:
+        if _u(b, addr, 1) != 1:
             raise H5Error("object header version {} at {}".format(b[addr], addr))
         total, out = _u(b, addr + 2, 2), []
-        blocks = [(addr + 16, _u(b, addr + 8, 4))]
+        blocks, seen = [(addr + 16, _u(b, addr + 8, 4))], set()
         while blocks and len(out) < total:
             p, size = blocks.pop(0)
+            if p in seen or len(seen) >= _MAX_NODES:             # continuation blocks that point back at each other
+                raise H5Error("object header at {} revisits continuation block {}".format(addr, p))
+            seen.add(p)
             end = p + size
             while p + 8 <= end and len(out) < total:
                 mtype, msize = _u(b, p, 2), _u(b, p + 2, 2)
-                body = b[p + 8:p + 8 + msize]
+                body = _span(b, p + 8, msize)
                 if mtype == 0x0010:
                     blocks.append((_u(body, 0, 8), _u(body, 8, 8)))
                 out.append((mtype, body))
@@ -289,6 +332,7 @@ class File:
     def __len__(self):
         return len(self._links)
 
+    @_guard
     def __getitem__(self, name):
         if name not in self._links:
             raise KeyError("Unable to open object (object '{}' doesn't exist)".format(name))

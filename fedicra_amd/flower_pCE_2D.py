@@ -110,15 +110,18 @@ class MyClient(BaseClient):
         get = getattr(self.model, "batch_stager", None)
         return get() if callable(get) and self._net().flat_state.is_cuda else None
 
-    def _prefetch_next(self, last=False):
+    def _prefetch_next(self, last=False, ala_expected=True):
         """Start the host -> device copy of the batch the NEXT iteration will take (flower_pCE_2D.py:66-73: same epoch
         list) while this one runs -- the next round's first iteration included.  At an epoch boundary the list is rebuilt
-        first: only a list-like trainloader (whose next epoch is known) is looked into, otherwise that copy is serial."""
+        first: only a list-like trainloader (whose next epoch is known) is looked into, otherwise that copy is serial.
+        `ala_expected`: the set_weights that follows the round will run its ALA epoch (FedICRA and iter_global > 50,
+        flower_common.py:524-526); when it will not, the epoch's batches are NOT sent ahead (they would cross PCIe for
+        nothing and pin ring pairs -- ADVICE r4) and the next round's first batch is prefetched as after any iteration."""
         stager = self._stager()
         n_b = len(self.trainloader)
         if stager is None or not self.sampled_batches:
             return
-        if last and self.args.strategy in ["FedICRA"] and isinstance(self.trainloader, (list, tuple)):
+        if last and ala_expected and self.args.strategy in ["FedICRA"] and isinstance(self.trainloader, (list, tuple)):
             # the round's last iteration is enqueued: what follows is set_weights with its ALA epoch over the whole loader
             # (flower_common.py:566-602) -- its batches cross PCIe now, beside the iterations the GPU still has queued, like a
             # DataLoader's workers run ahead (flower_pCE_2D.py:303-304); the first batch of the NEXT round is announced too
@@ -319,7 +322,7 @@ class MyClient(BaseClient):
                 self.current_iter += 1
                 lr_ = args.base_lr * (1.0 - self.current_iter / args.max_iterations) ** 0.9      # :154 (host mirror)
                 self.current_lr = lr_
-                self._prefetch_next(last=(i_iter == iters - 1))
+                self._prefetch_next(last=(i_iter == iters - 1), ala_expected=config.get("iter_global", 51) > 50)
             yield i_iter
         with self._scope():
             return self._round_result(hist, x, y, rec)

@@ -716,6 +716,13 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
     coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
     L.bn_finalize(stats, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                   bn.momentum, bn.eps, True, coef[0], coef[1], coef[2], coef[3])
+    if _ctx.bn_events is not None:
+        # the own forward's statistics-only head (aux="stats") has moved this BatchNorm's running statistics: the batched LC
+        # forwards on the second stream order THEIR update of the same layer behind this event (probe_after), exactly as
+        # behind a full _ConvBNAct layer -- without it the two read-modify-writes were unordered
+        ev = torch.cuda.Event()
+        ev.record()
+        _ctx.bn_events[id(bn)] = ev
 
 
 # ----------------------------------------------------------------------------- fused probe forward

@@ -161,12 +161,17 @@ _const_cache = {}
 
 def _norm_consts(cout, dev):
     """(ones, zeros, running-mean scratch, running-var scratch) of an affine-free InstanceNorm: the same four vectors for every
-    layer of that width (momentum 0 leaves the scratch statistics as they are) -- four fill launches per convolution otherwise."""
-    key = (dev.index, cout, torch.cuda.is_current_stream_capturing())
+    layer of that width (momentum 0 leaves the scratch statistics as they are) -- four fill launches per convolution otherwise.
+    Cached per (device, width) and only when created EAGERLY: tensors first made inside a stream capture live in that graph's
+    private pool and their fills are merely recorded, so another graph must not find them in a process-global cache (ADVICE
+    r4) -- a capture without an eager warm-up before it makes its own, uncached."""
+    key = (dev.index, cout)
     c = _const_cache.get(key)
     if c is None:
-        c = _const_cache[key] = (torch.ones(cout, device=dev), torch.zeros(cout, device=dev), torch.zeros(cout, device=dev),
-                                 torch.ones(cout, device=dev))
+        c = (torch.ones(cout, device=dev), torch.zeros(cout, device=dev), torch.zeros(cout, device=dev),
+             torch.ones(cout, device=dev))
+        if not torch.cuda.is_current_stream_capturing():
+            _const_cache[key] = c
     return c
 
 

@@ -3,6 +3,38 @@ import numpy as np
 import torch
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests on 127.0.0.1)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def communicate_all(procs, timeout=240):
+    """stdout of every rank process; if ANY of them is still running after `timeout` seconds, ALL are killed (a rank that
+    waits in a rendezvous or a collective for a dead peer would otherwise outlive the test and hang the suite)."""
+    import subprocess
+    import time
+    deadline = time.monotonic() + timeout
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=max(1.0, deadline - time.monotonic()))[0].decode())
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        tails = []
+        for p in procs:
+            try:
+                tails.append((p.communicate(timeout=10)[0] or b"").decode()[-2000:])
+            except Exception:  # noqa: BLE001
+                tails.append("<no output>")
+        raise AssertionError(f"rank processes still running after {timeout} s (killed); output tails: {tails}")
+    return outs
+
+
 def checksum(t) -> np.ndarray:
     a = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64).ravel()
     idx = np.linspace(0, a.size - 1, 16).astype(np.int64)

@@ -115,6 +115,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
+@pytest.mark.timeout(300)
 def test_weighted_allreduce_with_colocated_clients_gloo(tmp_path):
     """2 processes x 2 clients each: sum_k n_k w_k over the co-located clients, all-reduce, / sum of all n_k = flwr's
     weighted mean over the 4 clients."""
@@ -122,10 +123,11 @@ def test_weighted_allreduce_with_colocated_clients_gloo(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "w.py"
     script.write_text(_COLOC_WORKER)
-    port = str(30500 + os.getpid() % 1000)
+    from helpers import communicate_all, free_port
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), root, str(r), "2", port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    outs = communicate_all(procs, timeout=240)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
 

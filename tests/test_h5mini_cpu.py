@@ -73,8 +73,55 @@ def test_unsupported_and_damaged_files_raise(tmp_path):
         addr = ds._layout[1]
     hit = raw.index(b"\x78", addr + 200)                           # the first zlib header after the chunk B-tree node
     bad.write_bytes(raw[:hit + 8] + bytes(64) + raw[hit + 72:])
-    with pytest.raises(Exception):
+    with pytest.raises(h5mini.H5Error):
         h5mini.File(str(bad))["image"][:]
+
+
+def test_damaged_files_raise_h5error_only_and_never_hang(tmp_path):
+    """every byte read of the decoder is bounds-checked and B-tree / continuation walks are bounded, so a damaged
+    file ends in H5Error (or decodes) -- never IndexError / ValueError from a raw index, never an endless loop: a chunk
+    B-tree node that lists ITSELF as its child, and 300 files with 24 random bytes overwritten in the metadata region."""
+    src = os.path.join(GOLD, "h5", "faz_test_10280.h5")
+    raw = bytearray(open(src, "rb").read())
+    bad = tmp_path / "bad.h5"
+    with h5mini.File(src) as f:
+        root = f["image"]._layout[1]
+        rank = len(f["image"].shape)
+    node = bytearray(raw)
+    node[root + 5] = 1                                              # an interior node ...
+    node[root + 6:root + 8] = (1).to_bytes(2, "little")             # ... with one entry ...
+    key = 8 + 8 * (rank + 1)
+    node[root + 24 + key:root + 24 + key + 8] = int(root).to_bytes(8, "little")     # ... whose first child is itself
+    bad.write_bytes(bytes(node))
+    with pytest.raises(h5mini.H5Error, match="revisits"):
+        h5mini.File(str(bad))["image"][:]
+    rng = np.random.default_rng(7)
+    decoded = failed = 0
+    for trial in range(300):
+        b = bytearray(raw)
+        lim = min(len(b), 6000)                                     # superblock, group tree, heap, object headers live here
+        for pos in rng.integers(8, lim, 24):
+            b[pos] = int(rng.integers(0, 256))
+        bad.write_bytes(bytes(b))
+        try:
+            with h5mini.File(str(bad)) as f:
+                for k in f.keys():
+                    f[k][:]
+            decoded += 1
+        except (h5mini.H5Error, KeyError):
+            failed += 1
+    assert decoded + failed == 300 and failed > 0
+
+
+def test_dataset_decodes_once_and_hands_out_copies():
+    src = os.path.join(GOLD, "h5", "faz_test_10280.h5")
+    with h5mini.File(src) as f:
+        ds = f["image"]
+        a = ds[:]
+        a[...] = 0
+        b = ds[:]
+        assert ds._cache is not None and b.any() and b is not ds._cache
+        np.testing.assert_array_equal(ds[2:5], b[2:5])
 
 
 def test_base_datasets_reads_the_reference_layout(tmp_path, monkeypatch):

@@ -194,6 +194,7 @@ print("rank", rank, "ok")
 '''
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 3])
 def test_weighted_allreduce_gloo_multiprocess(tmp_path, world):
     script = tmp_path / "w.py"
@@ -201,7 +202,8 @@ def test_weighted_allreduce_gloo_multiprocess(tmp_path, world):
     port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(world)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    from helpers import communicate_all
+    outs = communicate_all(procs, timeout=240)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
 
@@ -393,6 +395,7 @@ def _const_term_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)
 def test_weighted_allreduce_constant_term_counts_the_clients_no_rank_hosts():
     """bench.py with fewer GPUs than the federation has clients: the absent clients' n_k * state enters the weighted sum
     once (rank 0 adds it), the total weight includes them, every rank gets the same mean (world_size 2, gloo)."""
@@ -404,9 +407,13 @@ def test_weighted_allreduce_constant_term_counts_the_clients_no_rank_hosts():
     ps = [ctx.Process(target=_const_term_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
-    for p in ps:
-        p.join(timeout=60)
+    try:
+        res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    finally:
+        for p in ps:
+            p.join(timeout=60)
+            if p.is_alive():                                 # a rank stuck in the rendezvous must not outlive the test
+                p.kill()
     base = torch.arange(6, dtype=torch.float32)
     want = (3 * base + 5 * (base + 10) + 2 * 100.0) / 10
     want_c = ((torch.tensor([1, 7]) * 3 + torch.tensor([2, 7]) * 5 + torch.tensor([4, 4]) * 2).double() / 10).to(torch.int64)

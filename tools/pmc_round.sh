@@ -11,5 +11,5 @@ done
 rm -rf /tmp/pmc_MFMA
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace -d /tmp/pmc_MFMA -- python $ROOT/bench.py $ARGS > /tmp/pmc_MFMA.log 2>&1
 python $ROOT/tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1) \
-    "$ARGS" "${KEY:-c3-unet_lc-12x3x512-bf16}" $(find /tmp/pmc_MFMA -name "*.db" | head -1) > $OUT/${TAG}_pmc_traffic.json
+    "$ARGS" "${KEY:-c3-unet_lc-12x3x512-bf16}" $(find /tmp/pmc_MFMA -name "*.db" | head -1) /tmp/pmc_FETCH_SIZE.log > $OUT/${TAG}_pmc_traffic.json
 head -c 1500 $OUT/${TAG}_pmc_traffic.json

@@ -2,7 +2,11 @@
 """HBM bytes per launch and kernel family from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as
 MI355X_MICROARCH.md prescribes).  Both counters are in KB; FETCH_SIZE is doubled on gfx950 (tools/pmc_cal.py: a 512 MiB
 coalesced read reports 262200 KB), WRITE_SIZE is taken as reported.
-    pmc_traffic.py fetch_results.db write_results.db ["bench args" [workload_key [mfma_results.db]]] > profiles/<tag>_pmc_traffic.json
+    pmc_traffic.py fetch_results.db write_results.db ["bench args" [workload_key [mfma_results.db [bench_stdout.log]]]] > profiles/<tag>_pmc_traffic.json
+`bench_stdout.log` = the stdout of the counted process (`bench.py --roofline-only` prints roofline.process_totals: launches and
+ALGORITHMIC bytes per family over every launch of the process): with it each family also gets hbm_bytes_total,
+algorithmic_bytes_total and traffic_over_algorithmic = the ratio of the two TOTALS over the same launch population (round 5;
+the per-launch means of a counter pass and of bench.py's 10 instrumented iterations are different head : body mixes).
 A third pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 in ONE run) adds the matrix
 pipe's busy share per family: mfma_busy_pct = 100 x sum(SQ_VALU_MFMA_BUSY_CYCLES) / (4 SIMDs x sum(SQ_BUSY_CU_CYCLES-equivalent))
 -- see `mfma()` for the normalisation actually used on this stack.  The json records the kernel-source hash of the tree it
@@ -91,8 +95,23 @@ def mfma(path):
     return out
 
 
-def main(fetch_db, write_db, bench_args="", key="c3-unet_lc-12x3x512-bf16", mfma_db=None):
+def process_totals(log_path):
+    """roofline.process_totals of the counted process, from its stdout (the last line that parses as the bench's JSON)."""
+    if not log_path or not os.path.exists(log_path):
+        return {}
+    for ln in reversed(open(log_path, errors="replace").read().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and "process_totals" in ln:
+            try:
+                return json.loads(ln)["roofline"]["process_totals"]
+            except (ValueError, KeyError):
+                continue
+    return {}
+
+
+def main(fetch_db, write_db, bench_args="", key="c3-unet_lc-12x3x512-bf16", mfma_db=None, bench_log=None):
     rd, wr = collect(fetch_db, "FETCH_SIZE"), collect(write_db, "WRITE_SIZE")
+    totals = process_totals(bench_log)
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
                      + bench_args + "; 1x MI355X (tools/pmc_round.sh)",
            "workload_key": key, "source_hash": _source_hash(),
@@ -106,6 +125,15 @@ def main(fetch_db, write_db, bench_args="", key="c3-unet_lc-12x3x512-bf16", mfma
         w = kbw * 1024.0 / nw if nw else 0.0
         out["families"][fam] = {"launches": n, "hbm_read_bytes_per_launch": int(r), "hbm_write_bytes_per_launch": int(w),
                                 "hbm_bytes_per_launch": int(r + w), "avg_us_under_pmc": round(dur / n / 1e3, 2)}
+        t = totals.get(fam)
+        if t and t.get("algorithmic_bytes"):
+            hbm_total = 2.0 * kb * 1024.0 + kbw * 1024.0
+            out["families"][fam].update({
+                "hbm_bytes_total": int(hbm_total), "algorithmic_bytes_total": int(t["algorithmic_bytes"]),
+                "algorithmic_launches": int(t["launches"]),
+                "traffic_over_algorithmic": round(hbm_total / t["algorithmic_bytes"], 4),
+                "population": f"every launch of the counted process: {n} dispatches counted (read pass), {nw} (write pass), "
+                              f"{int(t['launches'])} C-ABI launches priced -- totals over totals, same process"})
     if mfma_db:
         out["mfma_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 "
                               "--kernel-trace (its own pass)")
