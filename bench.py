@@ -56,6 +56,28 @@ MFMA_PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # TFLOP/s dense (g
 FEDERATION = 8                   # configs[2]: 8 clients
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on C stdout when its first communicator comes up (buffered: it used to surface at process
+    exit, BEHIND the JSON line).  stdout carries exactly ONE line -- the result -- so file descriptor 1 points at stderr while a
+    communicator is created, and the C streams are flushed before it is pointed back."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def make_args(a, cid):
     return argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=cid, min_num_clients=FEDERATION,
                               num_classes=a.classes, img_class="faz" if a.in_chns == 1 else "odoc", base_lr=0.01,
@@ -114,8 +136,9 @@ class Federation:
             self.backend = dist.get_backend()
             if not os.environ.get("FEDICRA_DIST_BACKEND"):          # (test hook: several ranks on one GPU through gloo)
                 assert self.backend == "nccl", f"multi-GPU bench must exchange over RCCL, got backend {self.backend!r}"
-            dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
-            torch.cuda.synchronize()
+            with _stdout_to_stderr():
+                dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
+                torch.cuda.synchronize()
         self.iter_global = 60                            # > 50: the ALA branch runs (flower_common.py:524-526)
         self.agg_events = []
         self.train_events = []
@@ -260,8 +283,9 @@ class Volumes:
             self.backend = dist.get_backend()
             if not os.environ.get("FEDICRA_DIST_BACKEND"):
                 assert self.backend == "nccl", f"multi-GPU bench must exchange over RCCL, got backend {self.backend!r}"
-            dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
-            torch.cuda.synchronize()
+            with _stdout_to_stderr():
+                dist.all_reduce(torch.zeros(1, device=dev if self.backend == "nccl" else "cpu"))
+                torch.cuda.synchronize()
         self.it = 0
         self.agg_events = []
         self.graphs, self.graph_error = {}, None
@@ -861,6 +885,10 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(a))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a rank drives five HIP streams once a communicator exists (training, LC forwards, batch staging, aggregation, RCCL's own):
+    # on the runtime's default four hardware queues two of them share one and serialise (same box, ALA epoch 20.6 ms with four,
+    # 20.0 with eight) -- read when the runtime comes up, i.e. at the first device call below
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from fedicra_amd.comm import init_process_group_from_env
     rank, local, world = init_process_group_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -880,10 +908,11 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-            probe = torch.ones(8, device=dev)
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
+            with _stdout_to_stderr():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+                probe = torch.ones(8, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
             assert float(probe.sum().item()) == 8.0
             a.rccl_single_rank = True
         except Exception as e:  # noqa: BLE001 -- the headline number must not depend on it; the line says what happened
@@ -1009,11 +1038,13 @@ def main():
                 line["config"]["dice"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a)
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
-        dist.destroy_process_group()
+        with _stdout_to_stderr():                        # (whatever the communicator says on its way out is not the result)
+            dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)              # the ONE line of stdout, and the last thing written to it
 
 
 if __name__ == "__main__":

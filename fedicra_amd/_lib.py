@@ -29,6 +29,7 @@ EXPORTS = [
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
     "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning", "fi_pack_weights3d_multi",
+    "fi_bn_running_groups_multi",
 ]
 
 
@@ -60,7 +61,7 @@ class FiError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 3             # include/fedicra_hip.h FI_ABI_VERSION
+ABI_VERSION = 4             # include/fedicra_hip.h FI_ABI_VERSION
 
 
 def source_hash():
@@ -376,6 +377,25 @@ def bn_act_pool_groups(y, coef, slope, z, groups, pool=True):
     with _timed("bn_act_pool" if pool else "bn_act_groups", (str(y.dtype)[6:], N, Hi, Wi, Cc), 0.0, y.numel() * _esz(y) + z.numel() * _esz(z)):
         _chk(lib().fi_bn_act_pool_groups(dt(y.dtype), ptr(y), ptr(coef[0]), ptr(coef[1]), C.c_float(slope), ptr(z), N, Ho, Wo, Cc,
                                          N // groups, int(bool(pool)), stream()), "fi_bn_act_pool_groups")
+
+
+class FiBnRunItem(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("stats_group_stride", C.c_long), ("count", C.c_double), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("groups", C.c_int),
+                ("C", C.c_int)]
+
+
+def bn_running_groups_multi(items):
+    """items: [(stats, groups, count, rmean, rvar, nbt, momentum, shared)] -- the running-statistics half of
+    bn_finalize_groups for every listed BatchNorm in one launch (per 32 layers)."""
+    if not items:
+        return
+    arr = (FiBnRunItem * len(items))()
+    for k, (stats, groups, count, rmean, rvar, nbt, momentum, shared) in enumerate(items):
+        _dev(stats)
+        arr[k] = FiBnRunItem(stats.data_ptr(), 0 if shared else stats.numel() // groups, float(count), rmean.data_ptr(),
+                             rvar.data_ptr(), 0 if nbt is None else nbt.data_ptr(), float(momentum), int(groups), rmean.numel())
+    _chk(lib().fi_bn_running_groups_multi(arr, len(items), stream()), "fi_bn_running_groups_multi")
 
 
 def bn_finalize_groups(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, shared=False):

@@ -118,6 +118,9 @@ extern "C" int fi_bn_finalize(const double* stats, double count, const float* ga
 __global__ void bn_finalize_groups_kernel(const double* stats, long gstride, int G, double count, const float* gamma,
                                           const float* beta, float* rmean, float* rvar, int64_t* nbt, float momentum,
                                           float eps, float* coef, int C) {
+  // rmean == NULL: coefficients only; coef == NULL: running statistics (and the counter) only -- the two halves of one call, with
+  // the arithmetic of the whole: a caller that must ORDER the running-statistics update behind another stream's work makes it
+  // later, on that stream, and still has the coefficients at once (ops.probe_conv_bn, flower_pCE_2D._iteration)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) nbt[0] += G;
   if (c >= C) return;
@@ -135,21 +138,71 @@ __global__ void bn_finalize_groups_kernel(const double* stats, long gstride, int
     const float mu = (float)m;
     const float istd = (float)(1.0 / sqrt(var + (double)eps));
     const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    bn_running_update(rmean, rvar, c, momentum, mu, (float)unb);
-    const float sc = ga * istd;
-    coef[(size_t)g * C + c] = sc;
-    coef[(size_t)(G + g) * C + c] = be - mu * sc;
+    if (rmean) bn_running_update(rmean, rvar, c, momentum, mu, (float)unb);
+    if (coef) {
+      const float sc = ga * istd;
+      coef[(size_t)g * C + c] = sc;
+      coef[(size_t)(G + g) * C + c] = be - mu * sc;
+    }
   }
 }
 
 extern "C" int fi_bn_finalize_groups(const double* stats, long stats_group_stride, int groups, double count,
                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                                      int64_t* nbt, float momentum, float eps, float* coef, int C, void* stream) {
-  if (!stats || !gamma || !beta || !running_mean || !running_var || !coef) return FI_ERR_NULL;
+  if (!stats || !gamma || !beta || (!running_mean != !running_var) || (!running_mean && !coef)) return FI_ERR_NULL;
+  if (!running_mean) nbt = nullptr;                        // coefficients only: nothing of the module's state moves
   if (groups < 1 || C < 1) return FI_ERR_SHAPE;
   hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(fi_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats,
                      stats_group_stride, groups, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, coef, C);
   FI_CHECK_LAUNCH();
+  return 0;
+}
+
+// The running-statistics half of fi_bn_finalize_groups for SEVERAL BatchNorm layers in one launch: what the batched LC
+// forwards leave to the training stream (ops._probe_finalize: 19 layers per iteration) would otherwise be 19 dependent launches
+// of a few microseconds each right before the optimizer step.  Items travel by value in the kernel argument (no device table
+// to build or keep alive under graph capture); blockIdx.y = item, the arithmetic and its order are bn_finalize_groups_kernel's.
+struct FiBnRunPack {
+  FiBnRunItem it[FI_BN_RUN_MAX];
+};
+
+__global__ void bn_running_groups_multi_kernel(FiBnRunPack p) {
+  const FiBnRunItem& q = p.it[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && q.num_batches_tracked) q.num_batches_tracked[0] += q.groups;
+  if (c >= q.C) return;
+  for (int g = 0; g < q.groups; ++g) {
+    const double* st = q.stats + (size_t)g * q.stats_group_stride;
+    double s1 = 0.0, s2 = 0.0;
+    for (int slot = 0; slot < FI_STATS_SLOTS; ++slot) {
+      s1 += st[((size_t)slot * q.C + c) * 2];
+      s2 += st[((size_t)slot * q.C + c) * 2 + 1];
+    }
+    const double m = s1 / q.count;
+    double var = s2 / q.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double unb = q.count > 1.0 ? var * (q.count / (q.count - 1.0)) : var;
+    bn_running_update(q.running_mean, q.running_var, c, q.momentum, (float)m, (float)unb);
+  }
+}
+
+extern "C" int fi_bn_running_groups_multi(const FiBnRunItem* items, int n, void* stream) {
+  if (!items) return FI_ERR_NULL;
+  if (n < 0) return FI_ERR_SHAPE;
+  for (int base = 0; base < n; base += FI_BN_RUN_MAX) {
+    FiBnRunPack p;
+    const int m = n - base < FI_BN_RUN_MAX ? n - base : FI_BN_RUN_MAX;
+    int cmax = 1;
+    for (int i = 0; i < m; ++i) {
+      p.it[i] = items[base + i];
+      if (!p.it[i].stats || !p.it[i].running_mean || !p.it[i].running_var) return FI_ERR_NULL;
+      if (p.it[i].groups < 1 || p.it[i].C < 1) return FI_ERR_SHAPE;
+      if (p.it[i].C > cmax) cmax = p.it[i].C;
+    }
+    hipLaunchKernelGGL(bn_running_groups_multi_kernel, dim3(fi_cdiv(cmax, 64), m), dim3(64), 0, (hipStream_t)stream, p);
+    FI_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -66,6 +66,9 @@ class MyClient(BaseClient):
         # ... and their decoder half (BatchNorm statistics only: nothing the iteration reads) on beside the loss and the backward
         # pass, joined before the optimizer step (measurement switch: 0 = joined before the LC loss, as in round 3)
         self.probe_tail_beside = os.environ.get("FEDICRA_PROBE_TAIL", "1") != "0"
+        # the probe's running-statistics updates on the main stream after the join instead of per-layer events between the two
+        # streams (measurement switch: 0 = round 3's events)
+        self.probe_defer_running = os.environ.get("FEDICRA_PROBE_DEFER", "1") != "0"
         self.aux_stats_only = os.environ.get("FEDICRA_AUX_STATS", "1") != "0"   # (measurement switch: 0 = the heads in full)
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
@@ -169,7 +172,14 @@ class MyClient(BaseClient):
             net._fi_refresh_packs(net.compute_dtype())       # packs the probe reads: ready BEFORE the fork
             fork = torch.cuda.Event()
             fork.record(main)
-            ops._ctx.bn_events = {}
+            if self.probe_defer_running:
+                # every BatchNorm's running statistics take the own forward's update first and the probe's K-1 after it: the
+                # probe makes only its coefficient rows on its stream, its running-statistics updates are made HERE, on this
+                # stream, after the join (ops._probe_finalize) -- no event between the two branches
+                ops._ctx.probe_deferred = []
+            else:
+                ops._ctx.bn_events = {}                      # (round 3's form: one event per layer, the probe waits for each)
+        deferred = None
         try:
             # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
             # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
@@ -187,6 +197,7 @@ class MyClient(BaseClient):
                     probe_stream = None
         finally:
             ops._ctx.bn_events = None
+            deferred, ops._ctx.probe_deferred = ops._ctx.probe_deferred, None
         logits = out[0]
         loss_ce = ops.ce_loss(logits.permute(0, 2, 3, 1), y, args.num_classes)       # :124
         loss = loss_ce
@@ -203,6 +214,8 @@ class MyClient(BaseClient):
                     probe_tail = probe_stream
                 else:
                     torch.cuda.current_stream().wait_stream(probe_stream)
+                    self._run_deferred(deferred)
+                    deferred = None
             else:
                 with torch.no_grad():                                                # all K-1 forwards as one batch
                     batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
@@ -229,16 +242,24 @@ class MyClient(BaseClient):
             self.scaler.scale(loss).backward()
             if probe_tail is not None:
                 torch.cuda.current_stream().wait_stream(probe_tail)
+            self._run_deferred(deferred)
             self.scaler.step(opt)
             self.scaler.update()
         else:
             loss.backward()
             if probe_tail is not None:
                 torch.cuda.current_stream().wait_stream(probe_tail)
+            self._run_deferred(deferred)
             opt.step()
         opt.advance_lr()
         rec.loss, rec.loss_ce, rec.loss_lc, rec.logits = loss.detach(), loss_ce.detach(), \
             (None if loss_lc is None else loss_lc.detach()), logits.detach()
+
+    @staticmethod
+    def _run_deferred(deferred):
+        """The probe's running-statistics updates that were left to this stream (ops._probe_finalize): called once the probe
+        stream has been joined."""
+        ops.run_probe_deferred(deferred)
 
     # ---------------------------------------------------------------------------------- _train
     @contextlib.contextmanager

@@ -95,6 +95,9 @@ class _Context:
         self.call_idx = {}             # uid -> how many times this layer drew a mask in the current iteration
         self.graph_tables = []         # pinned + device reduce tables of the steps captured under this context
         self.bn_events = None          # dict while the LC forwards run beside the client's own forward (see probe_after)
+        # list while they do (flower_pCE_2D._iteration): the running-statistics updates of the batched forward, which the
+        # CALLER makes on its own stream after joining the probe stream (_probe_finalize); None = made in place
+        self.probe_deferred = None
 
 
 _ctx = _Context()
@@ -319,8 +322,12 @@ def _conv_backward(ctx, dy, x0, x1, wk, mod):
         db = None
         if ctx.need_b:
             db, _, gb = _grad_target(mod.bias)
-        if ctx.need_w and dw.data_ptr() == wt_.data_ptr():
-            # stage 1 now (partial sums into a workspace); stage 2 of ALL layers in one launch at the end of backward
+        if ctx.need_w and dw.data_ptr() == wt_.data_ptr() and gw is None and gb is None:
+            # stage 1 now (partial sums into a workspace); stage 2 of ALL layers in one launch at the end of backward.
+            # Only when both targets are gradient SINKS this function does not hand back to autograd (a flat-store model,
+            # or .grad already in place): a fresh tensor returned from backward may be cloned by AccumulateGrad before the
+            # deferred reduce has written it -- a plain nn.Conv2d with a 1x1 kernel (whose KRSC view is contiguous) used to
+            # get zeros for dw and db that way (tools/grad_bisect.py, round 5)
             if _WGRAD_SIDE:
                 side, main = _side_stream(dy.device), torch.cuda.current_stream()
                 side.wait_stream(main)            # dy (and, the first time, x) are produced on the main stream
@@ -716,10 +723,11 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
     coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
     L.bn_finalize(stats, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                   bn.momentum, bn.eps, True, coef[0], coef[1], coef[2], coef[3])
-    if _ctx.bn_events is not None:
-        # the own forward's statistics-only head (aux="stats") has moved this BatchNorm's running statistics: the batched LC
-        # forwards on the second stream order THEIR update of the same layer behind this event (probe_after), exactly as
-        # behind a full _ConvBNAct layer -- without it the two read-modify-writes were unordered
+    if _ctx.bn_events is not None and _ctx.probe_deferred is None:
+        # the own forward's statistics-only head (aux="stats") has moved this BatchNorm's running statistics: batched LC
+        # forwards on a second stream must order THEIR update of the same layer behind it (round 4 left the two
+        # read-modify-writes unordered).  With a per-layer event like _ConvBNAct's (this branch) -- or, as flower_pCE_2D does, by
+        # making ALL of the probe's running-statistics updates on the caller's stream after the join (_probe_finalize)
         ev = torch.cuda.Event()
         ev.record()
         _ctx.bn_events[id(bn)] = ev
@@ -752,6 +760,23 @@ def probe_after(bn):
         ev = _ctx.bn_events.get(id(bn))
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+
+
+def run_probe_deferred(items):
+    """The running-statistics updates the batched forward left to the caller (_probe_finalize), on the CURRENT stream: all
+    layers in one launch (fi_bn_running_groups_multi; FI_BN_RUN_MULTI=0 = one launch per layer, the same kernel arithmetic)."""
+    if not items:
+        return
+    with torch.no_grad():
+        if _BN_RUN_MULTI:
+            L.bn_running_groups_multi(items)
+        else:
+            for stats, groups, count, rmean, rvar, nbt, momentum, shared in items:
+                L.bn_running_groups_multi([(stats, groups, count, rmean, rvar, nbt, momentum, shared)])
+    items.clear()
+
+
+_BN_RUN_MULTI = os.environ.get("FI_BN_RUN_MULTI", "1") != "0"
 
 
 def probe_ready():
@@ -811,11 +836,33 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
         done = L.conv2d_stats_xcorr(x0, t0, wp, conv.bias, stats, groups=groups, cout=cout)
     if not done:
         L.conv2d_fwd_fused(x0, t0, x1, t1, wp, conv.bias, y, stats, ksize=ksize, groups=groups, cout=cout, shared0=shared0)
-    coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
-    probe_after(bn)
-    L.bn_finalize_groups(stats, groups, float((N // groups) * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                         bn.num_batches_tracked, bn.momentum, bn.eps, coef)
+    count = float((N // groups) * H * W)
+    coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev) if store else None
+    _probe_finalize(stats, groups, count, bn, coef)
     return RawAct(y, coef, slope) if store else None
+
+
+def _probe_finalize(stats, groups, count, bn, coef, shared=False):
+    """Grouped BatchNorm finalize of the batched no-grad forward: coefficient rows for the consuming loader and `groups`
+    running-statistics updates in group order.  Beside the client's own forward (`_ctx.probe_deferred` is a list) only the
+    COEFFICIENTS are made here -- they depend on the batch statistics alone -- and the running-statistics half of the same
+    kernel is handed to the caller, who runs it on ITS stream after joining this one: behind the own forward's update of the
+    same BatchNorm by stream order (the reference's order, flower_pCE_2D.py:106,128-139), with NO edge between the two
+    branches of the captured step.  (Round 3 ordered the two updates with one event per layer; a single such edge late in the
+    step measured 1 398 -> 1 282 images/s on one box in round 5, and dropping all of them is what this form is for.)"""
+    if _ctx.probe_deferred is not None:
+        if coef is not None:
+            L.bn_finalize_groups(stats, groups, count, bn.weight, bn.bias, None, None, None, bn.momentum, bn.eps, coef, shared=shared)
+
+        # (stats, groups, count, running_mean, running_var, num_batches_tracked, momentum, shared): run_probe_deferred()
+        _ctx.probe_deferred.append((stats, groups, count, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                    bn.momentum, shared))
+        return
+    if coef is None:
+        coef = torch.empty((2, groups, bn.weight.numel()), dtype=torch.float32, device=stats.device)
+    probe_after(bn)
+    L.bn_finalize_groups(stats, groups, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, bn.momentum, bn.eps, coef, shared=shared)
 
 
 def probe_first_conv_bn(x, conv, bn, slope, groups):
@@ -830,9 +877,7 @@ def probe_first_conv_bn(x, conv, bn, slope, groups):
     y = torch.empty((N, H, W, cout), dtype=x.dtype, device=dev)
     L.conv2d_fwd(x, None, wp, conv.bias, y, None, stats, ksize=ksize)
     coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
-    probe_after(bn)
-    L.bn_finalize_groups(stats, groups, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                         bn.num_batches_tracked, bn.momentum, bn.eps, coef, shared=True)
+    _probe_finalize(stats, groups, float(N * H * W), bn, coef, shared=True)
     return RawAct(y, coef, slope, shared=True)
 
 

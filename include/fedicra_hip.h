@@ -51,7 +51,7 @@ extern "C" {
  *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check)
  *   3: round 4 (new entry points: fi_conv2d_stats_xcorr*, fi_bn_act_pool_groups, fi_conv1x1_up2x_fwd, fi_wgrad_tuning / fi_narrow_tuning /
  *      fi_upfuse_tuning, fi_pack_weights3d_multi; fi_wgrad_tuning's argument became a bit mask) */
-#define FI_ABI_VERSION 3
+#define FI_ABI_VERSION 4
 int fi_abi_version(void);
 
 /* ---------------------------------------------------------------- convolution ------------
@@ -251,10 +251,30 @@ int fi_bn_finalize(const double* stats, double count, const float* gamma, const 
 
 /* The same for G statistics groups of one launch of fi_conv2d_fwd_fused (group g at stats + g*stats_group_stride,
  * `count` elements each): coef = fp32 [2][G][C] (scale rows, then shift rows), and the running statistics are moved G
- * times IN GROUP ORDER -- what G consecutive train-mode forwards would do -- with num_batches_tracked += G. */
+ * times IN GROUP ORDER -- what G consecutive train-mode forwards would do -- with num_batches_tracked += G.
+ * Either half alone (round 5): running_mean == running_var == NULL -> coefficients only (no state moves, the counter is left);
+ * coef == NULL -> running statistics and counter only.  The two calls together leave exactly what the whole call leaves: a
+ * caller whose running-statistics update has to wait for another stream gets the coefficients at once and makes the update
+ * later (the batched LC forwards beside the client's own forward: flower_pCE_2D.py:106,128-139 fixes their order). */
 int fi_bn_finalize_groups(const double* stats, long stats_group_stride, int groups, double count, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           float momentum, float eps, float* coef, int C, void* stream);
+
+/* The running-statistics half (coef == NULL above) for `n` BatchNorm layers in ONE launch -- the K-1 batched LC forwards of an
+ * iteration leave the updates of all their layers to the training stream (flower_pCE_2D.py:106,128-139 fixes the order: the own
+ * forward's update of a layer first), where they would otherwise be n dependent launches.  Same arithmetic, same order per layer. */
+#define FI_BN_RUN_MAX 32
+typedef struct FiBnRunItem {
+  const double* stats;         /* [groups][SLOTS][C][2] (stats_group_stride doubles apart; 0 = one shared accumulator set)  */
+  long stats_group_stride;
+  double count;                /* elements behind one group's statistics (N_group * H * W)                                 */
+  float* running_mean;         /* fp32 [C], in place                                                                       */
+  float* running_var;
+  int64_t* num_batches_tracked;/* += groups, or NULL                                                                       */
+  float momentum;
+  int groups, C;
+} FiBnRunItem;
+int fi_bn_running_groups_multi(const FiBnRunItem* items, int n, void* stream);
 
 typedef struct FiBnAct {
   int dtype;

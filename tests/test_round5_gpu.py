@@ -101,25 +101,56 @@ def test_weighted_allreduce_and_captured_rounds_through_a_one_rank_rccl_group(tm
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_statistics_only_head_orders_its_running_statistics_before_the_probes(use_graph):
-    """with aux="stats" the own forward's auxiliary head is a statistics-only launch
-    (ops.conv_bn_stats_only) -- it moved the head BatchNorm's running statistics on the main stream WITHOUT recording the
-    per-layer event the batched LC forwards on the second stream wait for (ops.probe_after), so the two read-modify-writes of
-    running_mean / running_var were unordered.  Now every BatchNorm the probe finalises -- the head's included -- finds the own
-    forward's event, and the state equals the in-line order (/root/reference/code/flower_pCE_2D.py:106,128-139: own forward
-    first, then the K-1 forwards)."""
+@pytest.mark.parametrize("mode", ["deferred", "events"])
+def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
+    """The K-1 batched LC forwards beside the client's own forward must move every BatchNorm's running statistics AFTER the own
+    forward's update of the same layer (/root/reference/code/flower_pCE_2D.py:106,128-139: own forward first, then the K-1
+    forwards; the recursion r <- 0.9 r + 0.1 b is order dependent).  ADVICE r4 (medium): with aux="stats" the own forward's
+    auxiliary head moved its BatchNorm on the main stream with nothing ordering the probe's update of it on the second stream.
+      * "deferred" (default, round 5): the probe makes only the coefficient rows on its stream; the running-statistics half of
+        every grouped finalize -- heads included -- runs on the OWN forward's stream after the join (ops._probe_finalize):
+        checked call by call (stream, and behind the own update of the same BatchNorm in that iteration);
+      * "events" (FEDICRA_PROBE_DEFER=0, round 3's form): one event per layer, now also behind the statistics-only head:
+        every BatchNorm the probe finalises finds the own forward's event.
+    Either way the state equals the in-line order's."""
+    from fedicra_amd import _lib as L
     from fedicra_amd import ops
     from fedicra_amd.flower_common import MyModel
     from fedicra_amd.flower_pCE_2D import MyClient
     from fedicra_amd.networks import net_factory
     from helpers import loader
-    seen = []
-    orig = ops.probe_after
+    seen, log = [], []
+    orig_after, orig_fin, orig_fused, orig_one, orig_begin = ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration
+    orig_multi = L.bn_running_groups_multi
 
-    def spy(bn):
+    def spy_multi(items):
+        for it in items:
+            log.append(("probe", it[3].data_ptr(), False, cur()))
+        return orig_multi(items)
+
+    def spy_after(bn):
         ev = None if ops._ctx.bn_events is None else ops._ctx.bn_events.get(id(bn))
         seen.append((id(bn), ops._ctx.bn_events is not None, ev is not None))
-        return orig(bn)
+        return orig_after(bn)
+
+    def cur():
+        return torch.cuda.current_stream().cuda_stream
+
+    def spy_fin(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, **k):
+        log.append(("probe", None if rmean is None else rmean.data_ptr(), coef is not None, cur()))
+        return orig_fin(stats, groups, count, gamma, beta, rmean, rvar, nbt, momentum, eps, coef, **k)
+
+    def spy_fused(y, z, stats, gamma, beta, rmean, *a, **k):
+        log.append(("own", rmean.data_ptr(), True, cur()))
+        return orig_fused(y, z, stats, gamma, beta, rmean, *a, **k)
+
+    def spy_one(stats, count, gamma, beta, rmean, *a, **k):
+        log.append(("own", rmean.data_ptr(), True, cur()))
+        return orig_one(stats, count, gamma, beta, rmean, *a, **k)
+
+    def spy_begin(*a, **k):
+        log.append(("begin", None, None, cur()))
+        return orig_begin(*a, **k)
 
     res = []
     for beside in (False, True):
@@ -132,25 +163,54 @@ def test_statistics_only_head_orders_its_running_statistics_before_the_probes(us
         batches = loader(3, 4, 64, cid=1, device=DEV)
         client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
         client.probe_beside = beside
+        client.probe_defer_running = mode == "deferred"
         assert client.aux_stats_only
         names = {id(m): n for n, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
-        seen.clear()
-        ops.probe_after = spy
+        rm = {m.running_mean.data_ptr(): n for n, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
+        seen.clear(), log.clear()
+        ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = spy_after, spy_fin, spy_fused, spy_one, spy_begin
+        L.bn_running_groups_multi = spy_multi
         try:
             cfg = {"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
             client._train(cfg)
             client._train(cfg)
         finally:
-            ops.probe_after = orig
+            ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = orig_after, orig_fin, orig_fused, orig_one, orig_begin
+            L.bn_running_groups_multi = orig_multi
         torch.cuda.synchronize()
-        if beside:
+        if beside and mode == "events":
             forked = [(names.get(i, "?"), found) for i, on, found in seen if on]
             assert forked, "the probe never ran beside the own forward"
             missing = sorted({n for n, found in forked if not found})
             assert not missing, f"BatchNorms the probe updated without waiting for the own forward's update: {missing}"
             assert any("dsn_head" in n for n, _ in forked), sorted({n for n, _ in forked})
-        head = {n: b.clone() for n, b in net.named_buffers() if "dsn_head" in n}
-        res.append((list(client.last_losses), net.flat_state.clone(), net.flat_counters.clone(), head))
+        if beside and mode == "deferred":
+            assert not seen or not any(on for _, on, _ in seen)          # no per-layer events in this form
+            iters, curi = [], None
+            for rec in log:
+                if rec[0] == "begin":
+                    curi = []
+                    iters.append(curi)
+                elif curi is not None:
+                    curi.append(rec)
+            checked = heads = 0
+            for it in iters:
+                own = {}
+                for pos, (kind, ptr, has_coef, st) in enumerate(it):
+                    if kind == "own":
+                        own[ptr] = (pos, st)
+                    elif ptr is None:
+                        assert has_coef                                # the coefficient half: made on the probe stream ...
+                        assert own and st != next(iter(own.values()))[1], "coefficient rows were made on the own forward's stream"
+                    else:
+                        assert not has_coef                            # ... the running-statistics half: own stream, after the own update
+                        assert ptr in own, f"{rm.get(ptr)}: the probe moved the statistics before the own forward did"
+                        assert own[ptr][0] < pos and own[ptr][1] == st, (rm.get(ptr), own[ptr], pos, st)
+                        checked += 1
+                        heads += "dsn_head" in rm.get(ptr, "")
+            assert checked >= 19 * 3 and heads >= 3, (checked, heads)     # every layer of every eager / captured iteration
+        res.append((list(client.last_losses), net.flat_state.clone(), net.flat_counters.clone(),
+                    {n: b.clone() for n, b in net.named_buffers() if "dsn_head" in n}))
     (l0, s0, c0, h0), (l1, s1, c1, h1) = res
     assert torch.equal(c0, c1)
     assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
