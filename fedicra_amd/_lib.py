@@ -29,7 +29,8 @@ EXPORTS = [
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
     "fi_channel_gate_bwd", "fi_cast", "fi_nchw_to_nhwc", "fi_nhwc_to_nchw", "fi_probe_tr16",
     "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning", "fi_pack_weights3d_multi",
-    "fi_bn_running_groups_multi",
+    "fi_bn_running_groups_multi", "fi_tree_prep_fwd", "fi_tree_prep_bwd", "fi_tree_masked_l1_fwd", "fi_tree_masked_l1_bwd",
+    "fi_tv_loss_fwd", "fi_tv_loss_bwd", "fi_conv3d_first_fwd", "fi_conv3d_first_wgrad", "fi_conv3d_first_wgrad_workspace",
 ]
 
 
@@ -100,6 +101,7 @@ def lib():
         _lib.fi_conv3d_wgrad_fused_workspace.restype = C.c_long
         _lib.fi_tree_mst_workspace.restype = C.c_long
         _lib.fi_conv2d_stats_xcorr_workspace.restype = C.c_long
+        _lib.fi_conv3d_first_wgrad_workspace.restype = C.c_long
     return _lib
 
 
@@ -675,6 +677,69 @@ def tree_grad_rec(in_data, in_grad, out_data, w, sidx, spar, levels, grad):
                                 Cg, V, ptr(grad), stream()), "fi_tree_grad_rec")
 
 
+TREE_MAPS, TREE_TERMS = 4, 3       # FI_TREE_MAPS, FI_TREE_TERMS
+
+
+class FiTreeMap(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("stride", C.c_long * 4), ("C", C.c_int), ("h", C.c_int), ("w", C.c_int)]
+
+
+def _tree_maps(pairs):
+    """pairs: [(a, b, C, h, w)]: forward (source in any layout, dense resized map), backward (grad of the resized map, grad of
+    the source; h, w are the SOURCE's; both dense)."""
+    arr = (FiTreeMap * max(len(pairs), 1))()
+    for k, (a, b, Ck, h, w) in enumerate(pairs):
+        arr[k] = FiTreeMap(_dev(a).data_ptr(), _dev(b).data_ptr(), (C.c_long * 4)(*[int(v) for v in a.stride()]), int(Ck), int(h), int(w))
+    return arr
+
+
+def tree_prep_fwd(preds, prob, maps, roi_src, rois, count, N, H, W):
+    """preds / map sources: fp32 [N,C,h,w] in ANY layout (strides are passed); prob / resized maps dense NCHW; roi_src uint8
+    [N,h,w] dense or None."""
+    pairs = [(s_, d_, s_.shape[1], s_.shape[2], s_.shape[3]) for s_, d_ in maps]
+    Cc = 0 if preds is None else preds.shape[1]
+    pst = (C.c_long * 4)(*([0] * 4 if preds is None else [int(v) for v in preds.stride()]))
+    _chk(lib().fi_tree_prep_fwd(ptr(preds), pst, ptr(prob), int(N), int(Cc), int(H), int(W), _tree_maps(pairs), len(pairs), ptr(roi_src),
+                                0 if roi_src is None else roi_src.shape[1], 0 if roi_src is None else roi_src.shape[2],
+                                ptr(rois), ptr(count), stream()), "fi_tree_prep_fwd")
+
+
+def tree_prep_bwd(prob, dprob, dpreds, maps, N, H, W):
+    """maps: [(grad w.r.t. the resized map [N,C,H,W], grad w.r.t. the source [N,C,h,w] -- written)]."""
+    pairs = [(g_, o_, o_.shape[1], o_.shape[2], o_.shape[3]) for g_, o_ in maps]
+    Cc = 0 if dpreds is None else dpreds.shape[1]
+    _chk(lib().fi_tree_prep_bwd(ptr(prob), ptr(dprob), ptr(dpreds), int(N), int(Cc), int(H), int(W), _tree_maps(pairs), len(pairs),
+                                stream()), "fi_tree_prep_bwd")
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * max(len(ts), 1))(*[0 if t is None else t.data_ptr() for t in ts])
+
+
+def tree_masked_l1_fwd(prob, as_list, rois, count, weight, acc, loss):
+    N, Cc, H, W = _dev(prob).shape
+    _chk(lib().fi_tree_masked_l1_fwd(ptr(prob), _ptr_array(as_list), len(as_list), ptr(rois), N, Cc, H, W, ptr(count),
+                                     C.c_float(weight), ptr(acc), ptr(loss), stream()), "fi_tree_masked_l1_fwd")
+
+
+def tree_masked_l1_bwd(prob, as_list, rois, count, weight, gout, dprob, das):
+    N, Cc, H, W = _dev(prob).shape
+    _chk(lib().fi_tree_masked_l1_bwd(ptr(prob), _ptr_array(as_list), len(as_list), ptr(rois), N, Cc, H, W, ptr(count),
+                                     C.c_float(weight), ptr(gout), ptr(dprob), _ptr_array(das), stream()), "fi_tree_masked_l1_bwd")
+
+
+def tv_loss_fwd(p, eroded, idx_e, idx_d, positive, acc):
+    planes = _dev(p).numel() // (p.shape[-2] * p.shape[-1])
+    _chk(lib().fi_tv_loss_fwd(ptr(p), C.c_long(planes), p.shape[-2], p.shape[-1], ptr(eroded), ptr(idx_e), ptr(idx_d), ptr(positive),
+                              ptr(acc), stream()), "fi_tv_loss_fwd")
+
+
+def tv_loss_bwd(idx_e, idx_d, positive, gout, shape, scratch, dp):
+    planes = dp.numel() // (shape[-2] * shape[-1])
+    _chk(lib().fi_tv_loss_bwd(ptr(_dev(idx_e)), ptr(idx_d), ptr(positive), ptr(gout), C.c_long(planes), shape[-2], shape[-1],
+                              ptr(scratch), ptr(dp), stream()), "fi_tv_loss_bwd")
+
+
 CRF_SLOTS = 16       # FI_CRF_SLOTS
 
 
@@ -770,6 +835,26 @@ def conv3d_fwd(x0, x1, w_taps, bias, y, stats, *, ksize, y_f32=False):
                 vox * cin * _esz(x0) + vox * co * _esz(y) + cin * co * ksize ** 3 * _esz(x0)):
         _chk(lib().fi_conv3d_fwd(C.byref(d), D, ptr(x0), ptr(x1), _taps_array(w_taps), ptr(bias), ptr(y), ptr(stats),
                                  C.c_long(stride), stream()), "fi_conv3d_fwd")
+
+
+def conv3d_first_fwd(x, w27, bias, y, stats):
+    """Conv3d(1 -> 16, 3^3, pad 1): x [N,D,H,W,1] 16-bit, w27 fp32 [16,27] (kd, kh, kw), y [N,D,H,W,16]; stats [N, slots*16*2] / None."""
+    N, D, H, W, _ = _dev(x).shape
+    vox = N * D * H * W
+    with _timed("conv3d_fwd", (str(x.dtype)[6:], N, D, H, W, 1, 16, 3, "first"), 2.0 * vox * 16 * 27, vox * 17 * _esz(x) + 16 * 27 * _esz(x)):
+        _chk(lib().fi_conv3d_first_fwd(dt(x.dtype), N, D, H, W, ptr(x), ptr(_dev(w27)), ptr(bias), ptr(y), ptr(stats),
+                                       C.c_long(0 if stats is None else stats.stride(0)), stream()), "fi_conv3d_first_fwd")
+
+
+def conv3d_first_wgrad(x, dy, dw27, dbias):
+    """dw27 fp32 [16,27] and dbias fp32 [16] are added to."""
+    N, D, H, W, _ = _dev(x).shape
+    vox = N * D * H * W
+    nbytes = int(lib().fi_conv3d_first_wgrad_workspace(N, D, H, W))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    with _timed("conv3d_wgrad", (str(x.dtype)[6:], N, D, H, W, 1, 16, 3, "first"), 2.0 * vox * 16 * 27, vox * 17 * _esz(x) + 16 * 27 * _esz(x)):
+        _chk(lib().fi_conv3d_first_wgrad(dt(x.dtype), N, D, H, W, ptr(x), ptr(_dev(dy)), ptr(dw27), ptr(dbias), ptr(ws),
+                                         C.c_long(nbytes), stream()), "fi_conv3d_first_wgrad")
 
 
 def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):

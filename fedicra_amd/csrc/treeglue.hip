@@ -32,14 +32,18 @@ __device__ __forceinline__ int nearest_index(float scale, int dst, int n) {
 struct PrepMaps {
   const float* src[FI_TREE_MAPS];
   float* dst[FI_TREE_MAPS];
+  long sn[FI_TREE_MAPS], sc[FI_TREE_MAPS], sy[FI_TREE_MAPS], sx[FI_TREE_MAPS];     // element strides of the source (any layout)
   int C[FI_TREE_MAPS], h[FI_TREE_MAPS], w[FI_TREE_MAPS];
   int n;
+};
+struct Strides4 {
+  long n, c, y, x;
 };
 
 // one thread per output pixel (n, y, x): soft-max over the C logits, every guidance map's channels interpolated to H x W, the
 // nearest-resized mask and (block-reduced, one fp64 atomic per workgroup) the number of unlabeled pixels
-__global__ __launch_bounds__(256) void tree_prep_kernel(const float* __restrict__ preds, float* __restrict__ prob, int N, int C,
-                                                        int H, int W, PrepMaps m, const unsigned char* __restrict__ roi_src, int rh,
+__global__ __launch_bounds__(256) void tree_prep_kernel(const float* __restrict__ preds, Strides4 ps, float* __restrict__ prob, int N,
+                                                        int C, int H, int W, PrepMaps m, const unsigned char* __restrict__ roi_src, int rh,
                                                         int rw, float* __restrict__ rois, double* count) {
   const long HW = (long)H * W, total = (long)N * HW;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,14 +52,14 @@ __global__ __launch_bounds__(256) void tree_prep_kernel(const float* __restrict_
     const int n = (int)(i / HW);
     const int r = (int)(i - (long)n * HW), y = r / W, x = r - y * W;
     if (preds) {
-      const float* p = preds + (long)n * C * HW + r;
+      const float* p = preds + (long)n * ps.n + (long)y * ps.y + (long)x * ps.x;     // (the logits usually arrive as an NCHW view of NHWC)
       float mx = p[0];
-      for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[(long)c * HW]);
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[(long)c * ps.c]);
       float sum = 0.f;
-      for (int c = 0; c < C; ++c) sum += expf(p[(long)c * HW] - mx);
+      for (int c = 0; c < C; ++c) sum += expf(p[(long)c * ps.c] - mx);
       const float inv = 1.f / sum;
       float* q = prob + (long)n * C * HW + r;
-      for (int c = 0; c < C; ++c) q[(long)c * HW] = expf(p[(long)c * HW] - mx) * inv;
+      for (int c = 0; c < C; ++c) q[(long)c * HW] = expf(p[(long)c * ps.c] - mx) * inv;
     }
     for (int k = 0; k < m.n; ++k) {
       const int h = m.h[k], w = m.w[k], Ck = m.C[k];
@@ -63,12 +67,14 @@ __global__ __launch_bounds__(256) void tree_prep_kernel(const float* __restrict_
       float ly0, ly1, lx0, lx1;
       taps((float)h / (float)H, y, h, y0, y1, ly0, ly1);
       taps((float)w / (float)W, x, w, x0, x1, lx0, lx1);
-      const float* s = m.src[k] + (long)n * Ck * h * w;
+      const float* s = m.src[k] + (long)n * m.sn[k];
+      const long sy = m.sy[k], sx = m.sx[k];
       float* d = m.dst[k] + (long)n * Ck * HW + r;
       for (int c = 0; c < Ck; ++c) {
-        const float* sc = s + (long)c * h * w;
+        const float* sc = s + (long)c * m.sc[k];
         // upsample_bilinear2d's expression: h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (w0lambda * c + w1lambda * d)
-        d[(long)c * HW] = ly0 * (lx0 * sc[y0 * w + x0] + lx1 * sc[y0 * w + x1]) + ly1 * (lx0 * sc[y1 * w + x0] + lx1 * sc[y1 * w + x1]);
+        d[(long)c * HW] = ly0 * (lx0 * sc[y0 * sy + x0 * sx] + lx1 * sc[y0 * sy + x1 * sx]) +
+                          ly1 * (lx0 * sc[y1 * sy + x0 * sx] + lx1 * sc[y1 * sy + x1 * sx]);
       }
     }
     if (roi_src) {
@@ -332,9 +338,10 @@ inline unsigned grid_of(long n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 2
 
 }  // namespace
 
-extern "C" int fi_tree_prep_fwd(const float* preds, float* prob, int N, int C, int H, int W, const FiTreeMap* maps, int nmaps,
-                                const unsigned char* roi_src, int roi_h, int roi_w, float* rois, double* count, void* stream) {
-  if ((preds && !prob) || (nmaps > 0 && !maps) || (roi_src && (!rois || !count))) return FI_ERR_NULL;
+extern "C" int fi_tree_prep_fwd(const float* preds, const long* preds_strides, float* prob, int N, int C, int H, int W,
+                                const FiTreeMap* maps, int nmaps, const unsigned char* roi_src, int roi_h, int roi_w, float* rois,
+                                double* count, void* stream) {
+  if ((preds && (!prob || !preds_strides)) || (nmaps > 0 && !maps) || (roi_src && (!rois || !count))) return FI_ERR_NULL;
   if (N < 1 || H < 1 || W < 1 || nmaps < 0 || nmaps > FI_TREE_MAPS || (preds && C < 1)) return FI_ERR_SHAPE;
   PrepMaps m;
   m.n = nmaps;
@@ -342,8 +349,11 @@ extern "C" int fi_tree_prep_fwd(const float* preds, float* prob, int N, int C, i
     if (!maps[k].src || !maps[k].dst) return FI_ERR_NULL;
     if (maps[k].C < 1 || maps[k].h < 1 || maps[k].w < 1) return FI_ERR_SHAPE;
     m.src[k] = maps[k].src, m.dst[k] = maps[k].dst, m.C[k] = maps[k].C, m.h[k] = maps[k].h, m.w[k] = maps[k].w;
+    m.sn[k] = maps[k].stride[0], m.sc[k] = maps[k].stride[1], m.sy[k] = maps[k].stride[2], m.sx[k] = maps[k].stride[3];
   }
-  hipLaunchKernelGGL(tree_prep_kernel, dim3(grid_of((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, preds, prob, N, C, H, W, m,
+  Strides4 ps = {0, 0, 0, 0};
+  if (preds) ps = Strides4{preds_strides[0], preds_strides[1], preds_strides[2], preds_strides[3]};
+  hipLaunchKernelGGL(tree_prep_kernel, dim3(grid_of((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, preds, ps, prob, N, C, H, W, m,
                      roi_src, roi_h, roi_w, rois, roi_src ? count : nullptr);
   FI_CHECK_LAUNCH();
   return 0;

@@ -168,7 +168,8 @@ class MyClient(BaseClient):
             main = torch.cuda.current_stream()
             probe_stream = self.__dict__.get("_probe_stream")
             if probe_stream is None:
-                probe_stream = self.__dict__["_probe_stream"] = torch.cuda.Stream()
+                # (FEDICRA_PROBE_PRIO: HIP stream priority of the probe chain, the critical path of the iteration -- -1 = high)
+                probe_stream = self.__dict__["_probe_stream"] = torch.cuda.Stream(priority=int(os.environ.get("FEDICRA_PROBE_PRIO", "0")))
             net._fi_refresh_packs(net.compute_dtype())       # packs the probe reads: ready BEFORE the fork
             fork = torch.cuda.Event()
             fork.record(main)

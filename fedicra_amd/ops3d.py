@@ -18,6 +18,8 @@ No CPU fallback: everything routes through fedicra_amd._lib.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -175,6 +177,20 @@ def _norm_consts(cout, dev):
     return c
 
 
+_FIRST3D = os.environ.get("FI_FIRST3D", "1") != "0"            # measurement switch: 0 = the per-tap implicit GEMMs of rounds 1-4
+
+
+def _first_ok(dt, ydt, kd, ksize, x0, x1, cout):
+    """The shape csrc/conv3d_first.hip covers: ONE input channel, 16 output channels, 3x3x3, 16-bit storage."""
+    return (_FIRST3D and dt != torch.float32 and ydt == dt and kd == 3 and ksize == 3 and x1 is None and x0.shape[4] == 1
+            and cout == 16 and x0.numel() * 32 < (1 << 32) - 64)
+
+
+def _w27(weight):
+    """[16, 1, 3, 3, 3] (any strides) -> dense fp32 [16, 27], taps in (kd, kh, kw) order."""
+    return weight.detach().reshape(weight.shape[0], 27).float().contiguous()
+
+
 def _fused_ok(dt, ydt, kd, ksize, x0, x1, cout):
     """Shapes fi_conv3d_*_fused covers (the library re-checks and answers FI_ERR_UNSUPPORTED otherwise)."""
     if dt == torch.float32 or ydt != dt or kd != 3 or ksize != 3:
@@ -199,7 +215,12 @@ class _Conv3d(Function):
         stats = ops._ctx.arena.take(N * nst, dev).view(N, nst) if norm else None
         x0c, x1c = x0.contiguous(), None if x1 is None else x1.contiguous()
         y = None
-        if _fused_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
+        if _first_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
+            # the network's first convolution, 1 -> 16 channels: a vector-ALU stencil that streams the output once
+            # (csrc/conv3d_first.hip) instead of three read-modify-write passes of a K = 27 (padded to 32) implicit GEMM
+            y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
+            L.conv3d_first_fwd(x0c, _w27(weight), bias, y, stats)
+        elif _fused_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
             # ONE implicit GEMM over all slices of all volumes, the depth taps as channel groups of its contraction: y is
             # written once (the per-tap form below reads and rewrites it twice more)
             y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
@@ -279,7 +300,13 @@ class _Conv3d(Function):
                     gb = db if need_b else None
             x0c, x1c, dyc = x0.contiguous(), None if x1 is None else x1.contiguous(), dy.contiguous()
             done = False
-            if kd == 3 and ksize == 3:
+            if _first_ok(dt, dyc.dtype, kd, ksize, x0c, x1c, cout):
+                # (csrc/conv3d_first.hip: the stencil's mirror image, one partial slice per workgroup + a fixed-order sum)
+                g27 = ops._ctx.arena.take((cout * 27 + 1) // 2, dev).view(torch.float32)[:cout * 27]      # zeros of the iteration's arena
+                L.conv3d_first_wgrad(x0c, dyc, g27, db)
+                wt_.add_(g27.view(cout, 1, 3, 3, 3))
+                done = True
+            if not done and kd == 3 and ksize == 3:
                 # ONE launch over all slices of all volumes, the depth taps as channel groups of the input side
                 # (zeros out of the iteration's arena -- fp64 words viewed as fp32; the tensor dies with the add below)
                 ng = cout * ksize * ksize * kd * cin

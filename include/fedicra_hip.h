@@ -445,6 +445,58 @@ int fi_tree_prop_down(const float* x_sorted, const float* w, const int* sorted_i
 int fi_tree_grad_rec(const float* in_data, float* in_grad, const float* out_data, const float* w, const int* sorted_index,
                      const int* sorted_parent, const int* levels, int B, int Cd, int Cg, int V, float* grad, void* stream);
 
+/* The first convolution of the 3D U-Net, Conv3d(1 -> 16, 3x3x3, pad 1) (/root/reference/code/networks/unet_3D.py:38,
+ * networks/utils.py:99-123), as a vector-ALU stencil that streams the output once (round 5; the implicit-GEMM forms pad the
+ * 27-long contraction and make three read-modify-write passes).  16-bit storage (FI_BF16 / FI_F16), x [N][D][H][W] (one channel),
+ * w fp32 [16][27] with the taps in (kd, kh, kw) order, y / dy [N][D][H][W][16].
+ * fwd: y = conv + bias, rounded to the storage type; stats (or NULL): fp64 [N][FI_STATS_SLOTS][16][2] (stats_stride doubles per
+ *   sample), per-sample sum / sum of squares of the values AS STORED, added to one slot per workgroup (InstanceNorm3d's input).
+ * wgrad: dw fp32 [16][27] and dbias fp32 [16] are ADDED to (either may be NULL); workspace: fi_conv3d_first_wgrad_workspace bytes,
+ *   one partial slice per workgroup, summed in slice order by a second launch (deterministic). */
+long fi_conv3d_first_wgrad_workspace(int N, int D, int H, int W);
+int fi_conv3d_first_fwd(int dtype, int N, int D, int H, int W, const void* x, const float* w, const float* bias, void* y,
+                        double* stats, long stats_stride, void* stream);
+int fi_conv3d_first_wgrad(int dtype, int N, int D, int H, int W, const void* x, const void* dy, float* dw, float* dbias,
+                          void* workspace, long workspace_bytes, void* stream);
+
+/* Elementwise glue of the tree-energy losses (round 5; through round 4 these were ATen launches), NCHW fp32:
+ * fi_tree_prep_fwd: everything a loss computes before its trees, ONE launch over the N*H*W output pixels --
+ *   prob = softmax(preds, dim=1)                                   (flower_common.py:665,717,781; preds == NULL: skipped);
+ *   maps[k].dst [N][C_k][H][W] = F.interpolate(maps[k].src [N][C_k][h_k][w_k], size=(H, W), mode='bilinear',
+ *     align_corners=False) for k < nmaps <= FI_TREE_MAPS          (:659,672,711-714,775-778: the low-level image and the head maps);
+ *   rois [N][1][H][W] = F.interpolate(unlabeled_ROIs.unsqueeze(1).float(), size=(H, W), mode='nearest') of a uint8 / bool mask
+ *     [N][roi_h][roi_w] and count[0] += rois.sum()                (:660-662; count: fp64, zeroed by the caller; roi_src == NULL: skipped).
+ * fi_tree_prep_bwd: dpreds = softmax' (prob, dprob) and, per map, the gradient w.r.t. its source (maps[k].src = gradient w.r.t.
+ *   the resized map [N][C_k][H][W], maps[k].dst = gradient w.r.t. the source, WRITTEN); gathers, no atomics: deterministic.
+ * fi_tree_masked_l1_fwd: loss[0] = weight * (sum_k sum(rois * |prob - as[k]|)) / max(count, 1), nterms <= FI_TREE_TERMS maps
+ *   (:682-686 one term; :745-751 three terms added; `if N > 0: loss /= N` without a host sync: N == 0 => the sums are 0).
+ *   acc_zeroed: FI_TREE_TERMS + 1 doubles, zeroed by the caller (per-term sums, arrival ticket of the finishing workgroup).
+ * fi_tree_masked_l1_bwd: dprob (WRITTEN, may be NULL) and das[k] (WRITTEN where non-NULL) for the upstream gradient grad_out[0].
+ * fi_tv_loss_fwd / _bwd: tv_loss (:636-643): eroded = -max_pool2d(-p, 3, 1, 1), contour = relu(max_pool2d(eroded, 3, 1, 1) -
+ *   eroded), acc[0] += sum |contour| (the caller divides by the element count); max_pool2d's first-extremum-wins tie rule is
+ *   kept in the saved window indices (uint8 per element), so the backward routes gradients as torch's does. */
+#define FI_TREE_MAPS 4
+#define FI_TREE_TERMS 3
+typedef struct FiTreeMap {
+  const float* src;            /* forward: [N][C][h][w] through `stride` (elements; any layout -- head maps arrive as NCHW views */
+  float* dst;                  /*   of NHWC tensors); dst dense NCHW [N][C][H][W].  backward: see fi_tree_prep_bwd (dense both) */
+  long stride[4];              /* n, c, y, x element strides of src (forward only)                                           */
+  int C, h, w;
+} FiTreeMap;
+int fi_tree_prep_fwd(const float* preds, const long* preds_strides /* n, c, y, x */, float* prob, int N, int C, int H, int W,
+                     const FiTreeMap* maps, int nmaps, const unsigned char* roi_src, int roi_h, int roi_w, float* rois,
+                     double* count, void* stream);
+int fi_tree_prep_bwd(const float* prob, const float* dprob, float* dpreds, int N, int C, int H, int W, const FiTreeMap* maps,
+                     int nmaps, void* stream);
+int fi_tree_masked_l1_fwd(const float* prob, const float* const* as, int nterms, const float* rois, int N, int C, int H, int W,
+                          const double* count, float weight, double* acc_zeroed, float* loss, void* stream);
+int fi_tree_masked_l1_bwd(const float* prob, const float* const* as, int nterms, const float* rois, int N, int C, int H, int W,
+                          const double* count, float weight, const float* grad_out, float* dprob, float* const* das, void* stream);
+int fi_tv_loss_fwd(const float* p, long planes, int H, int W, float* eroded, unsigned char* idx_e, unsigned char* idx_d,
+                   unsigned char* positive, double* acc_zeroed, void* stream);
+int fi_tv_loss_bwd(const unsigned char* idx_e, const unsigned char* idx_d, const unsigned char* positive, const float* grad_out,
+                   long planes, int H, int W, float* scratch, float* dp, void* stream);
+
 /* Surface distances for medpy.metric.binary.hd95 (/root/reference/code/val_2D.py:14): border(m) = m AND NOT
  * erode(m) with the 4-neighbourhood (connectivity 1, outside = background).  fi_seg_borders appends the flat pixel
  * indices of the border of the prediction (argmax of logits [H*W][C]; class k=1: ==1, k>=2: >=1, val_2D.py:66-74) to

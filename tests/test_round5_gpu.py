@@ -216,3 +216,306 @@ def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
     assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
     assert torch.allclose(s0, s1, rtol=1e-4, atol=2e-5), float((s0 - s1).abs().max())
     assert h0 and all(torch.allclose(h0[n].float(), h1[n].float(), rtol=1e-4, atol=2e-5) for n in h0)
+
+
+# ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
+def _nchw_view(t):
+    """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("size", [(40, 28), (64, 64), (17, 33)])
+def test_tree_prep_launch_equals_softmax_interpolate_and_mask_count_of_torch(size):
+    """fi_tree_prep_fwd / _bwd against the reference's expressions (/root/reference/code/flower_common.py:656-665, 708-717, 772-781):
+    softmax(preds, 1); F.interpolate(bilinear, align_corners=False) of the low-level image and of three head maps at 1/4, 1/2 and
+    full resolution (ragged sizes: the scale is not an integer); F.interpolate(nearest) of the unlabeled mask and its count --
+    values against torch on the CPU, gradients of a random linear functional w.r.t. the logits and the head maps."""
+    import torch.nn.functional as F
+    from fedicra_amd.tree_energy import _TreePrep
+    H, W = size
+    g = torch.Generator().manual_seed(H * 100 + W)
+    N, C = 3, 3
+    preds = torch.randn(N, C, H, W, generator=g) * 2
+    low = torch.rand(N, 3, H + 5, W - 3, generator=g)
+    highs = [torch.randn(N, C, max(H // 4, 1), max(W // 4, 1), generator=g), torch.randn(N, C, (H + 1) // 2, (W + 1) // 2, generator=g),
+             torch.randn(N, C, H, W, generator=g)]
+    roi = torch.rand(N, 2 * H - 3, W + 7, generator=g) > 0.3
+    wts = [torch.randn(N, C, H, W, generator=g) for _ in range(4)]
+    # torch (CPU fp32)
+    pr = preds.clone().requires_grad_(True)
+    hr = [h.clone().requires_grad_(True) for h in highs]
+    prob_r = torch.softmax(pr, 1)
+    low_r = F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    hs_r = [F.interpolate(h, size=(H, W), mode="bilinear", align_corners=False) for h in hr]
+    rois_r = F.interpolate(roi.unsqueeze(1).float(), size=(H, W), mode="nearest")
+    ((prob_r * wts[0]).sum() + sum((a * b).sum() for a, b in zip(hs_r, wts[1:]))).backward()
+    # HIP: the logits and the head maps as NCHW views of NHWC tensors
+    pd = _nchw_view(preds.to(DEV)).requires_grad_(True)
+    hd = [_nchw_view(h.to(DEV)).requires_grad_(True) for h in highs]
+    out = _TreePrep.apply(pd, low.to(DEV), roi.to(DEV), *hd)
+    prob, low_d, rois, count, hs = out[0], out[1], out[2], out[3], out[4:]
+    ((prob * wts[0].to(DEV)).sum() + sum((a * b.to(DEV)).sum() for a, b in zip(hs, wts[1:]))).backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(prob.detach().cpu(), prob_r.detach(), atol=2e-7, rtol=1e-6)
+    assert torch.allclose(low_d.cpu(), low_r, atol=1e-6, rtol=1e-6)
+    for a, b in zip(hs, hs_r):
+        assert torch.allclose(a.detach().cpu(), b.detach(), atol=2e-6, rtol=1e-6)
+    assert torch.equal(rois.cpu(), rois_r) and float(count.item()) == float(rois_r.sum())
+    assert torch.allclose(pd.grad.cpu(), pr.grad, atol=2e-6, rtol=1e-5)
+    for a, b in zip(hd, hr):
+        assert torch.allclose(a.grad.cpu(), b.grad, atol=2e-5, rtol=1e-5), float((a.grad.cpu() - b.grad).abs().max())
+
+
+@pytest.mark.parametrize("terms", [1, 3])
+def test_masked_l1_launch_equals_the_references_sum_and_division(terms):
+    """fi_tree_masked_l1_fwd / _bwd: weight * sum_k (rois * |prob - AS_k|).sum() / N with `if N > 0` (flower_common.py:682-686,
+    745-751), values and the gradients w.r.t. prob and every AS_k; an all-labeled batch (N = 0) gives 0 and zero gradients."""
+    from fedicra_amd.tree_energy import _MaskedL1
+    g = torch.Generator().manual_seed(terms)
+    N, C, H, W = 2, 3, 24, 40
+    prob = torch.softmax(torch.randn(N, C, H, W, generator=g), 1)
+    maps = [torch.softmax(torch.randn(N, C, H, W, generator=g), 1) for _ in range(terms)]
+    maps[0][0, 0, :4] = prob[0, 0, :4]                               # exact zeros of prob - AS: sign(0) = 0
+    for empty in (False, True):
+        rois = torch.zeros(N, 1, H, W) if empty else (torch.rand(N, 1, H, W, generator=g) > 0.4).float()
+        pr = prob.clone().requires_grad_(True)
+        mr = [m.clone().requires_grad_(True) for m in maps]
+        tot = sum((rois * torch.abs(pr - m)).sum() for m in mr)
+        n = rois.sum()
+        ref = 0.6 * (tot / n if n > 0 else tot)
+        (ref * 1.7).backward()
+        pd = prob.to(DEV).requires_grad_(True)
+        md = [m.to(DEV).requires_grad_(True) for m in maps]
+        loss = _MaskedL1.apply(pd, rois.to(DEV), torch.tensor([float(n)], dtype=torch.float64, device=DEV), 0.6, *md)
+        (loss * 1.7).backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+        assert torch.allclose(pd.grad.cpu(), pr.grad, atol=1e-9, rtol=2e-6)
+        for a, b in zip(md, mr):
+            assert torch.allclose(a.grad.cpu(), b.grad, atol=1e-9, rtol=2e-6)
+
+
+def test_tv_loss_launches_keep_torchs_pooling_tie_rule(golden):
+    """fi_tv_loss_fwd / _bwd against the reference's tv_loss (flower_common.py:636-643) in torch on the CPU: a soft map, and a
+    map QUANTISED to a few levels -- plateaus everywhere, so nearly every 3x3 window has ties and the gradient lands where
+    max_pool2d's first-extremum rule puts it; golden g20 holds the reference's own value and gradient."""
+    import torch.nn.functional as F
+    from fedicra_amd.tree_energy import tv_loss
+
+    def ref_tv(p):
+        er = -F.max_pool2d(-p, (3, 3), 1, 1)
+        return torch.mean(torch.abs(torch.relu(F.max_pool2d(er, (3, 3), 1, 1) - er)))
+
+    g = torch.Generator().manual_seed(4)
+    soft = torch.softmax(torch.randn(2, 3, 33, 20, generator=g) * 3, 1)
+    quant = torch.round(torch.rand(2, 2, 32, 32, generator=g) * 3) / 3
+    g20 = golden("g20_tree_add_tv.npz")
+    for p, want in ((soft, None), (quant, None), (torch.from_numpy(g20["tv/p"]), (float(g20["tv/loss"]), torch.from_numpy(g20["tv/g"])))):
+        pr = p.clone().requires_grad_(True)
+        lr = ref_tv(pr)
+        lr.backward()
+        pd = p.to(DEV).requires_grad_(True)
+        ld = tv_loss(pd)
+        ld.backward()
+        torch.cuda.synchronize()
+        assert abs(float(ld) - float(lr)) <= 1e-6 * max(1.0, float(lr)), (float(ld), float(lr))
+        assert torch.allclose(pd.grad.cpu(), pr.grad, atol=1e-9, rtol=1e-6), float((pd.grad.cpu() - pr.grad).abs().max())
+        if want is not None:
+            assert abs(float(ld) - want[0]) <= 1e-6 and torch.allclose(pd.grad.cpu(), want[1], atol=1e-9, rtol=1e-6)
+
+
+def test_tree_energy_losses_on_the_hip_glue_equal_the_torch_glue():
+    """The three loss classes end to end with csrc/treeglue.hip against the SAME classes with the torch expressions of rounds 1-4
+    between the tree kernels (tree_energy._GLUE = False): loss, filtered maps, gradients w.r.t. the logits and the head maps
+    (flower_common.py:646-818).  (Golden g17 / g20 hold the reference's own numbers for the same classes:
+    tests/test_parity2_gpu.py, tests/test_round4_gpu.py run on this path too.)"""
+    from fedicra_amd import tree_energy as TE
+    g = torch.Generator().manual_seed(12)
+    N, C, S = 2, 2, 32
+    preds = torch.randn(N, C, S, S, generator=g)
+    img = torch.rand(N, 3, S, S, generator=g)
+    # guidance maps at FULL resolution: the resize is then an exact copy on both sides and the spanning trees are the same trees --
+    # a 1e-7 difference in an interpolated map may pick another of two near-equal edges and with it another (equally minimal)
+    # tree, after which the filtered maps are not comparable (the resize itself: the prep test above; the reference's own numbers
+    # at 1/4 and 1/2 resolution: golden g17 / g20 on this path)
+    hs = [torch.randn(N, C, S, S, generator=g) for _ in range(3)]
+    roi = torch.rand(N, S // 2, S // 2, generator=g) > 0.25
+    res = {}
+    for glue in (False, True):
+        TE._GLUE = glue
+        try:
+            for name, cls, nh in (("one", TE.TreeEnergyLoss, 1), ("recurve", TE.MScaleRecurveTreeEnergyLoss, 3), ("add", TE.MScaleAddTreeEnergyLoss, 3)):
+                pd = _nchw_view(preds.to(DEV)).requires_grad_(True)
+                hd = [_nchw_view(h.to(DEV)).requires_grad_(True) for h in hs[:nh]]
+                args = (pd, img.to(DEV)) + ((hd[0],) if nh == 1 else tuple(hd)) + (roi.to(DEV), 0.4)
+                out = cls()(*args)
+                out[0].backward()
+                torch.cuda.synchronize()
+                res[(name, glue)] = ([float(out[0])] + [o.detach().cpu() for o in out[1:]], pd.grad.cpu(), [h.grad.cpu() for h in hd])
+        finally:
+            TE._GLUE = True
+    for name in ("one", "recurve", "add"):
+        (o0, gp0, gh0), (o1, gp1, gh1) = res[(name, False)], res[(name, True)]
+        assert abs(o0[0] - o1[0]) <= 3e-6 * max(1.0, abs(o0[0])), (name, o0[0], o1[0])
+        for a, b in zip(o0[1:], o1[1:]):
+            assert torch.allclose(a, b, atol=3e-6, rtol=1e-5), name
+        assert torch.allclose(gp0, gp1, atol=1e-7, rtol=2e-4), (name, float((gp0 - gp1).abs().max()))
+        for a, b in zip(gh0, gh1):
+            assert torch.allclose(a, b, atol=1e-7, rtol=2e-4), (name, float((a - b).abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ 3D first layer (csrc/conv3d_first.hip)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 9, 20, 37), (1, 8, 64, 64), (1, 3, 70, 130), (2, 1, 1, 5)])
+def test_conv3d_first_layer_stencil_against_torch(dtype, shape):
+    """fi_conv3d_first_fwd / _wgrad -- Conv3d(1 -> 16, 3x3x3, pad 1), the first convolution of unet_3D
+    (/root/reference/code/networks/unet_3D.py:38, networks/utils.py:99-123) -- against torch's conv3d on the CPU in fp64 on the
+    same 16-bit operands: outputs to one rounding of the storage type, per-sample InstanceNorm statistics of the values as
+    stored, filter / bias gradients to fp32 accumulation round-off; ragged extents (rows and columns that do not fill a run, a
+    single slice, a 1 x 1 x 5 volume) exercise every boundary."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 1000 + W)
+    x = torch.randn(N, 1, D, H, W, generator=g).to(dtype)
+    w = (torch.randn(16, 1, 3, 3, 3, generator=g) * 0.3)
+    b = torch.randn(16, generator=g) * 0.1
+    dy = (torch.randn(N, 16, D, H, W, generator=g) * 0.5).to(dtype)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    xd = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)                     # NDHWC
+    y = torch.empty((N, D, H, W, 16), dtype=dtype, device=DEV)
+    stats = torch.zeros((N, L.STATS_SLOTS * 16 * 2), dtype=torch.float64, device=DEV)
+    L.conv3d_first_fwd(xd, w.reshape(16, 27).to(DEV), b.to(DEV), y, stats)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 4, 1, 2, 3).double()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert torch.all((got - ref).abs() <= ulp * ref.abs() + 1e-6), float(((got - ref).abs() / (ref.abs() + 1e-3)).max())
+    st = stats.view(N, L.STATS_SLOTS, 16, 2).sum(1).cpu()
+    assert torch.allclose(st[..., 0], got.sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * max(1.0, D * H * W / 1e4))
+    assert torch.allclose(st[..., 1], (got * got).sum((2, 3, 4)), rtol=1e-5, atol=1e-3 * max(1.0, D * H * W / 1e4))
+    # filter / bias gradient of <y, dy>
+    wr = w.double().clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    (F.conv3d(x.double(), wr, br, padding=1) * dy.double()).sum().backward()
+    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    dw = torch.full((16, 27), 0.25, dtype=torch.float32, device=DEV)        # ADDED to: start from a known value
+    db = torch.full((16,), -0.5, dtype=torch.float32, device=DEV)
+    L.conv3d_first_wgrad(xd, dyd, dw, db)
+    torch.cuda.synchronize()
+    gw, gb = (dw.cpu().double() - 0.25).view(16, 1, 3, 3, 3), db.cpu().double() + 0.5
+    tol = 3e-6 * float((x.double().abs().sum() * dy.double().abs().max()).clamp(min=1.0)) ** 0.5 + 2e-5 * float(wr.grad.abs().max())
+    assert torch.allclose(gw, wr.grad, rtol=1e-4, atol=max(tol, 1e-4)), float((gw - wr.grad).abs().max())
+    assert torch.allclose(gb, br.grad, rtol=1e-4, atol=max(tol, 1e-4)), float((gb - br.grad).abs().max())
+
+
+def test_unet3d_first_layer_on_the_stencil_equals_the_per_tap_form_at_full_size():
+    """BASELINE configs[3]'s first convolution at 2 x 1 x 128^3 bf16 through csrc/conv3d_first.hip against the per-tap
+    implicit-GEMM form of rounds 1-4 (ops3d._FIRST3D = False): (i) the bare convolution, forward and backward on the SAME
+    gradient -- outputs one bf16 step apart at most, filter / bias gradients to accumulation round-off; (ii) `UnetConv3`'s first
+    half (InstanceNorm3d + ReLU behind it): activations one step apart (the per-tap form rounds its output three times, once per
+    depth-tap pass, the stencil once; gradients then differ through the ReLU mask of the elements that round across zero);
+    (iii) which of the two is right: a crop of the stencil's output against fp64."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    from fedicra_amd import ops, ops3d
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 128, 128, 128, 1, generator=g).to(torch.bfloat16).to(DEV)
+    gz = (torch.randn(2, 128, 128, 128, 16, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    res = {}
+    for norm in (False, True):
+        for first in (False, True):
+            ops3d._FIRST3D = first
+            try:
+                torch.manual_seed(3)
+                conv = nn.Conv3d(1, 16, 3, padding=1).to(DEV)
+                ops.begin_iteration(torch.device(DEV))
+                z = ops3d._Conv3d.apply(x, None, conv.weight, conv.bias, norm, False, None)
+                z.backward(gz)
+                torch.cuda.synchronize()
+                res[(norm, first)] = (z.detach().float(), conv.weight.grad.clone(), conv.bias.grad.clone())
+            finally:
+                ops3d._FIRST3D = True
+    (y0, w0, b0), (y1, w1, b1) = res[(False, False)], res[(False, True)]
+    assert float((y0 - y1).abs().max()) <= 2.0 ** -6 * float(y0.abs().max())
+    assert float((w0 - w1).abs().max()) <= 2e-3 * float(w0.abs().max()), float((w0 - w1).abs().max() / w0.abs().max())
+    assert float((b0 - b1).abs().max()) <= 2e-3 * float(b0.abs().max()) + 1e-2, float((b0 - b1).abs().max() / b0.abs().max())
+    (z0, w0, b0), (z1, w1, b1) = res[(True, False)], res[(True, True)]
+    assert float((z0 - z1).abs().max()) <= 2.0 ** -5 * float(z0.abs().max())
+    assert float((z0 - z1).abs().mean()) <= 3e-2 * float(z0.abs().mean())
+    assert float((w0 - w1).abs().max()) <= 0.1 * float(w0.abs().max()), float((w0 - w1).abs().max() / w0.abs().max())
+    torch.manual_seed(3)
+    ref_conv = nn.Conv3d(1, 16, 3, padding=1)                                    # the same seed: the same filter as the runs above
+    crop = x[1:2, 59:71, 0:26, 95:128, 0].float().cpu().double().unsqueeze(1)    # z 60..69, y 0..23, x 96..127 with their halo
+    yc = F.conv3d(crop, ref_conv.weight.double(), ref_conv.bias.double(), padding=1)[:, :, 1:-1, :-2, 1:]
+    y_new = torch.empty((2, 128, 128, 128, 16), dtype=torch.bfloat16, device=DEV)
+    L.conv3d_first_fwd(x, ref_conv.weight.reshape(16, 27).to(DEV), ref_conv.bias.to(DEV), y_new, None)
+    got = y_new[1, 60:70, 0:24, 96:128].float().cpu().permute(3, 0, 1, 2).double()
+    assert torch.all((got - yc[0]).abs() <= 2.0 ** -8 * yc[0].abs() + 1e-6), float((got - yc[0]).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ bf16 against fp32 at the benchmarked shape
+def test_bf16_iteration_of_config3_with_every_form_on_against_the_fp32_mode():
+    """every bf16 form of rounds 2-4 is tested alone against its predecessor; this is their COMPOSITION at the
+    benchmarked shape -- BASELINE configs[2]: `unet_lc`, 8 clients, 12 x 3 x 512^2, ONE body-phase FedICRA iteration exactly as
+    bench.py times it (device RNG dropout, the 7 LC forwards batched beside the own forward with their running-statistics
+    updates deferred, statistics-only heads, the head's statistics from the autocorrelation, fused up-sampling, narrow first /
+    logits layers, row-streaming filter gradients) -- in bf16 against the same iteration in the fp32 parity mode (exact-fp32
+    MFMA, the generic kernels): the same seeds draw the same masks in both.  Compared: the loss terms, every BatchNorm's
+    running statistics after the 1 + 7 updates, and the gradient of every parameter (cosine and norm ratio).
+    (/root/reference/code/flower_pCE_2D.py:51-181 the iteration; the fp32 mode itself is held to the reference by g4 / g5 and
+    tests/test_parity2_gpu.py at this shape.)"""
+    from fedicra_amd import ops
+    from fedicra_amd.flower_common import MyModel
+    from fedicra_amd.flower_pCE_2D import MyClient
+    from fedicra_amd.networks import net_factory
+    from fedicra_amd.networks.unet import set_compute_dtype
+    from fedicra_amd.synth import phantom_batch
+    K, cid = 8, 0
+    img, weak, _ = phantom_batch(12, 512, 3, 3, cid=cid, index=0)
+    batch = [{"image": torch.from_numpy(img).to(DEV), "label": torch.from_numpy(weak).to(DEV)}]
+    out = {}
+    for dtype in ("fp32", "bf16"):
+        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=cid, min_num_clients=K, num_classes=3,
+                                  img_class="odoc", base_lr=0.01, max_iterations=30000, iters=1, rep_iters=1, alpha=1.0,
+                                  snapshot_path=None, use_graph=False)
+        torch.manual_seed(2022)
+        ops.manual_seed(7)
+        net = net_factory(args, net_type="unet_lc", in_chns=3, class_num=3).to(DEV)
+        set_compute_dtype(net, dtype)
+        client = MyClient(args, MyModel(args, net, batch, batch), batch, batch)
+        assert client.probe_beside and client.probe_defer_running and client.aux_stats_only
+        client._train({"iter_global": 60, "iters": 1, "eval_iters": 10, "batch_size": 12, "stage": "fit"})   # iters - rep_iters = 0: body phase
+        torch.cuda.synchronize()
+        grads = {n: p._fi_gview.detach().double().clone() for n, p in net.named_parameters() if getattr(p, "_fi_gview", None) is not None}
+        stats = {n: b.detach().double().clone() for n, b in net.named_buffers() if "running" in n}
+        out[dtype] = (client.last_terms[0], grads, stats, net.flat_counters.clone())
+        del client, net
+        torch.cuda.empty_cache()
+    (t32, g32, s32, c32), (t16, g16, s16, c16) = out["fp32"], out["bf16"]
+    # loss, ce, tree, crf, lc (flower_pCE_2D._round_result)
+    assert abs(t16[0] - t32[0]) <= 2e-2 * max(1.0, abs(t32[0])), (t16, t32)
+    assert abs(t16[1] - t32[1]) <= 2e-2 * max(1.0, abs(t32[1])) and abs(t16[4] - t32[4]) <= 2e-2 * max(1e-2, abs(t32[4])), (t16, t32)
+    assert torch.equal(c32, c16)                                                  # every counter moved 1 + 7 times in both
+    worst_stat = 0.0
+    for n in s32:
+        scale = float(s32[n].abs().max()) + 1e-3
+        d = float((s16[n] - s32[n]).abs().max()) / scale
+        worst_stat = max(worst_stat, d)
+        assert d <= 3e-2, (n, d)
+    rows = []
+    for n, a in g32.items():
+        b = g16[n]
+        na, nb = float(a.norm()), float(b.norm())
+        if na < 1e-7 * a.numel() ** 0.5:                                         # (a bias in front of a BatchNorm: gradient = round-off)
+            continue
+        cos = float((a * b).sum() / (na * nb + 1e-300))
+        rows.append((cos, nb / na, n))
+    rows.sort()
+    print(f"bf16 vs fp32, one C3 body iteration: loss {t16[0]:.6f} / {t32[0]:.6f}, lc {t16[4]:.6f} / {t32[4]:.6f}; worst running-statistic "
+          f"deviation {worst_stat:.2e} of its scale; gradient cosine min {rows[0][0]:.4f} ({rows[0][2]}), median {rows[len(rows) // 2][0]:.4f}; "
+          f"norm ratio range {min(r[1] for r in rows):.3f} .. {max(r[1] for r in rows):.3f} over {len(rows)} parameters")
+    assert len(rows) >= 60
+    assert rows[0][0] >= 0.90, rows[:5]                                           # every parameter's gradient points the fp32 way
+    assert rows[len(rows) // 10][0] >= 0.98, rows[:8]                             # ... and 90 % of them within 0.98
+    assert all(0.8 <= r[1] <= 1.25 for r in rows), [r for r in rows if not 0.8 <= r[1] <= 1.25][:5]
