@@ -31,6 +31,7 @@ EXPORTS = [
     "fi_conv2d_stats_xcorr", "fi_conv2d_stats_xcorr_workspace", "fi_conv2d_stats_xcorr_layout", "fi_wgrad_tuning", "fi_bn_act_pool_groups", "fi_narrow_tuning", "fi_conv1x1_up2x_fwd", "fi_upfuse_tuning", "fi_pack_weights3d_multi",
     "fi_bn_running_groups_multi", "fi_tree_prep_fwd", "fi_tree_prep_bwd", "fi_tree_masked_l1_fwd", "fi_tree_masked_l1_bwd",
     "fi_tv_loss_fwd", "fi_tv_loss_bwd", "fi_conv3d_first_fwd", "fi_conv3d_first_wgrad", "fi_conv3d_first_wgrad_workspace",
+    "fi_conv3d_point_fwd", "fi_conv3d_point_dgrad", "fi_conv3d_point_wgrad", "fi_conv3d_point_wgrad_workspace",
 ]
 
 
@@ -102,6 +103,7 @@ def lib():
         _lib.fi_tree_mst_workspace.restype = C.c_long
         _lib.fi_conv2d_stats_xcorr_workspace.restype = C.c_long
         _lib.fi_conv3d_first_wgrad_workspace.restype = C.c_long
+        _lib.fi_conv3d_point_wgrad_workspace.restype = C.c_long
     return _lib
 
 
@@ -855,6 +857,35 @@ def conv3d_first_wgrad(x, dy, dw27, dbias):
     with _timed("conv3d_wgrad", (str(x.dtype)[6:], N, D, H, W, 1, 16, 3, "first"), 2.0 * vox * 16 * 27, vox * 17 * _esz(x) + 16 * 27 * _esz(x)):
         _chk(lib().fi_conv3d_first_wgrad(dt(x.dtype), N, D, H, W, ptr(x), ptr(_dev(dy)), ptr(dw27), ptr(dbias), ptr(ws),
                                          C.c_long(nbytes), stream()), "fi_conv3d_first_wgrad")
+
+
+def conv3d_point_fwd(x, w2, bias, y):
+    """Conv3d(16 -> cout <= 4, 1x1x1): x [..., 16] 16-bit dense, w2 fp32 [cout, 16], y fp32 [..., cout]."""
+    vox, co = _dev(x).numel() // 16, w2.shape[0]
+    with _timed("conv3d_fwd", (str(x.dtype)[6:],) + tuple(x.shape[:4]) + (16, co, 1, "point"), 2.0 * vox * 16 * co,
+                vox * 16 * _esz(x) + vox * co * 4):
+        _chk(lib().fi_conv3d_point_fwd(dt(x.dtype), C.c_long(vox), co, ptr(x), ptr(_dev(w2)), ptr(bias), ptr(y), stream()),
+             "fi_conv3d_point_fwd")
+
+
+def conv3d_point_dgrad(dy, w2, dx):
+    vox, co = _dev(dx).numel() // 16, w2.shape[0]
+    with _timed("conv3d_dgrad", (str(dx.dtype)[6:],) + tuple(dx.shape[:4]) + (co, 16, 1, "point"), 2.0 * vox * 16 * co,
+                vox * 16 * _esz(dx) + vox * co * 4):
+        _chk(lib().fi_conv3d_point_dgrad(dt(dx.dtype), C.c_long(vox), co, ptr(_dev(dy)), ptr(w2), ptr(dx), stream()),
+             "fi_conv3d_point_dgrad")
+
+
+def conv3d_point_wgrad(x, dy, dw, dbias):
+    """dw fp32 [cout * 16] / dbias fp32 [cout] are added to (either may be None)."""
+    vox = _dev(x).numel() // 16
+    co = dy.numel() // vox
+    nbytes = int(lib().fi_conv3d_point_wgrad_workspace())
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    with _timed("conv3d_wgrad", (str(x.dtype)[6:],) + tuple(x.shape[:4]) + (16, co, 1, "point"), 2.0 * vox * 16 * co,
+                vox * 16 * _esz(x) + vox * co * 4):
+        _chk(lib().fi_conv3d_point_wgrad(dt(x.dtype), C.c_long(vox), co, ptr(x), ptr(_dev(dy)), ptr(dw), ptr(dbias), ptr(ws),
+                                         C.c_long(nbytes), stream()), "fi_conv3d_point_wgrad")
 
 
 def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):

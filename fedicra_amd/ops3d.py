@@ -186,6 +186,17 @@ def _first_ok(dt, ydt, kd, ksize, x0, x1, cout):
             and cout == 16 and x0.numel() * 32 < (1 << 32) - 64)
 
 
+def _point_ok(dt, ydt, kd, ksize, x0, x1, cout, norm):
+    """The shape csrc/conv3d_point.hip covers: 16 channels in, <= 4 fp32 channels out, 1x1x1, no normalisation, 16-bit input."""
+    return (_FIRST3D and not norm and dt != torch.float32 and ydt == torch.float32 and kd == 1 and ksize == 1 and x1 is None
+            and x0.shape[4] == 16 and cout <= 4)
+
+
+def _w_point(weight):
+    """[Cout, 16, 1, 1, 1] (any strides) -> dense fp32 [Cout, 16]."""
+    return weight.detach().reshape(weight.shape[0], 16).float().contiguous()
+
+
 def _w27(weight):
     """[16, 1, 3, 3, 3] (any strides) -> dense fp32 [16, 27], taps in (kd, kh, kw) order."""
     return weight.detach().reshape(weight.shape[0], 27).float().contiguous()
@@ -215,7 +226,12 @@ class _Conv3d(Function):
         stats = ops._ctx.arena.take(N * nst, dev).view(N, nst) if norm else None
         x0c, x1c = x0.contiguous(), None if x1 is None else x1.contiguous()
         y = None
-        if _first_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
+        if _point_ok(dt, ydt, kd, ksize, x0c, x1c, cout, norm):
+            # the network's last convolution, 16 -> n_classes at 1x1x1 to fp32 logits: one streaming pass (csrc/conv3d_point.hip)
+            # instead of a zero fill + an accumulating padded GEMM per sample
+            y = torch.empty((N, D, H, W, cout), dtype=torch.float32, device=dev)
+            L.conv3d_point_fwd(x0c, _w_point(weight), bias, y)
+        elif _first_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
             # the network's first convolution, 1 -> 16 channels: a vector-ALU stencil that streams the output once
             # (csrc/conv3d_first.hip) instead of three read-modify-write passes of a K = 27 (padded to 32) implicit GEMM
             y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
@@ -261,6 +277,37 @@ class _Conv3d(Function):
                 L.bn_act_bwd_reduce(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, 0.0, None)
                 L.bn_act_bwd_apply(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, True, dy[n], None,
                                    None, 0.0, None)
+        elif _point_ok(dt, dz.dtype, kd, ksize, x0, x1, cout, False):
+            # (csrc/conv3d_point.hip: the fp32 logit gradient is consumed as it is -- no cast pass -- by one streaming launch per
+            #  direction; gradient targets as below)
+            x0c = x0.contiguous()
+            w2 = _w_point(weight)
+            dx0 = gw = gb = None
+            if ctx.needs_input_grad[0]:
+                dx0 = torch.empty_like(x0c)
+                L.conv3d_point_dgrad(dz, w2, dx0)
+            need_w, need_b = ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3]
+            if need_w or need_b:
+                mod = ctx.mod
+                wt_ = gw = None
+                if need_w:
+                    if mod is not None:
+                        wt_, _, gw = ops._grad_target(mod.weight)
+                    else:
+                        wt_ = gw = torch.zeros_like(weight, dtype=torch.float32)
+                db = None
+                if need_b:
+                    if mod is not None:
+                        db, _, gb = ops._grad_target(mod.bias)
+                    else:
+                        db = gb = torch.zeros(cout, dtype=torch.float32, device=dev)
+                g = None
+                if need_w:
+                    g = ops._ctx.arena.take((cout * 16 + 1) // 2, dev).view(torch.float32)[:cout * 16]     # zeros of the iteration's arena
+                L.conv3d_point_wgrad(x0c, dz, g, db)
+                if need_w:
+                    wt_.add_(g.view(cout, 16, 1, 1, 1))
+            return dx0, None, gw, gb, None, None, None
         else:
             dy = dz if dz.dtype == dt else dz.to(dt)
         need_x0, need_x1 = ctx.needs_input_grad[0], x1 is not None and ctx.needs_input_grad[1]

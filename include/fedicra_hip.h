@@ -459,6 +459,16 @@ int fi_conv3d_first_fwd(int dtype, int N, int D, int H, int W, const void* x, co
 int fi_conv3d_first_wgrad(int dtype, int N, int D, int H, int W, const void* x, const void* dy, float* dw, float* dbias,
                           void* workspace, long workspace_bytes, void* stream);
 
+/* The last convolution of the 3D U-Net, Conv3d(16 -> cout <= 4, 1x1x1) to fp32 logits (/root/reference/code/networks/unet_3D.py:57):
+ * one streaming pass per direction (round 5).  x / dx [voxels][16] 16-bit (FI_BF16 / FI_F16), w fp32 [cout][16], y / dy fp32
+ * [voxels][cout] -- the loss's fp32 gradient is consumed as it is.  wgrad: dw fp32 [cout][16] and dbias fp32 [cout] are ADDED to
+ * (either may be NULL); workspace: fi_conv3d_point_wgrad_workspace() bytes (one partial row per workgroup, fixed-order sum). */
+long fi_conv3d_point_wgrad_workspace(void);
+int fi_conv3d_point_fwd(int dtype, long voxels, int cout, const void* x, const float* w, const float* bias, float* y, void* stream);
+int fi_conv3d_point_dgrad(int dtype, long voxels, int cout, const float* dy, const float* w, void* dx, void* stream);
+int fi_conv3d_point_wgrad(int dtype, long voxels, int cout, const void* x, const float* dy, float* dw, float* dbias,
+                          void* workspace, long workspace_bytes, void* stream);
+
 /* Elementwise glue of the tree-energy losses (round 5; through round 4 these were ATen launches), NCHW fp32:
  * fi_tree_prep_fwd: everything a loss computes before its trees, ONE launch over the N*H*W output pixels --
  *   prob = softmax(preds, dim=1)                                   (flower_common.py:665,717,781; preds == NULL: skipped);

@@ -519,3 +519,37 @@ def test_bf16_iteration_of_config3_with_every_form_on_against_the_fp32_mode():
     assert rows[0][0] >= 0.90, rows[:5]                                           # every parameter's gradient points the fp32 way
     assert rows[len(rows) // 10][0] >= 0.98, rows[:8]                             # ... and 90 % of them within 0.98
     assert all(0.8 <= r[1] <= 1.25 for r in rows), [r for r in rows if not 0.8 <= r[1] <= 1.25][:5]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cout", [2, 3, 4])
+def test_conv3d_pointwise_logits_layer_against_torch(dtype, cout):
+    """fi_conv3d_point_fwd / _dgrad / _wgrad -- Conv3d(16 -> n_classes, 1x1x1) to fp32 logits, the last convolution of unet_3D
+    (/root/reference/code/networks/unet_3D.py:57) -- through ops3d._Conv3d against torch on the CPU in fp64 on the same 16-bit
+    input: logits, the input gradient (one rounding of the storage type), filter and bias gradients; a voxel count that does not
+    fill the last workgroup."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from fedicra_amd import ops, ops3d
+    g = torch.Generator().manual_seed(cout)
+    N, D, H, W = 2, 5, 9, 13
+    x = torch.randn(N, D, H, W, 16, generator=g).to(dtype)
+    conv = nn.Conv3d(16, cout, 1)
+    gy = torch.randn(N, D, H, W, cout, generator=g)
+    xr = x.double().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    wr, br = conv.weight.detach().double().clone().requires_grad_(True), conv.bias.detach().double().clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br)
+    (yr * gy.double().permute(0, 4, 1, 2, 3)).sum().backward()
+    cd = conv.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    ops.begin_iteration(torch.device(DEV))
+    y = ops3d._Conv3d.apply(xd, None, cd.weight, cd.bias, False, True, None)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (N, D, H, W, cout)
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.allclose(y.detach().cpu().double(), yr.detach().permute(0, 2, 3, 4, 1), rtol=1e-5, atol=1e-5)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    dx_ref = xr.grad.permute(0, 2, 3, 4, 1)
+    assert torch.all((xd.grad.float().cpu().double() - dx_ref).abs() <= ulp * dx_ref.abs() + 1e-6)
+    assert torch.allclose(cd.weight.grad.cpu().double(), wr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(cd.bias.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-4)
