@@ -32,6 +32,7 @@ EXPORTS = [
     "fi_bn_running_groups_multi", "fi_tree_prep_fwd", "fi_tree_prep_bwd", "fi_tree_masked_l1_fwd", "fi_tree_masked_l1_bwd",
     "fi_tv_loss_fwd", "fi_tv_loss_bwd", "fi_conv3d_first_fwd", "fi_conv3d_first_wgrad", "fi_conv3d_first_wgrad_workspace",
     "fi_conv3d_point_fwd", "fi_conv3d_point_dgrad", "fi_conv3d_point_wgrad", "fi_conv3d_point_wgrad_workspace",
+    "fi_bn_fused_fwd_batched", "fi_bn_act_bwd_reduce_batched", "fi_bn_act_bwd_apply_batched",
 ]
 
 
@@ -514,6 +515,29 @@ def bn_act_bwd_apply(dz, y, scale, shift, mean, invstd, sums, training, dy, dgam
         _chk(lib().fi_bn_act_bwd_apply(C.byref(d), ptr(dz), ptr(y), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
                                        ptr(sums), int(training), ptr(dy), ptr(dgamma), ptr(dbeta),
                                        int(accumulate_param), stream()), "fi_bn_act_bwd_apply")
+
+
+def instnorm_fwd_batched(y, z, stats, ones, zeros, rm, rv, eps, coef):
+    """InstanceNorm3d(affine=False) + ReLU of all samples in one launch: y / z [N, D, H, W, C] dense, stats fp64 [N, slots*C*2],
+    coef fp32 [N, 4, C] (scale, shift, mean, invstd rows per sample)."""
+    d = _bnact(_dev(y)[0], 0.0, None)
+    N = y.shape[0]
+    with _timed("bn_act_fwd", (str(y.dtype)[6:],) + tuple(y.shape), 0, 2 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_fused_fwd_batched(C.byref(d), N, C.c_long(y[0].numel()), C.c_long(stats.stride(0)), C.c_long(coef.stride(0)),
+                                           ptr(y), ptr(z), ptr(stats), ptr(ones), ptr(zeros), ptr(rm), ptr(rv), C.c_float(eps),
+                                           ptr(coef), stream()), "fi_bn_fused_fwd_batched")
+
+
+def instnorm_bwd_batched(dz, y, coef, sums, dy):
+    """Both backward passes (reduce, apply) of the batched InstanceNorm3d + ReLU: sums fp64 [N, slots*C*2] zeroed."""
+    d = _bnact(_dev(y)[0], 0.0, None)
+    N = y.shape[0]
+    args = (C.byref(d), N, C.c_long(y[0].numel()), C.c_long(sums.stride(0)), C.c_long(coef.stride(0)), ptr(dz), ptr(y),
+            ptr(coef[0, 0]), ptr(coef[0, 1]), ptr(coef[0, 2]), ptr(coef[0, 3]), ptr(sums))
+    with _timed("bn_act_bwd_reduce", (str(y.dtype)[6:],) + tuple(y.shape), 0, 2 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_act_bwd_reduce_batched(*args, stream()), "fi_bn_act_bwd_reduce_batched")
+    with _timed("bn_act_bwd_apply", (str(y.dtype)[6:],) + tuple(y.shape), 0, 3 * y.numel() * _esz(y)):
+        _chk(lib().fi_bn_act_bwd_apply_batched(*args, 1, ptr(dy), stream()), "fi_bn_act_bwd_apply_batched")
 
 
 def maxpool2_fwd(x, y):

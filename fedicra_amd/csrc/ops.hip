@@ -267,6 +267,14 @@ __device__ __forceinline__ void drop_factors(const DropSpec& d, uint64_t seed, s
   }
 }
 
+// Several SAMPLES of one launch (blockIdx.y): InstanceNorm3d is these kernels per sample -- its own statistics, coefficient rows and
+// sums -- and was one launch per sample and pass; the small deep levels of the 3D U-Net are a few microseconds of work under a
+// launch floor each.  n <= 1: one tensor, the pointers as they are.
+struct BnBatch {
+  int n;
+  long tensor, stats, coef;        // strides between samples: elements of the activation, doubles, floats per coefficient ROW set
+};
+
 static DropSpec make_drop(const FiBnAct* d) {
   DropSpec s;
   s.mode = d->drop_p > 0.f ? d->drop_mode : FI_DROP_NONE;
@@ -387,8 +395,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, double* sums,
-                                                                long pixels, int C, float slope, DropSpec dr) {
+                                                                long pixels, int C, float slope, DropSpec dr, BnBatch bb) {
   constexpr int VG = DT<T>::VG;
+  if (bb.n > 1) {
+    const long b = blockIdx.y;
+    dz += b * bb.tensor, y += b * bb.tensor, sums += b * bb.stats;
+    scale += b * bb.coef, shift += b * bb.coef, mean += b * bb.coef, invstd += b * bb.coef;
+  }
   const int CV = C / VG;          // channel vectors per pixel; divides 256
   const int PS = 256 / CV;        // pixels handled concurrently by one workgroup
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
@@ -451,9 +464,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
   }
 }
 
-extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void* y, const float* scale,
-                                    const float* shift, const float* mean, const float* invstd, double* sums,
-                                    void* stream) {
+static int bn_act_bwd_reduce_impl(const FiBnAct* d, const void* dz, const void* y, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, double* sums, BnBatch bb, void* stream) {
   if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
   const DropSpec dr = make_drop(d);
   hipStream_t st = (hipStream_t)stream;
@@ -465,16 +477,34 @@ extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void
   const int PS = 256 / CV;
   const int grid = grid_for(d->pixels, PS * 4);
   if (d->dtype == FI_F32)
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
-                       (const float*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid, bb.n), dim3(256), 0, st, (const float*)dz,
+                       (const float*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr, bb);
   else if (d->dtype == FI_F16)
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)dz,
-                       (const f16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<f16_t>, dim3(grid, bb.n), dim3(256), 0, st, (const f16_t*)dz,
+                       (const f16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr, bb);
   else
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
-                       (const bf16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(grid, bb.n), dim3(256), 0, st, (const bf16_t*)dz,
+                       (const bf16_t*)y, scale, shift, mean, invstd, sums, d->pixels, d->C, d->slope, dr, bb);
   FI_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int fi_bn_act_bwd_reduce(const FiBnAct* d, const void* dz, const void* y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, double* sums,
+                                    void* stream) {
+  return bn_act_bwd_reduce_impl(d, dz, y, scale, shift, mean, invstd, sums, BnBatch{1, 0, 0, 0}, stream);
+}
+static int bn_batch_ok(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride) {
+  if (!d) return FI_ERR_NULL;
+  if (nbatch < 1 || nbatch > 65535 || tensor_stride < d->pixels * d->C || stats_stride < 0 || coef_stride < d->C) return FI_ERR_SHAPE;
+  if (d->drop_p > 0.f) return FI_ERR_UNSUPPORTED;              // (mask indices / seeds are per tensor: not batched)
+  return 0;
+}
+extern "C" int fi_bn_act_bwd_reduce_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride,
+                                            const void* dz, const void* y, const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, double* sums, void* stream) {
+  const int rc = bn_batch_ok(d, nbatch, tensor_stride, stats_stride, coef_stride);
+  if (rc) return rc;
+  return bn_act_bwd_reduce_impl(d, dz, y, scale, shift, mean, invstd, sums, BnBatch{nbatch, tensor_stride, stats_stride, coef_stride}, stream);
 }
 
 template <typename T, bool HOIST>
@@ -486,9 +516,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                const double* __restrict__ sums, int training,
                                                                T* __restrict__ dy, float* dgamma, float* dbeta,
                                                                int accumulate_param, long nvec, long pixels, int C,
-                                                               float slope, DropSpec dr) {
+                                                               float slope, DropSpec dr, BnBatch bb) {
   constexpr int VG = DT<T>::VG;
   typedef typename DT<T>::vec_t vec_t;
+  if (bb.n > 1) {
+    const long b = blockIdx.y;
+    dz += b * bb.tensor, y += b * bb.tensor, sums += b * bb.stats;
+    if (dy) dy += b * bb.tensor;
+    scale += b * bb.coef, shift += b * bb.coef, mean += b * bb.coef, invstd += b * bb.coef;
+  }
   const int CV = C / VG;
   const unsigned CVu = CV;
   const int c0 = (int)(threadIdx.x % CVu) * VG;
@@ -576,10 +612,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   }
 }
 
-extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void* y, const float* scale,
-                                   const float* shift, const float* mean, const float* invstd, const double* sums,
-                                   int training, void* dy, float* dgamma, float* dbeta, int accumulate_param,
-                                   void* stream) {
+static int bn_act_bwd_apply_impl(const FiBnAct* d, const void* dz, const void* y, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const double* sums, int training, void* dy, float* dgamma,
+                                 float* dbeta, int accumulate_param, BnBatch bb, void* stream) {
   if (!d || !dz || !y || !scale || !shift || !mean || !invstd || !sums) return FI_ERR_NULL;
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
   {
@@ -592,11 +627,11 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
   const long nvec = d->pixels * (d->C / vgl);
   if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
   const bool hoist = nvec <= 512L * 1024;             // the 64^2 level and below of the U-Net (measured crossover)
-  const dim3 g(grid_for(nvec, 256 * 4)), b(256);
+  const dim3 g(grid_for(nvec, 256 * 4), bb.n), b(256);
 #define FI_APPLY(T_, H_)                                                                                            \
   hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, H_>), g, b, 0, st, (const T_*)dz, (const T_*)y, scale, shift, mean, \
                      invstd, sums, training, (T_*)dy, dgamma, dbeta, accumulate_param, nvec, d->pixels, d->C,       \
-                     d->slope, dr)
+                     d->slope, dr, bb)
   if (d->dtype == FI_F32) {
     if (hoist) FI_APPLY(float, true); else FI_APPLY(float, false);
   } else if (d->dtype == FI_F16) {
@@ -607,6 +642,22 @@ extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void*
 #undef FI_APPLY
   FI_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int fi_bn_act_bwd_apply(const FiBnAct* d, const void* dz, const void* y, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd, const double* sums,
+                                   int training, void* dy, float* dgamma, float* dbeta, int accumulate_param,
+                                   void* stream) {
+  return bn_act_bwd_apply_impl(d, dz, y, scale, shift, mean, invstd, sums, training, dy, dgamma, dbeta, accumulate_param,
+                               BnBatch{1, 0, 0, 0}, stream);
+}
+extern "C" int fi_bn_act_bwd_apply_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride,
+                                           const void* dz, const void* y, const float* scale, const float* shift,
+                                           const float* mean, const float* invstd, const double* sums, int training, void* dy,
+                                           void* stream) {
+  const int rc = bn_batch_ok(d, nbatch, tensor_stride, stats_stride, coef_stride);
+  if (rc) return rc;
+  return bn_act_bwd_apply_impl(d, dz, y, scale, shift, mean, invstd, sums, training, dy, nullptr, nullptr, 0,
+                               BnBatch{nbatch, tensor_stride, stats_stride, coef_stride}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1368,8 +1419,13 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, float* rmean, float* rvar,
                                                            int64_t* nbt, float momentum, float eps, int training,
                                                            float* __restrict__ coef, long nvec, int C, float slope,
-                                                           DropSpec dr) {
+                                                           DropSpec dr, BnBatch bb) {
   constexpr int VG = DT<T>::VG;
+  if (bb.n > 1) {
+    const long b = blockIdx.y;
+    y += b * bb.tensor, z += b * bb.tensor, coef += b * bb.coef;
+    if (stats) stats += b * bb.stats;
+  }
   __shared__ float s_scale[512], s_shift[512];
   // (requesting the first batch of y ahead of this prologue was measured: no gain on the small maps, 12.7 -> 14.7 us
   // on the 256^2 level -- the extra live registers cost more than the overlapped round trip saves)
@@ -1448,9 +1504,9 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const T* __restrict__
   }
 }
 
-extern "C" int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const double* stats, const float* gamma,
-                               const float* beta, float* running_mean, float* running_var, int64_t* nbt,
-                               float momentum, float eps, int training, float* coef, void* stream) {
+static int bn_fused_fwd_impl(const FiBnAct* d, const void* y, void* z, const double* stats, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, int training,
+                             float* coef, BnBatch bb, void* stream) {
   if (!d || !y || !z || !gamma || !beta || !running_mean || !running_var || !coef) return FI_ERR_NULL;
   if (training && !stats) return FI_ERR_NULL;
   if (d->dtype != FI_F32 && d->dtype != FI_BF16 && d->dtype != FI_F16) return FI_ERR_DTYPE;
@@ -1463,17 +1519,36 @@ extern "C" int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const d
   // race note: workgroup 0 updates running_mean/var while other workgroups read them only in eval mode, where
   // nothing is written; in training mode nobody reads them.
   if (d->dtype == FI_F32)
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st, (const float*)y,
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<float>, dim3(grid_for(nvec, 256 * 4), bb.n), dim3(256), 0, st, (const float*)y,
                        (float*)z, stats, (double)d->pixels, gamma, beta, running_mean, running_var, nbt, momentum,
-                       eps, training, coef, nvec, d->C, d->slope, dr);
+                       eps, training, coef, nvec, d->C, d->slope, dr, bb);
   else if (d->dtype == FI_F16)
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<f16_t>, dim3(grid_for(nvec, 256 * 4), bb.n), dim3(256), 0, st,
                        (const f16_t*)y, (f16_t*)z, stats, (double)d->pixels, gamma, beta, running_mean,
-                       running_var, nbt, momentum, eps, training, coef, nvec, d->C, d->slope, dr);
+                       running_var, nbt, momentum, eps, training, coef, nvec, d->C, d->slope, dr, bb);
   else
-    hipLaunchKernelGGL(bn_fused_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4)), dim3(256), 0, st,
+    hipLaunchKernelGGL(bn_fused_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256 * 4), bb.n), dim3(256), 0, st,
                        (const bf16_t*)y, (bf16_t*)z, stats, (double)d->pixels, gamma, beta, running_mean,
-                       running_var, nbt, momentum, eps, training, coef, nvec, d->C, d->slope, dr);
+                       running_var, nbt, momentum, eps, training, coef, nvec, d->C, d->slope, dr, bb);
   FI_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int fi_bn_fused_fwd(const FiBnAct* d, const void* y, void* z, const double* stats, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                               float momentum, float eps, int training, float* coef, void* stream) {
+  return bn_fused_fwd_impl(d, y, z, stats, gamma, beta, running_mean, running_var, nbt, momentum, eps, training, coef,
+                           BnBatch{1, 0, 0, 0}, stream);
+}
+// `nbatch` samples of one launch, each with its own statistics (stats_stride doubles apart), coefficient rows (coef [nbatch][4][C]:
+// coef_stride = 4 * C floats) and slice of y / z (tensor_stride elements apart): InstanceNorm3d(affine=False) + ReLU per sample
+// (/root/reference/code/networks/utils.py:106-110) -- gamma / beta the constant (1, 0) rows, momentum 0 (the running statistics
+// are scratch and left as they are), no dropout.
+extern "C" int fi_bn_fused_fwd_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride,
+                                       const void* y, void* z, const double* stats, const float* gamma, const float* beta,
+                                       float* running_scratch_mean, float* running_scratch_var, float eps, float* coef,
+                                       void* stream) {
+  const int rc = bn_batch_ok(d, nbatch, tensor_stride, stats_stride, coef_stride);
+  if (rc) return rc;
+  return bn_fused_fwd_impl(d, y, z, stats, gamma, beta, running_scratch_mean, running_scratch_var, nullptr, 0.f, eps, 1, coef,
+                           BnBatch{nbatch, tensor_stride, stats_stride, coef_stride}, stream);
 }

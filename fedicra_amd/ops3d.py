@@ -177,6 +177,7 @@ def _norm_consts(cout, dev):
     return c
 
 
+_IN_BATCHED = os.environ.get("FI_IN_BATCHED", "1") != "0"      # measurement switch: 0 = one InstanceNorm launch per sample and pass
 _FIRST3D = os.environ.get("FI_FIRST3D", "1") != "0"            # measurement switch: 0 = the per-tap implicit GEMMs of rounds 1-4
 
 
@@ -254,8 +255,12 @@ class _Conv3d(Function):
         z = torch.empty_like(y)
         coef = torch.empty((N, 4, cout), dtype=torch.float32, device=dev)
         one, zero, rm, rv = _norm_consts(cout, dev)                 # (rm, rv: scratch -- no running statistics)
-        for n in range(N):
-            L.bn_fused_fwd(y[n], z[n], stats[n], one, zero, rm, rv, None, 0.0, 1e-5, True, coef[n], 0.0, None)
+        if _IN_BATCHED and N > 1 and y.is_contiguous():
+            # every sample of the batch in ONE launch (blockIdx.y = sample: its own statistics and coefficient rows)
+            L.instnorm_fwd_batched(y, z, stats, one, zero, rm, rv, 1e-5, coef)
+        else:
+            for n in range(N):
+                L.bn_fused_fwd(y[n], z[n], stats[n], one, zero, rm, rv, None, 0.0, 1e-5, True, coef[n], 0.0, None)
         ctx.save_for_backward(x0, x1, weight, y, coef)
         ctx.norm, ctx.has_bias = True, bias is not None
         return z
@@ -272,11 +277,16 @@ class _Conv3d(Function):
         dz = dz.contiguous()
         if ctx.norm:
             dy = torch.empty_like(y)
-            for n in range(N):
-                sums = ops._ctx.arena.take(L.STATS_SLOTS * cout * 2, dev)
-                L.bn_act_bwd_reduce(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, 0.0, None)
-                L.bn_act_bwd_apply(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, True, dy[n], None,
-                                   None, 0.0, None)
+            if _IN_BATCHED and N > 1 and y.is_contiguous():
+                nst = L.STATS_SLOTS * cout * 2
+                sums = ops._ctx.arena.take(N * nst, dev).view(N, nst)
+                L.instnorm_bwd_batched(dz, y, coef, sums, dy)       # two launches for the whole batch (reduce, apply)
+            else:
+                for n in range(N):
+                    sums = ops._ctx.arena.take(L.STATS_SLOTS * cout * 2, dev)
+                    L.bn_act_bwd_reduce(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, 0.0, None)
+                    L.bn_act_bwd_apply(dz[n], y[n], coef[n, 0], coef[n, 1], coef[n, 2], coef[n, 3], sums, True, dy[n], None,
+                                       None, 0.0, None)
         elif _point_ok(dt, dz.dtype, kd, ksize, x0, x1, cout, False):
             # (csrc/conv3d_point.hip: the fp32 logit gradient is consumed as it is -- no cast pass -- by one streaming launch per
             #  direction; gradient targets as below)

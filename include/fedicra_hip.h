@@ -445,6 +445,21 @@ int fi_tree_prop_down(const float* x_sorted, const float* w, const int* sorted_i
 int fi_tree_grad_rec(const float* in_data, float* in_grad, const float* out_data, const float* w, const int* sorted_index,
                      const int* sorted_parent, const int* levels, int B, int Cd, int Cg, int V, float* grad, void* stream);
 
+/* InstanceNorm3d(affine=False) + ReLU of a whole batch in ONE launch per pass (round 5; /root/reference/code/networks/utils.py:
+ * 106-110): `nbatch` samples, each with its own statistics (stats_stride doubles apart), coefficient rows (coef fp32 [nbatch][4][C],
+ * coef_stride = 4*C floats between samples -- also the stride of the scale / shift / mean / invstd ROW pointers of the backward) and
+ * slice of the activation (tensor_stride elements apart).  The per-tensor entry points' kernels and arithmetic; no dropout, no
+ * affine gradients; gamma / beta = the caller's constant (1, 0) rows, the running-statistics pointers are scratch (momentum 0). */
+int fi_bn_fused_fwd_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride, const void* y,
+                            void* z, const double* stats, const float* gamma, const float* beta, float* running_scratch_mean,
+                            float* running_scratch_var, float eps, float* coef, void* stream);
+int fi_bn_act_bwd_reduce_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride,
+                                 const void* dz, const void* y, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, double* sums, void* stream);
+int fi_bn_act_bwd_apply_batched(const FiBnAct* d, int nbatch, long tensor_stride, long stats_stride, long coef_stride,
+                                const void* dz, const void* y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const double* sums, int training, void* dy, void* stream);
+
 /* The first convolution of the 3D U-Net, Conv3d(1 -> 16, 3x3x3, pad 1) (/root/reference/code/networks/unet_3D.py:38,
  * networks/utils.py:99-123), as a vector-ALU stencil that streams the output once (round 5; the implicit-GEMM forms pad the
  * 27-long contraction and make three read-modify-write passes).  16-bit storage (FI_BF16 / FI_F16), x [N][D][H][W] (one channel),

@@ -553,3 +553,34 @@ def test_conv3d_pointwise_logits_layer_against_torch(dtype, cout):
     assert torch.all((xd.grad.float().cpu().double() - dx_ref).abs() <= ulp * dx_ref.abs() + 1e-6)
     assert torch.allclose(cd.weight.grad.cpu().double(), wr.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(cd.bias.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_instance_norm_equals_the_per_sample_launches_bit_for_bit(dtype):
+    """InstanceNorm3d(affine=False) + ReLU of a batch as ONE launch per pass (fi_bn_fused_fwd_batched, fi_bn_act_bwd_reduce_batched
+    / _apply_batched: blockIdx.y = sample) against one launch per sample and pass (ops3d._IN_BATCHED = False): the same kernels
+    and arithmetic, so the activations, the input gradient and the filter gradient behind it are identical
+    (/root/reference/code/networks/utils.py:106-110 `nn.InstanceNorm3d` + `nn.ReLU` after every Conv3d of UnetConv3)."""
+    import torch.nn as nn
+    from fedicra_amd import ops, ops3d
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 6, 10, 12, 32, generator=g).to(dtype).to(DEV)
+    gz = torch.randn(3, 6, 10, 12, 16, generator=g).to(dtype).to(DEV)
+    res = []
+    for batched in (False, True):
+        ops3d._IN_BATCHED = batched
+        try:
+            torch.manual_seed(1)
+            conv = nn.Conv3d(32, 16, 3, padding=1).to(DEV)
+            xi = x.clone().requires_grad_(True)
+            ops.begin_iteration(torch.device(DEV))
+            z = ops3d._Conv3d.apply(xi, None, conv.weight, conv.bias, True, False, None)
+            z.backward(gz)
+            torch.cuda.synchronize()
+            res.append((z.detach().clone(), xi.grad.clone(), conv.weight.grad.clone()))
+        finally:
+            ops3d._IN_BATCHED = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    zr = res[1][0].float()
+    assert float(zr.min()) == 0.0 and abs(float(zr.mean())) < 1.0          # normalised, rectified

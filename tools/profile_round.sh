@@ -6,7 +6,7 @@ TAG=${1:-r02_a}; ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 FEDICRA_BENCH_TABLE=$OUT/${TAG}_per_layer_roofline.txt FEDICRA_BENCH_VERBOSE=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_k /tmp/prof_r
-rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-dice \
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-dice --no-3d \
     > /tmp/prof_k.log 2>&1
 python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_k -name "*.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/prof_r -- python $ROOT/bench.py --roofline-only > /tmp/prof_r.log 2>&1
