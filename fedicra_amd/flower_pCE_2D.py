@@ -166,10 +166,10 @@ class MyClient(BaseClient):
             # enqueued first (dropout call counters), and every BatchNorm's running statistics take the own update before the
             # probe's (ops.probe_after: one event per layer).  Fork / join are graph edges under capture.
             main = torch.cuda.current_stream()
-            probe_stream = self.__dict__.get("_probe_stream")
-            if probe_stream is None:
-                # (FEDICRA_PROBE_PRIO: HIP stream priority of the probe chain, the critical path of the iteration -- -1 = high)
-                probe_stream = self.__dict__["_probe_stream"] = torch.cuda.Stream(priority=int(os.environ.get("FEDICRA_PROBE_PRIO", "0")))
+            # (FEDICRA_PROBE_PRIO: HIP stream priority of the probe chain, the critical path of the iteration -- -1 = high;
+            # stream_beside: never the stream this iteration runs / is captured on, whatever torch's pool hands out)
+            probe_stream = self.__dict__["_probe_stream"] = ops.stream_beside(
+                self.__dict__.get("_probe_stream"), main, priority=int(os.environ.get("FEDICRA_PROBE_PRIO", "0")))
             net._fi_refresh_packs(net.compute_dtype())       # packs the probe reads: ready BEFORE the fork
             fork = torch.cuda.Event()
             fork.record(main)

@@ -50,8 +50,7 @@ class MyClient(_PCEClient):
         others = []
         if args.strategy in ["FedICRA"]:
             cur = torch.cuda.current_stream()
-            if self._lc_stream is None:
-                self._lc_stream = torch.cuda.Stream(device=x.device)
+            self._lc_stream = ops.stream_beside(self._lc_stream, cur, device=x.device)
             self._lc_stream.wait_stream(cur)
             with torch.cuda.stream(self._lc_stream), torch.no_grad():
                 ids = [c for c in range(args.min_num_clients) if c != args.cid]

@@ -221,10 +221,22 @@ _WGRAD_SIDE = os.environ.get("FI_WGRAD_STREAM", "0") != "0"   # measured: 2.59 m
 _side_used = False
 
 
+def stream_beside(cached, main, device=None, priority=0):
+    """A stream that is NOT `main`, for work meant to run beside it.  torch hands out streams from a round-robin pool of
+    32 per device and priority: in a long-lived process a freshly made stream can BE the one an earlier caller holds --
+    e.g. torch.cuda.graph's capture stream -- and a branch "forked" onto the stream it came from is silently serial.
+    `cached` (or None) is kept when it differs from `main`; otherwise a new one is drawn until it does."""
+    if cached is not None and cached.cuda_stream != main.cuda_stream:
+        return cached
+    for _ in range(64):
+        s = torch.cuda.Stream(device=device, priority=priority)
+        if s.cuda_stream != main.cuda_stream:
+            return s
+    raise RuntimeError("fedicra_amd.ops.stream_beside: torch's stream pool returned the current stream 64 times")
+
+
 def _side_stream(dev):
-    s = _side_streams.get(dev.index)
-    if s is None:
-        s = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    s = _side_streams[dev.index] = stream_beside(_side_streams.get(dev.index), torch.cuda.current_stream(dev), device=dev)
     return s
 
 

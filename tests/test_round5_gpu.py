@@ -218,6 +218,23 @@ def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
     assert h0 and all(torch.allclose(h0[n].float(), h1[n].float(), rtol=1e-4, atol=2e-5) for n in h0)
 
 
+def test_stream_beside_never_returns_the_stream_it_is_beside():
+    """torch's stream pool is round-robin over 32 streams: the 33rd torch.cuda.Stream() of a process IS the first one.  A probe
+    stream drawn late in a long-lived process was torch.cuda.graph's capture stream (seen in the full test suite: the LC
+    forwards "beside" the own forward were captured onto its own stream)."""
+    from fedicra_amd import ops
+    a = torch.cuda.Stream()
+    period = next((k for k in range(1, 257) if torch.cuda.Stream().cuda_stream == a.cuda_stream), None)
+    assert period is not None, "torch's stream pool did not wrap within 256 draws"     # 32 in torch 2.x: this is the hazard
+    for _ in range(period - 1):
+        torch.cuda.Stream()                                              # the next draw from the pool is `a` again
+    b = ops.stream_beside(None, a)
+    assert b.cuda_stream != a.cuda_stream
+    assert ops.stream_beside(b, a) is b                                  # a good cached stream is kept
+    c = ops.stream_beside(a, a)                                          # a cached stream that IS the current one is replaced
+    assert c.cuda_stream != a.cuda_stream
+
+
 # ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
 def _nchw_view(t):
     """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""
