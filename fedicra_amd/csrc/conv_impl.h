@@ -2350,7 +2350,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
   const int cin = (a.depth > 0 ? 3 : 1) * (a.c0 + a.c1), cout = a.cout;
-  int bid = blockIdx.x;
+  // (cit, cot) workgroups of one spatial block read the same gradient / input tiles at the same time: XCD g (= blockIdx % 8, an L2
+  // each) takes a CONTIGUOUS range of the (sb, cot, cit) order instead of every eighth workgroup
+  int bid;
+  {
+    const unsigned B = gridDim.x, g = blockIdx.x & 7u, qq = blockIdx.x >> 3, Bq = B >> 3, r = B & 7u;
+    bid = (int)(g * Bq + (g < r ? g : r) + qq);
+  }
   const int cit = bid % a.nci;
   bid /= a.nci;
   const int cot = bid % a.nco;
@@ -2591,7 +2597,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(WgradArgs a) {
   const int li = lane & 15, kg = lane >> 4;
   const int qo = wave >> 1, qi = wave & 1;
   const int cin = (a.depth > 0 ? 3 : 1) * (a.c0 + a.c1), cout = a.cout;
-  int bid = blockIdx.x;
+  // (cit, cot) workgroups of one spatial block read the same gradient / input tiles at the same time: XCD g (= blockIdx % 8, an L2
+  // each) takes a CONTIGUOUS range of the (sb, cot, cit) order instead of every eighth workgroup
+  int bid;
+  {
+    const unsigned B = gridDim.x, g = blockIdx.x & 7u, qq = blockIdx.x >> 3, Bq = B >> 3, r = B & 7u;
+    bid = (int)(g * Bq + (g < r ? g : r) + qq);
+  }
   const int cit = bid % a.nci;
   bid /= a.nci;
   const int cot = bid % a.nco;

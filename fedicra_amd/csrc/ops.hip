@@ -1085,7 +1085,144 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   }
 }
 
+// Separable row form of the backward for the launches that matter (the four UpBlocks of a 12-image backward pass: 128 us at 0.15-0.25
+// of their HBM floor in the gather form above, which requests 25 vectors and spends ~750 vector instructions per 16 bytes of dx).
+// The interpolation is a tensor product, so its transpose is too:  dx[iy][ix] = sum_l wx[l] * ( sum_k wy[k] * dy[oy_lo+k][ox_lo+l] ).
+// A workgroup owns a run of input rows of one launch: per input row the inner sums over the (at most five) output rows become ONE
+// fp32 row of 2w x C in LDS -- five coalesced loads per vector, row weights wave-uniform -- and the outer sums read it back five
+// times per dx vector.  10 global vector requests per dx vector instead of 25, ~200 instructions instead of ~750; the column taps
+// are tabulated once per workgroup, the row taps of its run by its first lanes.  Weights are lin_coord's, i.e. the forward's.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(const T* __restrict__ dy, T* __restrict__ dx, int nrows, int h, int w,
+                                                                int C, float sh, float sw, int accumulate, int rpw, int cv_shift) {
+  constexpr int VG = DT<T>::VG;
+  constexpr int TABLE = 512, RUN = 16;
+  extern __shared__ __attribute__((aligned(16))) float4 s_t[];                // [2w][C] fp32: the row-combined gradient of the current input row
+  constexpr int Q = VG / 4;                         // float4s per vector
+  __shared__ float s_wx[TABLE][5], s_wy[RUN][5];
+  __shared__ int s_lox[TABLE], s_loy[RUN];
+  const int Ho = 2 * h, Wo = 2 * w, CV = 1 << cv_shift;
+  // workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: runs that share halo rows (neighbours) go to the SAME
+  // XCD -- workgroup b takes run (b % 8) * (gridDim.x / 8) + b / 8 (the grid is a multiple of 8; runs past the end do nothing)
+  const int run = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int row0 = run * rpw, row1 = min(row0 + rpw, nrows);
+  if (row0 >= nrows) return;
+  for (int i = threadIdx.x; i < w; i += 256) {
+    int lo;
+    float wt[5];
+    up_taps(i, w, Wo, sw, lo, wt);
+    s_lox[i] = lo;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_wx[i][k] = wt[k];
+  }
+  if ((int)threadIdx.x < row1 - row0) {
+    int lo;
+    float wt[5];
+    up_taps((row0 + (int)threadIdx.x) % h, h, Ho, sh, lo, wt);
+    s_loy[threadIdx.x] = lo;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_wy[threadIdx.x][k] = wt[k];
+  }
+  __syncthreads();
+  const int rowv = Wo << cv_shift, inv = w << cv_shift;      // vectors of an output row / of an input row
+  for (int row = row0; row < row1; ++row) {
+    const int n = row / h, r = row - row0;
+    const int oy_lo = s_loy[r];
+    float wy[5];
+    const T* src[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      wy[k] = s_wy[r][k];
+      src[k] = dy + ((size_t)n * Ho + min(oy_lo + k, Ho - 1)) * Wo * C;
+    }
+#pragma clang loop vectorize(disable) interleave(disable)   // (else: packed FMAs over lanes of TWO vectors, the row stored word by word)
+    for (int i = threadIdx.x; i < rowv; i += 256) {
+      typename DT<T>::vec_t v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = load_raw<T>(src[k] + (size_t)i * VG);
+      float acc[VG];
+#pragma unroll
+      for (int j = 0; j < VG; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        float g[VG];
+        unpack<T>(v[k], g);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) acc[j] += wy[k] * g[j];
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) s_t[i * Q + q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    __syncthreads();
+    T* const out = dx + (size_t)row * w * C;
+    for (int e = threadIdx.x; e < inv; e += 256) {
+      const int ix = e >> cv_shift, cv = e - (ix << cv_shift);
+      const int lo = s_lox[ix];
+      float acc[VG];
+#pragma unroll
+      for (int j = 0; j < VG; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int l = 0; l < 5; ++l) {
+        const float wl = s_wx[ix][l];
+        const float4* t = s_t + (((min(lo + l, Wo - 1)) << cv_shift) + cv) * Q;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float4 tv = t[q];
+          acc[4 * q] += wl * tv.x, acc[4 * q + 1] += wl * tv.y, acc[4 * q + 2] += wl * tv.z, acc[4 * q + 3] += wl * tv.w;
+        }
+      }
+      T* o = out + (size_t)e * VG;
+      if (accumulate) {
+        float old[VG];
+        load_vec<T>(o, old);
+#pragma unroll
+        for (int j = 0; j < VG; ++j) acc[j] += old[j];
+      }
+      store_vec<T>(o, acc);
+    }
+    __syncthreads();                                 // s_t is rewritten by the next row
+  }
+}
+
 static inline float up_scale(int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
+
+// gather form for small launches, separable row form where a launch has rows enough to fill the chip (FI_UPBWD_ROWS=0: gather form
+// everywhere, A/B runs; FI_UPBWD_WGS: workgroups of the row form -- default one per input row).  tools/upbench.py --bwd --images 12,
+// the four levels of a 12-image backward pass, us: gather form 10.4 / 15.4 / 27.8 / 50.1 = 103.6; row form with its runs dealt
+// round-robin to the XCDs like the workgroups are 8.3 / 15.2 / 24.7 / 46.1 = 94.3 (runs of 4 rows; 8 rows: 88.9 -- the halo rows of
+// neighbouring runs were fetched once per XCD); with neighbouring runs on one XCD 7.6 / 9.4 / 19.7 / 36.7 = 73.4 at one row per
+// workgroup (runs of 2: 78.6, of 4: 83.7, of 16: 104.6).
+template <typename T>
+static int launch_upsample_bwd(const void* dy, void* dx, int N, int h, int w, int C, int accumulate, hipStream_t st) {
+  constexpr int VG = DT<T>::VG;
+  if (C % VG) return FI_ERR_SHAPE;
+  const int CV = C / VG;
+  const long nvec = (long)N * h * w * CV;
+  if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
+  static const long rows_on = [] {
+    const char* v = getenv("FI_UPBWD_ROWS");
+    return v ? atol(v) : 1L;
+  }();
+  static const long wgs = [] {
+    const char* v = getenv("FI_UPBWD_WGS");
+    return v && atol(v) > 0 ? atol(v) : (1L << 20);
+  }();
+  int shift = 0;
+  while ((1 << shift) < CV) ++shift;
+  const long nrows = (long)N * h, lds = (long)2 * w * C * (long)sizeof(float);
+  if (rows_on && (1 << shift) == CV && w <= 512 && lds <= 48 * 1024 && nrows >= 64 && nrows < (1L << 31) && (long)w * CV >= 64) {
+    long rpw = (nrows + wgs - 1) / wgs;
+    if (rpw > 16) rpw = 16;
+    const long blocks = ((nrows + rpw - 1) / rpw + 7) / 8 * 8;
+    hipLaunchKernelGGL(upsample_bwd_rows_kernel<T>, dim3((unsigned)blocks), dim3(256), (size_t)lds, st, (const T*)dy, (T*)dx, (int)nrows,
+                       h, w, C, up_scale(h), up_scale(w), accumulate, (int)rpw, shift);
+  } else {
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for((long)N * h * ((w * CV + 63) / 64), 4)), dim3(256), 0, st, (const T*)dy,
+                       (T*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
+  }
+  FI_CHECK_LAUNCH();
+  return 0;
+}
 
 // launches big enough to be VALU-bound in the flat form take the row form (FI_UP_ROWS=0 keeps the flat form: A/B runs)
 template <typename T>
@@ -1130,29 +1267,10 @@ extern "C" int fi_upsample2x_bwd(int dtype, const void* dy, void* dx, int N, int
                                  void* stream) {
   if (!dy || !dx) return FI_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FI_F32) {
-    if (C % 4) return FI_ERR_SHAPE;
-    const long nvec = (long)N * h * w * (C / 4);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid_for((long)N * h * ((w * (C / 4) + 63) / 64), 4)), dim3(256), 0, st, (const float*)dy,
-                       (float*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
-  } else if (dtype == FI_BF16) {
-    if (C % 8) return FI_ERR_SHAPE;
-    const long nvec = (long)N * h * w * (C / 8);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for((long)N * h * ((w * (C / 8) + 63) / 64), 4)), dim3(256), 0, st, (const bf16_t*)dy,
-                       (bf16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
-  } else if (dtype == FI_F16) {
-    if (C % 8) return FI_ERR_SHAPE;
-    const long nvec = (long)N * h * w * (C / 8);
-    if (nvec >= (1L << 32)) return FI_ERR_UNSUPPORTED;  // kernels index vectors with 32 bits
-    hipLaunchKernelGGL(upsample_bwd_kernel<f16_t>, dim3(grid_for((long)N * h * ((w * (C / 8) + 63) / 64), 4)), dim3(256), 0, st, (const f16_t*)dy,
-                       (f16_t*)dx, N, h, w, C, up_scale(h), up_scale(w), accumulate);
-  } else {
-    return FI_ERR_DTYPE;
-  }
-  FI_CHECK_LAUNCH();
-  return 0;
+  if (dtype == FI_F32) return launch_upsample_bwd<float>(dy, dx, N, h, w, C, accumulate, st);
+  if (dtype == FI_BF16) return launch_upsample_bwd<bf16_t>(dy, dx, N, h, w, C, accumulate, st);
+  if (dtype == FI_F16) return launch_upsample_bwd<f16_t>(dy, dx, N, h, w, C, accumulate, st);
+  return FI_ERR_DTYPE;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -235,6 +235,42 @@ def test_stream_beside_never_returns_the_stream_it_is_beside():
     assert c.cuda_stream != a.cuda_stream
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_upsample_backward_row_form_is_the_transpose_of_the_forward(dtype):
+    """fi_upsample2x_bwd's separable row form (csrc/ops.hip upsample_bwd_rows_kernel; nn.Upsample(scale_factor=2, bilinear,
+    align_corners=True) of /root/reference/code/networks/unet.py:62-66, backward) on shapes that take it -- ragged, a run of rows
+    that crosses an image boundary, one-column maps -- against torch's autograd of F.interpolate in fp64 on the same values, with
+    and without accumulation into dx, and as the exact adjoint of fi_upsample2x_fwd (<up(u), g> = <u, up^T(g)>)."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    vg = 4 if dtype == torch.float32 else 8
+    # (fp32: the kernels' interpolation weights are fp32 like torch's own fp32 kernel -- against fp64 weights a coordinate near 100 is
+    # off by 4e-6, times |g| up to 4)
+    tol = 3e-5 if dtype == torch.float32 else (8e-3 if dtype == torch.bfloat16 else 1e-3)
+    for N, h, w, C in [(2, 37, 50, 2 * vg), (3, 70, 33, 4 * vg), (1, 64, 16, 8 * vg), (5, 19, 64, vg), (12, 32, 32, 128), (1, 300, 8, 8 * vg), (5, 201, 16, 4 * vg)]:
+        gen = torch.Generator().manual_seed(h * 1000 + w)
+        g = torch.randn(N, 2 * h, 2 * w, C, generator=gen).to(dtype)
+        u = torch.randn(N, h, w, C, generator=gen).to(dtype)
+        ref_in = torch.zeros(N, C, h, w, dtype=torch.float64, requires_grad=True)
+        F.interpolate(ref_in, scale_factor=2, mode="bilinear", align_corners=True).backward(g.double().permute(0, 3, 1, 2))
+        ref = ref_in.grad.permute(0, 2, 3, 1)
+        gd, dx = g.to(DEV), torch.full((N, h, w, C), float("nan"), dtype=dtype, device=DEV)
+        L.upsample2x_bwd(gd, dx)
+        err = float((dx.double().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= tol, ("plain", N, h, w, C, err)
+        base = torch.randn(N, h, w, C, generator=gen).to(dtype)
+        acc = base.to(DEV).clone()
+        L.upsample2x_bwd(gd, acc, accumulate=True)
+        err = float((acc.double().cpu() - (ref + base.double())).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= 2 * tol, ("accumulate", N, h, w, C, err)
+        up = torch.empty(N, 2 * h, 2 * w, C, dtype=dtype, device=DEV)
+        L.upsample2x_fwd(u.to(DEV), up)
+        a = float((up.double() * gd.double()).sum())
+        b = float((u.to(DEV).double() * dx.double()).sum())
+        scale = float((up.double() * gd.double()).abs().sum())
+        assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 4e-3 if dtype == torch.bfloat16 else 5e-4) * scale * 0.05 + 1e-9, (a, b, scale)
+
+
 # ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
 def _nchw_view(t):
     """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""
