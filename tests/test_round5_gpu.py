@@ -271,6 +271,40 @@ def test_upsample_backward_row_form_is_the_transpose_of_the_forward(dtype):
         assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 4e-3 if dtype == torch.bfloat16 else 5e-4) * scale * 0.05 + 1e-9, (a, b, scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_trilinear_row_forms_against_torch(dtype):
+    """fi_upsample3d2x_fwd / _bwd in their row forms (csrc/ops3d.hip upsample3d_fwd_rows_kernel / upsample3d_bwd_rows_kernel;
+    nn.Upsample(scale_factor=(2,2,2), mode='trilinear') of /root/reference/code/networks/utils.py:260-276 UnetUp3_CT) on shapes that
+    take them -- ragged, one-voxel axes, rows longer than a workgroup -- against F.interpolate and its autograd in fp64 on the same
+    values, and backward as the exact adjoint of forward."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    vg = 4 if dtype == torch.float32 else 8
+    tol = 2e-6 if dtype == torch.float32 else (8e-3 if dtype == torch.bfloat16 else 1e-3)
+    for N, d, h, w, C in [(2, 8, 8, 8, 4 * vg), (1, 5, 13, 9, 4 * vg), (2, 7, 9, 4, 8 * vg), (1, 1, 70, 33, vg), (1, 9, 8, 80, 4 * vg),
+                          (3, 6, 11, 1, 32 * vg), (1, 16, 16, 16, 128)]:
+        gen = torch.Generator().manual_seed(d * 100 + h * 10 + w)
+        u = torch.randn(N, d, h, w, C, generator=gen).to(dtype)
+        g = torch.randn(N, 2 * d, 2 * h, 2 * w, C, generator=gen).to(dtype)
+        ref_in = u.double().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+        ref_up = F.interpolate(ref_in, scale_factor=(2, 2, 2), mode="trilinear", align_corners=False)
+        ref_up.backward(g.double().permute(0, 4, 1, 2, 3))
+        ud, gd = u.to(DEV), g.to(DEV)
+        up = torch.full((N, 2 * d, 2 * h, 2 * w, C), float("nan"), dtype=dtype, device=DEV)
+        L.upsample3d2x_fwd(ud, up)
+        err = float((up.double().cpu() - ref_up.detach().permute(0, 2, 3, 4, 1)).abs().max()) / max(1.0, float(ref_up.abs().max()))
+        assert err <= tol, ("fwd", N, d, h, w, C, err)
+        dx = torch.full((N, d, h, w, C), float("nan"), dtype=dtype, device=DEV)
+        L.upsample3d2x_bwd(gd, dx)
+        rg = ref_in.grad.permute(0, 2, 3, 4, 1)
+        err = float((dx.double().cpu() - rg).abs().max()) / max(1.0, float(rg.abs().max()))
+        assert err <= tol, ("bwd", N, d, h, w, C, err)
+        a = float((up.double() * gd.double()).sum())
+        b = float((ud.double() * dx.double()).sum())
+        scale = float((up.double() * gd.double()).abs().sum())
+        assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 4e-3 if dtype == torch.bfloat16 else 5e-4) * scale * 0.05 + 1e-9, (a, b, scale)
+
+
 # ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
 def _nchw_view(t):
     """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""

@@ -22,7 +22,23 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--up3d", action="store_true", help="trilinear x2 forward and backward at unet_3D's four levels (2 x 128^3 input)")
     a = ap.parse_args()
+    if a.up3d:
+        tf = tb = 0.0
+        for d, c in ((8, 256), (16, 128), (32, 64), (64, 32)):
+            x = torch.randn(2, d, d, d, c, device="cuda").to(torch.bfloat16)
+            y = torch.empty(2, 2 * d, 2 * d, 2 * d, c, device="cuda", dtype=torch.bfloat16)
+            g = torch.randn_like(y)
+            dx = torch.empty_like(x)
+            uf = timeit(lambda: L.upsample3d2x_fwd(x, y), a.reps)
+            ub = timeit(lambda: L.upsample3d2x_bwd(g, dx), a.reps)
+            tf += uf
+            tb += ub
+            nb = (x.numel() + y.numel()) * 2
+            print(f"up3d 2 x {d:3d}^3 x {c:3d}: fwd {uf:8.1f} us {nb / uf / 1e3:8.1f} GB/s   bwd {ub:8.1f} us {nb / ub / 1e3:8.1f} GB/s")
+        print(f"up3d total fwd {tf:.1f} us  bwd {tb:.1f} us  (FI_UP3D_ROWS={os.environ.get('FI_UP3D_ROWS', '1')})")
+        return
     if a.bwd:
         tot = 0.0
         for f, c in ((16, 128), (8, 64), (4, 32), (2, 16)):
