@@ -23,7 +23,7 @@ EXPORTS = [
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
-    "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
+    "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_maxpool3d_bwd_add", "fi_conv3d_wgrad_fused_partial", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
     "fi_pdice_bwd", "fi_dice_counts", "fi_gatedcrf_fwd", "fi_tree_mst_workspace", "fi_tree_grid_weights", "fi_tree_mst", "fi_tree_bfs", "fi_tree_edge_weights", "fi_tree_edge_weights_bwd", "fi_tree_aggr_up", "fi_tree_prop_down", "fi_tree_grad_rec", "fi_seg_borders", "fi_surface_distances", "fi_augment2d", "fi_fedopt_step", "fi_depth_to_space2x", "fi_groupnorm_fwd", "fi_groupnorm_bwd", "fi_channel_stats", "fi_conv3d_fwd", "fi_conv3d_dgrad", "fi_conv3d_wgrad_workspace", "fi_conv3d_wgrad", "fi_convtranspose2x_fwd", "fi_convtranspose2x_dgrad", "fi_convtranspose2x_wgrad_workspace",
     "fi_convtranspose2x_wgrad", "fi_adamw_hyper",
     "fi_lr_poly_advance", "fi_adamw_step", "fi_sgd_step", "fi_amp_unscale", "fi_amp_guard", "fi_amp_update", "fi_scale", "fi_axpy", "fi_ala_update", "fi_global_avgmax", "fi_channel_gate_fwd",
@@ -605,6 +605,11 @@ def maxpool3d_bwd(x, dy, dx):
     _chk(lib().fi_maxpool3d_bwd(dt(x.dtype), ptr(x), ptr(dy), ptr(dx), N, D, H, W, Cc, stream()), "fi_maxpool3d_bwd")
 
 
+def maxpool3d_bwd_add(x, dy, add, dx):
+    N, D, H, W, Cc = _dev(x).shape
+    _chk(lib().fi_maxpool3d_bwd_add(dt(x.dtype), ptr(x), ptr(dy), ptr(add), ptr(dx), N, D, H, W, Cc, stream()), "fi_maxpool3d_bwd_add")
+
+
 def upsample3d2x_fwd(x, y):
     N, d, h, w, Cc = _dev(x).shape
     _chk(lib().fi_upsample3d2x_fwd(dt(x.dtype), ptr(x), ptr(y), N, d, h, w, Cc, stream()), "fi_upsample3d2x_fwd")
@@ -984,6 +989,27 @@ def conv3d_wgrad_fused(x0, x1, dy, dw_all, dbias, *, ksize):
         _chk(lib().fi_conv3d_wgrad_fused(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), ptr(dw_all), ptr(dbias), ptr(ws),
                                          C.c_long(nbytes), stream()), "fi_conv3d_wgrad_fused")
     return True
+
+
+def conv3d_wgrad_fused_partial(x0, x1, dy, want_bias, *, ksize):
+    """Stage 1 of conv3d_wgrad_fused only.  -> (workspace tensor, slices, stride) for a later fi_wgrad_reduce_multi (table word 9 =
+    cin), or None when the shape is not covered."""
+    N, D, H, W, c0 = _dev(x0).shape
+    c1 = 0 if x1 is None else x1.shape[4]
+    d = FiConv(dt(x0.dtype), N, H, W, ksize, c0, c1, dy.shape[4], 0, 0, 0, 0)
+    nbytes = lib().fi_conv3d_wgrad_fused_workspace(C.byref(d), D)
+    if nbytes == FI_ERR_UNSUPPORTED:
+        return None
+    if nbytes < 0:
+        _chk(int(nbytes), "fi_conv3d_wgrad_fused_workspace")
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x0.device)
+    cin, co, vox = c0 + c1, dy.shape[4], N * D * H * W
+    slices, stride = C.c_int(0), C.c_long(0)
+    with _timed("conv3d_wgrad", (str(x0.dtype)[6:], N, D, H, W, cin, co, ksize, "fused"), 2.0 * vox * cin * co * ksize ** 3,
+                vox * (cin + co) * _esz(x0) + cin * co * ksize ** 3 * 4):
+        _chk(lib().fi_conv3d_wgrad_fused_partial(C.byref(d), D, ptr(x0), ptr(x1), ptr(dy), int(want_bias), ptr(ws), C.c_long(nbytes),
+                                                 C.byref(slices), C.byref(stride), stream()), "fi_conv3d_wgrad_fused_partial")
+    return ws, slices.value, stride.value
 
 
 def convtranspose2x_fwd(x, w_packed, bias_taps, packed, y, N, D, H, W, cin, cout, three_d):

@@ -604,7 +604,7 @@ extern "C" int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const vo
 // table rows (int64 x 7): { partial ptr, slice stride (floats), slices, dw ptr, n_dw, dbias ptr or 0, cout }
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long* __restrict__ table, int ntensors) {
   // One launch folds every layer's partial slices (278 MB per U-Net step) into the gradient buffer.  Rows of
-  // FI_WGRAD_ROW int64: {part, stride, slices, dw, n_dw, dbias|0, cout, first_block, log2(lanes)}.  A block owns
+  // FI_WGRAD_ROW int64: {part, stride, slices, dw, n_dw, dbias|0, cout, first_block, log2(lanes), cin3}.  A block owns
   // 4*lanes consecutive elements of one tensor; its 256/lanes thread groups take the slices round-robin with 16-B loads
   // (rows are 16-B aligned: stride % 4 == 0), and the groups are then folded through LDS in a fixed order.
   __shared__ float sm[256 * 4];
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long
   float* dbias = reinterpret_cast<float*>(r[5]);
   const size_t n = n_dw + (dbias ? (size_t)r[6] : 0);
   const int ll = (int)r[8], lanes = 1 << ll, groups = 256 >> ll;
+  const size_t cin3 = (size_t)r[9];     // > 0: the slices are a one-launch 3x3x3 gradient [cout][9][3][cin3], dw is the PARAMETER layout [cout][cin3][3][3][3]
   const int e = threadIdx.x & (lanes - 1), g = threadIdx.x >> ll;
   const size_t base = ((size_t)blockIdx.x - (size_t)r[7]) * (size_t)(lanes * 4);
   const size_t i = base + (size_t)e * 4;
@@ -646,10 +647,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const long long
     if (j >= n) break;
     float s = sm[q];
     for (int h = 1; h < groups; ++h) s += sm[h * (lanes * 4) + q];
-    if (j < n_dw)
-      dw[j] += s;
-    else
+    if (j >= n_dw) {
       dbias[j - n_dw] += s;
+    } else if (cin3 == 0) {
+      dw[j] += s;
+    } else {
+      const size_t ci = j % cin3, q1 = j / cin3, kd = q1 % 3, q2 = q1 / 3, t = q2 % 9, co = q2 / 9;
+      dw[(co * cin3 + ci) * 27 + kd * 9 + t] += s;
+    }
   }
 }
 
@@ -892,6 +897,20 @@ extern "C" int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, con
   FiConv s = *d;
   s.N = d->N * D;
   return wgrad_impl(&s, x0, x1, dy, dw_all, dbias, workspace, workspace_bytes, 1, nullptr, nullptr, stream, D);
+}
+
+// Stage 1 of the same only (fi_conv2d_wgrad_partial's 3D sibling): the partial slices stay in `workspace`, *slices / *stride (floats)
+// describe them -- [slices][cout*9*3*cin (+ cout bias sums when want_bias)] -- and fi_wgrad_reduce_multi folds them later, for all
+// layers of a backward pass in one launch, straight into the parameter's own [cout][cin][3][3][3] layout (table word 9 = cin).
+extern "C" int fi_conv3d_wgrad_fused_partial(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, int want_bias,
+                                             void* workspace, long workspace_bytes, int* slices, long* stride, void* stream) {
+  if (!d || !x0 || !dy || !workspace || !slices || !stride) return FI_ERR_NULL;
+  if (int rc = conv3d_wgrad_fused_ok(d, D)) return rc;
+  if (d->c1 > 0 && !x1) return FI_ERR_NULL;
+  FiConv s = *d;
+  s.N = d->N * D;
+  return wgrad_impl(&s, x0, x1, dy, (float*)workspace, want_bias ? (float*)workspace : nullptr, workspace, workspace_bytes, 0, slices,
+                    stride, stream, D);
 }
 
 // dw_taps: fp32 [kd][cout][k][k][cin] (one 2D filter gradient per depth tap), dbias fp32 [cout] or NULL; both ADDED to.

@@ -34,9 +34,11 @@ static inline int grid3(long work, int per_block) {
 
 // ---- MaxPool3d(kernel 2, stride 2).  x [N,D,H,W,C] -> y [N,D/2,H/2,W/2,C].  Backward routes dy to the FIRST maximum of
 //      the window in (d, h, w) scan order (strict >), as ATen does.
-template <typename T, bool BWD>
+//      ADD: dx = add + the routed gradient -- an encoder feature that also feeds a decoder skip connection receives two gradients,
+//      and the sum is made here instead of by an elementwise launch of autograd's (one fp32 add per element, then the storage type).
+template <typename T, bool BWD, bool ADD = false>
 __global__ __launch_bounds__(256) void maxpool3d_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
-                                                        int N, int D, int H, int W, int C) {
+                                                        int N, int D, int H, int W, int C, const T* __restrict__ add = nullptr) {
   constexpr int VG = DT<T>::VG;
   const int CV = C / VG, Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long nvec = (long)N * Do * Ho * Wo * CV;
@@ -83,6 +85,15 @@ __global__ __launch_bounds__(256) void maxpool3d_kernel(const T* __restrict__ x,
           }
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q][j] = q == best ? g[j] : 0.f;
+      }
+      if (ADD) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float s[VG];
+          ld<T>(add + offs[q], s);
+#pragma unroll
+          for (int j = 0; j < VG; ++j) o[q][j] += s[j];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) st<T>(out + offs[q], o[q]);
@@ -464,6 +475,28 @@ extern "C" int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* 
   else
     hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
                        (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, C);
+  FI_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fi_maxpool3d_bwd_add(int dtype, const void* x, const void* dy, const void* add, void* dx, int N, int D, int H, int W,
+                                    int C, void* stream) {
+  if (!x || !dy || !add || !dx) return FI_ERR_NULL;
+  if ((D & 1) || (H & 1) || (W & 1)) return FI_ERR_SHAPE;
+  hipStream_t st_ = (hipStream_t)stream;
+  const int vg = dtype == FI_F32 ? 4 : 8;
+  if (dtype != FI_F32 && dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_DTYPE;
+  if (C % vg) return FI_ERR_SHAPE;
+  const long nvec = (long)N * (D / 2) * (H / 2) * (W / 2) * (C / vg);
+  if (dtype == FI_F32)
+    hipLaunchKernelGGL((maxpool3d_kernel<float, true, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const float*)x,
+                       (const float*)dy, (float*)dx, N, D, H, W, C, (const float*)add);
+  else if (dtype == FI_F16)
+    hipLaunchKernelGGL((maxpool3d_kernel<f16_t, true, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const f16_t*)x,
+                       (const f16_t*)dy, (f16_t*)dx, N, D, H, W, C, (const f16_t*)add);
+  else
+    hipLaunchKernelGGL((maxpool3d_kernel<bf16_t, true, true>), dim3(grid3(nvec, 256)), dim3(256), 0, st_, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, C, (const bf16_t*)add);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -125,11 +125,13 @@ class unet_3D(FlatStoreMixin, nn.Module):
         channel selection of unet_3D_lc in after the deepest block."""
         dt = self.compute_dtype()
         x = inputs.permute(0, 2, 3, 4, 1).contiguous().to(dt)            # NCDHW -> dense NDHWC (plumbing)
-        conv1 = self.conv1._run(x)
-        conv2 = self.conv2._run(ops3d.maxpool3d(conv1))
-        conv3 = self.conv3._run(ops3d.maxpool3d(conv2))
-        conv4 = self.conv4._run(ops3d.maxpool3d(conv3))
-        center = self.center._run(ops3d.maxpool3d(conv4))
+        # (pool_skip3d: an encoder feature is pooled AND concatenated in the up path -- the sum of its two gradients is made by the
+        # pooling's backward pass)
+        conv1, pooled = ops3d.pool_skip3d(self.conv1._run(x))
+        conv2, pooled = ops3d.pool_skip3d(self.conv2._run(pooled))
+        conv3, pooled = ops3d.pool_skip3d(self.conv3._run(pooled))
+        conv4, pooled = ops3d.pool_skip3d(self.conv4._run(pooled))
+        center = self.center._run(pooled)
         if gate is not None:
             center = gate(center)
         center = ops3d.dropout(center, self.dropout1.p, self.training, owner=self.dropout1)

@@ -240,9 +240,10 @@ def _side_stream(dev):
     return s
 
 
-def _defer_wgrad_reduce(ws, stride, slices, dw, n_dw, db, cout, keep=None):
+def _defer_wgrad_reduce(ws, stride, slices, dw, n_dw, db, cout, keep=None, cin3=0):
+    """cin3 > 0: the slices are a one-launch 3x3x3 gradient [cout][9][3][cin3] and dw the parameter's own [cout][cin3][3][3][3]."""
     global _wgrad_cb_queued
-    _pending_wgrad.append((ws, stride, slices, dw, n_dw, db, cout, keep))
+    _pending_wgrad.append((ws, stride, slices, dw, n_dw, db, cout, keep, cin3))
     if not _wgrad_cb_queued:
         # runs once, after the last node of the current backward pass
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad)
@@ -261,10 +262,10 @@ def flush_wgrad():
         torch.cuda.current_stream().wait_stream(_side_stream(_pending_wgrad[0][0].device))
         _side_used = False
     rows, nblocks = [], 0
-    for ws, stride, slices, dw, n_dw, db, cout, _keep in _pending_wgrad:
+    for ws, stride, slices, dw, n_dw, db, cout, _keep, cin3 in _pending_wgrad:
         ll = 8 if slices <= 16 else 6 if slices <= 64 else 4      # fewer lanes per row when there are many slices to fold
         rows.append([ws.data_ptr(), stride, slices, dw.data_ptr(), n_dw, 0 if db is None else db.data_ptr(), cout,
-                     nblocks, ll, 0])
+                     nblocks, ll, cin3])
         nblocks += -(-stride // (4 << ll))
     dev = _pending_wgrad[0][0].device
     capturing = torch.cuda.is_current_stream_capturing()

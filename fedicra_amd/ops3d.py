@@ -178,6 +178,8 @@ def _norm_consts(cout, dev):
 
 
 _IN_BATCHED = os.environ.get("FI_IN_BATCHED", "1") != "0"      # measurement switch: 0 = one InstanceNorm launch per sample and pass
+_WGRAD3D_DEFER = os.environ.get("FI_WGRAD3D_DEFER", "1") != "0"   # measurement switch: 0 = a reduce launch + a permuted add per 3x3x3 layer
+_POOLSKIP3D = os.environ.get("FI_POOLSKIP3D", "1") != "0"        # measurement switch: 0 = autograd adds skip and pooling gradients itself
 _FIRST3D = os.environ.get("FI_FIRST3D", "1") != "0"            # measurement switch: 0 = the per-tap implicit GEMMs of rounds 1-4
 
 
@@ -366,6 +368,16 @@ class _Conv3d(Function):
             if not done and kd == 3 and ksize == 3:
                 # ONE launch over all slices of all volumes, the depth taps as channel groups of the input side
                 # (zeros out of the iteration's arena -- fp64 words viewed as fp32; the tensor dies with the add below)
+                if _WGRAD3D_DEFER and mod is not None and need_w and gw is None and (db is None or gb is None) and wt_.is_contiguous():
+                    # both targets are gradient SINKS (a flat-store model): stage 1 now, stage 2 of ALL layers as one launch at
+                    # the end of the backward pass, written straight into the parameter layout (ops.flush_wgrad, table word 9) --
+                    # a reduce launch and a permuted add per layer otherwise (17 + 17 launches, 0.28 ms of a unet_3D iteration)
+                    part = L.conv3d_wgrad_fused_partial(x0c, x1c, dyc, db is not None, ksize=ksize)
+                    if part is not None:
+                        ws, slices, stride = part
+                        ops._defer_wgrad_reduce(ws, stride, slices, wt_, cout * 27 * cin, db, cout, None, cin3=cin)
+                        done = True
+            if not done and kd == 3 and ksize == 3:
                 ng = cout * ksize * ksize * kd * cin
                 gall = ops._ctx.arena.take((ng + 1) // 2, dev).view(torch.float32)[:ng].view(cout, ksize, ksize, kd, cin)   # [Cout][9][3][Cin]
                 if L.conv3d_wgrad_fused(x0c, x1c, dyc, gall, db, ksize=ksize):        # (declines before it launches anything)
@@ -376,6 +388,35 @@ class _Conv3d(Function):
                 L.conv3d_wgrad(x0c, x1c, dyc, gwk, db, ksize=ksize)
                 wt_.add_(gwk.permute(1, 4, 0, 2, 3))                   # -> [Cout,Cin,kD,kH,kW]
         return dx0, dx1, gw, gb, None, None, None
+
+
+class _PoolSkip3d(Function):
+    """(skip, pooled) = (z, maxpool3d(z)) for an encoder feature that feeds both the next level and a decoder skip connection
+    (/root/reference/code/networks/unet_3D.py:63-76: conv1..conv4 are pooled AND concatenated in the up path).  autograd would add
+    the two gradients with an elementwise launch of its own (4 per iteration, 84 us at 2 x 128^3); backward here makes the sum in
+    the pooling pass (ops._PoolSkip's 3D sibling; even extents only -- the caller falls back to maxpool3d otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, D, H, W, Cc = x.shape
+        y = torch.empty((N, D // 2, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.maxpool3d_fwd(x, y)
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dskip, dy):
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return dskip
+        dx = torch.empty_like(x)
+        if dskip is None:
+            L.maxpool3d_bwd(x, dy.contiguous(), dx)
+        else:
+            if dskip.dtype != x.dtype:
+                dskip = dskip.to(x.dtype)
+            L.maxpool3d_bwd_add(x, dy.contiguous(), dskip.contiguous(), dx)
+        return dx
 
 
 class _MaxPool3d(Function):
@@ -457,6 +498,14 @@ def conv3d(x0, x1, conv, norm=False, y_f32=False):
 
 def maxpool3d(x):
     return _MaxPool3d.apply(x)
+
+
+def pool_skip3d(x):
+    """Returns (x, maxpool3d(x)); use the first result wherever x is consumed besides the pooling (FI_POOLSKIP3D=0, odd extents or a
+    tensor that needs no gradient: the plain pooling)."""
+    if _POOLSKIP3D and x.requires_grad and not ((x.shape[1] | x.shape[2] | x.shape[3]) & 1):
+        return _PoolSkip3d.apply(x)
+    return x, _MaxPool3d.apply(x)
 
 
 def upsample3d2x(x):

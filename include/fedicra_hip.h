@@ -194,11 +194,19 @@ int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, cons
 long fi_conv3d_wgrad_fused_workspace(const FiConv* d, int D);
 int fi_conv3d_wgrad_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_all, float* dbias,
                           void* workspace, long workspace_bytes, void* stream);
+/* Stage 1 of fi_conv3d_wgrad_fused only (the 3D sibling of fi_conv2d_wgrad_partial): partial slices [slices][cout*9*3*cin (+ cout
+ * bias sums when want_bias)] stay in `workspace` (fi_conv3d_wgrad_fused_workspace bytes); fold them with fi_wgrad_reduce_multi, table
+ * word 9 = cin, into the parameter gradient [cout][cin][3][3][3] -- one launch for every layer of a backward pass instead of a reduce
+ * launch and a permuted add per layer (unet_3D: 17 + 17 launches, 0.28 ms of a 6.3 ms iteration). */
+int fi_conv3d_wgrad_fused_partial(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, int want_bias,
+                                  void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
 
 /* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
  * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of
  * fi_wgrad_reduce_multi over a device table (int64[n][FI_WGRAD_ROW]):
- * { partial ptr, stride (multiple of 4), slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout, first_block, log2(lanes) }
+ * { partial ptr, stride (multiple of 4), slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout, first_block, log2(lanes), cin3 }
+ * (cin3 = 0: dw has the slices' own layout; cin3 > 0: the slices come from fi_conv3d_wgrad_fused_partial -- [cout][9][3][cin3] --
+ * and dw is the parameter's [cout][cin3][3][3][3])
  * where a workgroup folds 4*lanes consecutive elements (lanes in {16, 64, 256}: few lanes when there are many slices),
  * tensor t owns workgroups [first_block_t, first_block_t + ceil(stride_t / (4*lanes_t))) and nblocks is their total.
  * dw/dbias += fixed-order slice sums. */
@@ -349,6 +357,10 @@ int fi_upfuse_tuning(int rows);
  * nn.MaxPool3d(2) (unet_3D.py:35): y[N,D/2,H/2,W/2,C]; backward routes dy to the first maximum in (d,h,w) scan order. */
 int fi_maxpool3d_fwd(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
 int fi_maxpool3d_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, void* stream);
+/* dx = add + the routed gradient (add: the gradient the same tensor receives as a skip connection, same layout as x): the sum
+ * autograd would make with an elementwise launch of its own. */
+int fi_maxpool3d_bwd_add(int dtype, const void* x, const void* dy, const void* add, void* dx, int N, int D, int H, int W, int C,
+                         void* stream);
 /* nn.Upsample(scale_factor=(2,2,2), mode='trilinear') with align_corners=False (networks/utils.py:264):
  * [N,d,h,w,C] -> [N,2d,2h,2w,C];  backward = exact adjoint (gather over the 4x4x4 candidate outputs). */
 int fi_upsample3d2x_fwd(int dtype, const void* x, void* y, int N, int d, int h, int w, int C, void* stream);

@@ -305,6 +305,95 @@ def test_trilinear_row_forms_against_torch(dtype):
         assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 4e-3 if dtype == torch.bfloat16 else 5e-4) * scale * 0.05 + 1e-9, (a, b, scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_maxpool3d_backward_with_the_skip_gradient_added(dtype):
+    """fi_maxpool3d_bwd_add = fi_maxpool3d_bwd + the skip connection's gradient, one fp32 add per element before the storage type
+    (/root/reference/code/networks/unet_3D.py:63-76: conv1..conv4 are pooled and concatenated)."""
+    from fedicra_amd import _lib as L
+    vg = 4 if dtype == torch.float32 else 8
+    for N, D, H, W, C in [(2, 4, 6, 8, vg), (1, 16, 16, 16, 4 * vg), (1, 2, 2, 2, 2 * vg)]:
+        gen = torch.Generator().manual_seed(D * 100 + H)
+        x = torch.randn(N, D, H, W, C, generator=gen).to(dtype).to(DEV)
+        x[:, ::2, ::2, ::2] = 0.25
+        x[:, 1::2, 1::2, 1::2] = 0.25                                       # ties: the first maximum in (d, h, w) order takes the gradient
+        dy = torch.randn(N, D // 2, H // 2, W // 2, C, generator=gen).to(dtype).to(DEV)
+        add = torch.randn(N, D, H, W, C, generator=gen).to(dtype).to(DEV)
+        plain, fused = torch.empty_like(x), torch.full_like(x, float("nan"))
+        L.maxpool3d_bwd(x, dy, plain)
+        L.maxpool3d_bwd_add(x, dy, add, fused)
+        assert torch.equal(fused, (plain.float() + add.float()).to(dtype))
+
+
+def test_unet3d_deferred_filter_gradients_and_skip_sums_equal_the_per_layer_forms():
+    """A unet_3D iteration on the flat store with (a) every 3x3x3 filter gradient's partial slices folded by ONE launch at the end of
+    the backward pass straight into the parameter layout (fi_conv3d_wgrad_fused_partial + fi_wgrad_reduce_multi, table word 9) and
+    (b) the two gradients of conv1..conv4 summed by the pooling's backward pass (ops3d.pool_skip3d) -- against the same iteration with
+    a reduce launch + a permuted add per layer and autograd's own sums: the same partial slices in the same order, so the filter
+    gradients agree to fp32 round-off of one differently-associated add; eager and captured."""
+    from fedicra_amd import ops, ops3d
+    from fedicra_amd.networks.net_factory_3d import net_factory_3d
+    from fedicra_amd.networks.unet import set_compute_dtype
+    x = torch.rand(2, 1, 32, 32, 32, device=DEV)
+    y = (torch.rand(2, 32, 32, 32, device=DEV) > 0.5).to(torch.uint8)
+    res = {}
+    saved = ops3d._WGRAD3D_DEFER, ops3d._POOLSKIP3D
+    calls = []
+    orig = ops._defer_wgrad_reduce
+
+    def spy(*a, **k):
+        calls.append(k.get("cin3", 0))
+        return orig(*a, **k)
+
+    ops._defer_wgrad_reduce = spy
+    try:
+        for mode in ("per-layer", "deferred", "captured"):
+            ops3d._WGRAD3D_DEFER = ops3d._POOLSKIP3D = mode != "per-layer"
+            torch.manual_seed(1)
+            net = net_factory_3d("unet_3D", 1, 2).cuda().train()
+            set_compute_dtype(net, "bf16")
+            for m in net.modules():
+                if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout3d)):
+                    m.p = 0.0
+
+            def backward():
+                ops.begin_iteration(torch.device(DEV))
+                out = net(x).permute(0, 2, 3, 4, 1)
+                N, D, H, W, C = out.shape
+                ops.ce_loss(out.reshape(N * D, H, W, C), y.reshape(N * D, H, W), 255).backward()
+
+            net.zero_grad()
+            calls.clear()
+            if mode == "captured":
+                backward()                                                  # warm: packs, arenas
+                net.zero_grad()
+                torch.cuda.synchronize()
+                ops.reserve_graph_tables()
+                ops.bump_weights_epoch()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    backward()
+                net.flat_grads.zero_()
+                g.replay()
+            else:
+                backward()
+            torch.cuda.synchronize()
+            if mode == "per-layer":
+                assert not any(calls)
+            else:
+                assert sum(1 for c in calls if c > 0) >= 15, calls           # every 3x3x3 layer but the first took the deferred form
+            res[mode] = net.flat_grads.clone()
+    finally:
+        ops3d._WGRAD3D_DEFER, ops3d._POOLSKIP3D = saved
+        ops._defer_wgrad_reduce = orig
+    ref = res["per-layer"]
+    scale = float(ref.abs().max())
+    assert scale > 0
+    for mode in ("deferred", "captured"):
+        err = float((res[mode] - ref).abs().max())
+        assert err <= 2e-3 * scale, (mode, err, scale)      # (the InstanceNorm statistics are atomic sums: runs are not bit-identical)
+    assert float((res["captured"] - res["deferred"]).abs().max()) <= 2e-3 * scale
+
+
 # ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
 def _nchw_view(t):
     """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""
