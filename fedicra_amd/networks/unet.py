@@ -257,7 +257,12 @@ class LCEncoder(_FiModule):
         feats, hmaps = [], []
         n = len(self.conv_list)
         for i, blk in enumerate(self.conv_list):
-            x = blk._run(x)
+            if i > 0 and feats and isinstance(blk, DownBlock) and feats[-1] is x:
+                # the feature is pooled here AND read by the decoder's skip connection: both gradients in one backward pass
+                # (ops._PoolSkip, like Encoder._run; autograd added them with an elementwise launch per level otherwise)
+                feats[-1], x = blk._run_skip(x)
+            else:
+                x = blk._run(x)
             h = None
             if i >= n - self.n_pcs:
                 x, h = self.pcs_list[i - n + self.n_pcs]._run(x, emb)
