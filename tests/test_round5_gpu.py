@@ -292,7 +292,7 @@ def test_trilinear_row_forms_against_torch(dtype):
         ud, gd = u.to(DEV), g.to(DEV)
         up = torch.full((N, 2 * d, 2 * h, 2 * w, C), float("nan"), dtype=dtype, device=DEV)
         L.upsample3d2x_fwd(ud, up)
-        err = float((up.double().cpu() - ref_up.detach().permute(0, 2, 3, 4, 1)).abs().max()) / max(1.0, float(ref_up.abs().max()))
+        err = float((up.double().cpu() - ref_up.detach().permute(0, 2, 3, 4, 1)).abs().max()) / max(1.0, float(ref_up.detach().abs().max()))
         assert err <= tol, ("fwd", N, d, h, w, C, err)
         dx = torch.full((N, d, h, w, C), float("nan"), dtype=dtype, device=DEV)
         L.upsample3d2x_bwd(gd, dx)
