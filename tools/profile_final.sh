@@ -5,8 +5,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 TAG=${1:-r05_z}
-bash tools/profile_round.sh $TAG 2>&1 | tail -25
+# PMC passes first: the bench line that follows then finds a traffic file taken on ITS sources (roofline.traffic is refused otherwise)
 bash tools/pmc_round.sh $TAG 2>&1 | tail -12
+cd $GRAFT_REPO_ROOT
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/
+bash tools/profile_round.sh $TAG 2>&1 | tail -25
 bash tools/profile_ala.sh $TAG 2>&1 | tail -45
 bash tools/profile_gaps.sh $TAG 2>&1 | tail -40
 bash tools/profile_c4.sh ${TAG}_c4 2>&1 | tail -12
