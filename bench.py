@@ -403,7 +403,7 @@ class Volumes:
             bound, ach, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         table = os.environ.get("FEDICRA_BENCH_TABLE")
         if table:
-            with open(table, "w") as f:
+            with open(table + getattr(self.a, "table_suffix", ""), "w") as f:
                 f.write(f"# per-launch-shape roofline of one {self.kind} training iteration (2 instrumented iterations, HIP events, {dtype_name})\n")
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
                     us = v["ms"] / v["calls"] * 1e3
@@ -492,6 +492,7 @@ def volumes_leg(a, rank, world, dev, dist, kind, steps=20, warmup=12):
     import copy
     b = copy.copy(a)
     b.size, b.batch, b.steps, b.warmup = 128, 2, steps, warmup
+    b.table_suffix = "." + kind             # FEDICRA_BENCH_TABLE: the legs write <path>.c4 / <path>.c5 beside the headline's own table
     dtype = "bf16" if kind == "c4" else "fp16"
     t0 = time.perf_counter()
     vol = Volumes(b, rank, world, dev, dtype, kind=kind)
