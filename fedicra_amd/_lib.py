@@ -300,16 +300,20 @@ def conv_tuning(v2=-1, nf=0, ck=0, wgs_per_cu=0):
     _chk(lib().fi_conv_tuning(int(v2), int(nf), int(ck), int(wgs_per_cu)), "fi_conv_tuning")
 
 
-def in_xform(coef, slope, *, pool=False, drop=None, seed_group_stride=0):
+def in_xform(coef, slope, *, pool=False, drop=None, seed_group_stride=0, group0=0):
     """FiInXform for a source that holds a raw conv output: coef = fp32 [2][G][C] from bn_finalize_groups (None: the source
-    is used as it is); drop = (mode, p, seed, mask, seed_offset) as ops._drop_spec returns it (RNG element mode only)."""
+    is used as it is); drop = (mode, p, seed, mask, seed_offset) as ops._drop_spec returns it (RNG element mode only).
+    group0: the launch covers the images of groups group0, group0 + 1, ... only (its group 0 reads coefficient row group0; no
+    dropout draws in that form: their seeds are numbered from the launch's first group)."""
     if coef is None:
         return None
     G, Cc = coef.shape[1], coef.shape[2]
     mode, p, seed, mask, soff = drop if drop is not None else (DROP_NONE, 0.0, 0, None, None)
     if mode not in (DROP_NONE, DROP_RNG_ELEM) or mask is not None:
         raise FiError("the fused forward draws its dropout masks on the device (RNG element mode only)")
-    t = FiInXform(coef.data_ptr(), coef[1].data_ptr(), float(slope), int(pool), mode, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+    if group0 and (mode != DROP_NONE or not 0 <= group0 < G):
+        raise FiError("in_xform: a group offset goes with no dropout and an existing group")
+    t = FiInXform(coef[0, group0].data_ptr(), coef[1, group0].data_ptr(), float(slope), int(pool), mode, float(p), seed & 0xFFFFFFFFFFFFFFFF,
                   seed_group_stride & 0xFFFFFFFFFFFFFFFF, None if soff is None else soff.data_ptr())
     t._keep = (coef, soff)
     return t

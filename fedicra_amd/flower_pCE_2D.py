@@ -70,6 +70,11 @@ class MyClient(BaseClient):
         # streams (measurement switch: 0 = round 3's events)
         self.probe_defer_running = os.environ.get("FEDICRA_PROBE_DEFER", "1") != "0"
         self.aux_stats_only = os.environ.get("FEDICRA_AUX_STATS", "1") != "0"   # (measurement switch: 0 = the heads in full)
+        # head phase: the own forward as group 0 of the batched LC forwards (see _iteration).  OFF by default: the two-stream form
+        # had already taken what there was to take -- the captured head-phase step replays in 5.43 ms merged against 5.51 ms with
+        # the own forward as a pass of its own beside the batch (tools/own_in_probe_ab.py, same process), and the bench's rounds
+        # measured 1 195 against 1 375 images/s (ABBA on one box, gpurun_out/v5_bench.log).  FEDICRA_OWN_IN_PROBE=1 turns it on.
+        self.own_in_probe = os.environ.get("FEDICRA_OWN_IN_PROBE", "0") != "0"
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
 
@@ -146,6 +151,7 @@ class MyClient(BaseClient):
         head_phase = i_iter < self.args.iters - self.args.rep_iters
         for name, param in self.model.named_parameters():
             param.requires_grad = (name.replace("model.", "") in local_keys) == head_phase
+        self._head_only = head_phase                         # nothing below decoder.out_conv receives a gradient in this iteration
         return "head" if head_phase else "body"
 
     def _iteration(self, x, y, rec: _GraphStep):
@@ -157,8 +163,23 @@ class MyClient(BaseClient):
         batched, probe_stream, probe_tail, enc_done = None, None, None, None
         others = [c for c in range(args.min_num_clients) if c != args.cid]
         net = self.model.model
-        side = (self.probe_beside and args.strategy in ["FedICRA"] and hasattr(net, "probe_heatmaps") and x.is_cuda
-                and ops.probe_ready() and net.training)
+        can_batch = (args.strategy in ["FedICRA"] and hasattr(net, "probe_heatmaps") and x.is_cuda and ops.probe_ready()
+                     and net.training)
+        side = self.probe_beside and can_batch
+        merged = None
+        if (can_batch and self.own_in_probe and self.__dict__.get("_head_only", False) and self.aux_stats_only
+                and hasattr(getattr(net, "decoder", None), "out_conv")):
+            # HEAD PHASE (:84-101: only decoder.out_conv trains): no gradient flows below the logits convolution, so of the own
+            # forward (:106) nothing is read but the logits' input, the heat-map and -- as side effects -- the BatchNorm statistics
+            # and the dropout draws.  It travels as GROUP 0 of the batched LC forwards (:128-139): first in every BatchNorm's
+            # update order and every dropout layer's draw order, like the reference's call order; its activations are never
+            # materialised except the last decoder feature.  12-image launches worth 1.4 ms of isolated launch time become an
+            # eighth of the batch's work (0.64 ms) on one stream -- which is what the two streams already made of them (see __init__).
+            with torch.no_grad():
+                merged = net.probe_heatmaps(x, others, own=True)
+        if merged is not None:
+            side = False
+            self.merged_iterations = self.__dict__.get("merged_iterations", 0) + 1     # (eager runs and captures; replays do not pass here)
         if side:
             # The K-1 no-grad LC forwards (:128-139) do not depend on the client's own forward (:106), only on the weights and
             # the batch: they run on a SECOND stream beside it -- the own forward's 12-image launches fill the gaps the batched
@@ -182,9 +203,14 @@ class MyClient(BaseClient):
                 ops._ctx.bn_events = {}                      # (round 3's form: one event per layer, the probe waits for each)
         deferred = None
         try:
-            # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
-            # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
-            out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
+            if merged is not None:
+                maps, feat = merged
+                out = [net._out(ops.conv2d(feat, None, net.decoder.out_conv, y_f32=True)), None, None, None, None, None, [maps[0]]]
+                batched = maps[1:]
+            else:
+                # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
+                # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
+                out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
             if side:
                 probe_stream.wait_event(fork)
                 enc_done = torch.cuda.Event() if self.probe_tail_beside else None
@@ -217,12 +243,15 @@ class MyClient(BaseClient):
                     torch.cuda.current_stream().wait_stream(probe_stream)
                     self._run_deferred(deferred)
                     deferred = None
-            else:
+            elif merged is None:
                 with torch.no_grad():                                                # all K-1 forwards as one batch
                     batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
             base = None
             if batched is not None and heatmaps[-1].is_cuda:
                 base = batched[0]._base if batched[0]._base is not None else batched[0]
+                if merged is not None and base.dtype == torch.float32 and base.is_contiguous() and \
+                        base.numel() == (len(others) + 1) * heatmaps[-1].numel():
+                    base = base.reshape(-1)[heatmaps[-1].numel():]                   # the own map leads the tensor: the others follow it
                 if base.numel() != len(others) * heatmaps[-1].numel() or base.dtype != torch.float32 or not base.is_contiguous():
                     base = None
             if base is not None:

@@ -758,10 +758,11 @@ class RawAct:
     coefficient rows of its BatchNorm (fp32 [2][G][C], one row pair per statistics group) and the activation slope.  The
     consuming convolution applies them in its loader (fi_conv2d_fwd_fused).  `shared`: y holds ONE group's images, which
     every group reads."""
-    __slots__ = ("y", "coef", "slope", "shared")
+    __slots__ = ("y", "coef", "slope", "shared", "own_only")
 
-    def __init__(self, y, coef, slope, shared=False):
+    def __init__(self, y, coef, slope, shared=False, own_only=False):
         self.y, self.coef, self.slope, self.shared = y, coef, slope, shared
+        self.own_only = own_only            # y holds group 0's images only (probe_conv_bn(store="own")); coef has every group's rows
 
 
 def probe_after(bn):
@@ -839,6 +840,22 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
     if (pool or in_drop is not None) and t0 is None:
         raise L.FiError("pooling / dropout in the loader need a raw source 0")
     stats = _ctx.arena.take(groups * L.STATS_SLOTS * cout * 2, dev)
+    if store == "own":
+        # the caller reads group 0's output only (the client's own forward travelling as the first group of the batch,
+        # flower_pCE_2D._iteration): its images as one launch that stores, the other groups' as a statistics-only launch -- each with
+        # its own rows of the coefficient and statistics tables -- instead of writing G - 1 outputs nobody reads
+        if r0 is None or shared0 or pool or in_drop is not None or s1 is not None or groups < 2:
+            store = True                                         # (forms without a group offset: write everything, read the first)
+        else:
+            B, per = N // groups, L.STATS_SLOTS * cout * 2
+            y = torch.empty((B, H, W, cout), dtype=x0.dtype, device=dev)
+            L.conv2d_fwd_fused(x0[:B], L.in_xform(r0.coef, r0.slope), None, None, wp, conv.bias, y, stats[:per], ksize=ksize, groups=1,
+                               cout=cout)
+            L.conv2d_fwd_fused(x0[B:], L.in_xform(r0.coef, r0.slope, group0=1), None, None, wp, conv.bias, None, stats[per:], ksize=ksize,
+                               groups=groups - 1, cout=cout)
+            coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
+            _probe_finalize(stats, groups, float(B * H * W), bn, coef)
+            return RawAct(y, coef, slope, own_only=True)
     y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev) if store else None
     done = False
     if (not store and _XCORR and ksize == 3 and x1 is None and not shared0 and not pool and in_drop is None
@@ -919,6 +936,15 @@ def probe_materialize(r, groups):
     selection; every level for the ALA epoch's frozen encoder): all statistics groups in one launch."""
     z = torch.empty_like(r.y)
     L.bn_act_pool_groups(r.y, r.coef, r.slope, z, groups, pool=False)
+    return z
+
+
+def probe_materialize_own(r, groups):
+    """z = act(BN(y)) of GROUP 0 of a raw activation (the client's own forward inside the batch): r.y holds group 0's images
+    (probe_conv_bn(store="own")) or every group's."""
+    y = r.y if r.own_only else r.y[:r.y.shape[0] // groups]
+    z = torch.empty_like(y)
+    L.bn_act_pool_groups(y, r.coef[:, 0:1], r.slope, z, 1, pool=False)
     return z
 
 
