@@ -485,6 +485,11 @@ def volumes_line(a, vol, elapsed, agg_ms, world, roof):
     return line
 
 
+def _staging_calibration():
+    from fedicra_amd import staging
+    return list(staging.calibration)
+
+
 def volumes_leg(a, rank, world, dev, dist, kind, steps=20, warmup=12):
     """configs[3] / configs[4] beside the headline: a short run of the 3D client OUTSIDE the c3 timed
     region -- `warmup` untimed steps (both resident batch buffers captured), `steps` timed ones incl. their FedAvg rounds, then
@@ -886,10 +891,11 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(a))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # a rank drives five HIP streams once a communicator exists (training, LC forwards, batch staging, aggregation, RCCL's own):
-    # on the runtime's default four hardware queues two of them share one and serialise (same box, ALA epoch 20.6 ms with four,
-    # 20.0 with eight) -- read when the runtime comes up, i.e. at the first device call below
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # GPU_MAX_HW_QUEUES is left at the runtime's default (4).  A rank drives five HIP streams once a communicator exists, and eight
+    # hardware queues measured 0.3-0.6 ms off the ALA epoch -- but WHICH streams then share a queue follows from the order the
+    # streams were made in, and one order in three put the batch staging behind the compute queue: 66.3 -> 72 ms of training per round
+    # (same box, gpurun_out/v8_matrix.log: 8 queues without the RCCL group 1 304 / 1 318 images/s against 1 378-1 390 for 4 queues with
+    # or without it and 8 with it; a form of the step with one compute stream: 1 195).  Four queues measured the same either way.
     from fedicra_amd.comm import init_process_group_from_env
     rank, local, world = init_process_group_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -990,6 +996,9 @@ def main():
                        "data_location": ("pinned host memory; batch i+1 crosses PCIe on a side stream while iteration i computes "
                                          "(inside the timed region)") if a.data == "host" else "resident in HBM",
                        "h2d_bytes_per_step": h2d_bytes_per_step,
+                       # how the staging streams were chosen (fedicra_amd.staging._copy_stream: a candidate whose copy ran BESIDE
+                       # the compute stream's kernels in a one-off trial, not behind them on a shared hardware queue)
+                       "staging_streams": _staging_calibration(),
                        "resident_images_per_sec": None if resident is None else resident["images_per_sec"],
                        "resident": resident,
                        "fp32_images_per_sec": None if fp32 is None else fp32["images_per_sec"],
