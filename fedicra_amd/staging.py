@@ -17,6 +17,10 @@ _NO_PREFETCH = os.environ.get("FEDICRA_NO_PREFETCH", "0") != "0"      # measurem
 
 
 _CALIBRATE = os.environ.get("FEDICRA_STAGE_CALIBRATE", "0") != "0"    # (measurement switch, off: see _copy_stream)
+# HIP priority of the staging stream (measurement switch).  -1 = high was tried as a way to give the copies hardware queues of their
+# own whatever the creation order: 1 344 / 1 350 -> 1 204 / 1 199 images/s on one box (gpurun_out/w1_prio.log) -- the blit kernels then go
+# ahead of the compute kernels they were meant to hide behind.  0 stays.
+_STAGE_PRIO = int(os.environ.get("FEDICRA_STAGE_PRIO", "0"))
 calibration = []               # one record per stager: {"tries", "overlap", "copy_alone_ms", "copy_beside_ms", "kernels_ms"} (bench.py reports it)
 
 
@@ -30,7 +34,7 @@ def _copy_stream(device):
     candidate is taken when its copy finishes about as fast as alone (not behind the kernels).  One-off, ~20 ms per stager."""
     dev = torch.device(device)
     if not _CALIBRATE or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
-        return torch.cuda.Stream(device=dev)
+        return torch.cuda.Stream(device=dev, priority=_STAGE_PRIO)
     from . import ops
     main = torch.cuda.current_stream(dev)
     host = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
