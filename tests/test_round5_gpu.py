@@ -521,7 +521,7 @@ def test_masked_l1_launch_equals_the_references_sum_and_division(terms):
         loss = _MaskedL1.apply(pd, rois.to(DEV), torch.tensor([float(n)], dtype=torch.float64, device=DEV), 0.6, *md)
         (loss * 1.7).backward()
         torch.cuda.synchronize()
-        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+        assert abs(float(loss.detach()) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(loss.detach()), float(ref))
         assert torch.allclose(pd.grad.cpu(), pr.grad, atol=1e-9, rtol=2e-6)
         for a, b in zip(md, mr):
             assert torch.allclose(a.grad.cpu(), b.grad, atol=1e-9, rtol=2e-6)
