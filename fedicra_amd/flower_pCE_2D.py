@@ -73,7 +73,8 @@ class MyClient(BaseClient):
         # head phase: the own forward as group 0 of the batched LC forwards (see _iteration).  OFF by default: the two-stream form
         # had already taken what there was to take -- the captured head-phase step replays in 5.43 ms merged against 5.51 ms with
         # the own forward as a pass of its own beside the batch (tools/own_in_probe_ab.py, same process), and the bench's rounds
-        # measured 1 195 against 1 375 images/s (ABBA on one box, gpurun_out/v5_bench.log).  FEDICRA_OWN_IN_PROBE=1 turns it on.
+        # measured 1 362 against 1 357-1 364 images/s (same box, gpurun_out/v9_q4.log; with eight hardware queues 1 195 against
+        # 1 375: the batch staging behind the one compute stream's queue).  FEDICRA_OWN_IN_PROBE=1 turns it on.
         self.own_in_probe = os.environ.get("FEDICRA_OWN_IN_PROBE", "0") != "0"
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
