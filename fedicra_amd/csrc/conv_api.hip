@@ -36,6 +36,8 @@ int fi_conv_fwd_ws_bf16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& 
 int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws2_bf16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_ws2_f16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_dma_bf16(int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+int fi_conv_fwd_dma_f16(int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_thin_f32n_bf16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_thin_f32n_f16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_narrow_in_bf16(const ConvArgs& a, hipStream_t st);
@@ -80,7 +82,8 @@ static long env_v2() {
   return v;
 }
 extern "C" int fi_conv_tuning(int v2, int nf, int ck, int wgs_per_cu) {
-  if ((nf && nf != 1 && nf != 2 && nf != 4) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 16) return FI_ERR_SHAPE;
+  if ((nf && nf != 1 && nf != 2 && nf != 4 && !(v2 == 7 && nf == 8)) || (ck && ck != 16 && ck != 32) || wgs_per_cu < 0 || wgs_per_cu > 16)
+    return FI_ERR_SHAPE;
   if (v2 > 7) return FI_ERR_SHAPE;
   g_tune[0] = v2;
   g_tune[1] = nf;
@@ -333,7 +336,29 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
       const bool xfok = a.xf == 1 || (ws2_plain && a.xf == 0 && a.gimages > 0);
       const bool wanted = env_ws2() == 2 || g_tune[0] == 7 || (xfok && ok16 && tiles16 * (cout / 128) >= 1024) ||
                           (xfok && ok32 && cout == 64 && tiles32 >= 1024);
-      if (ok32 && wanted) {
+      // LDS-DMA GEMM tile (conv_fwd_dma_kernel; conv_dma.h): two 16 x 16-pixel sub-tiles x 128 output channels per workgroup, operands by
+      // LDS-DMA, the transform in place in LDS.  fi_conv_tuning(7, 8, ...) forces it wherever it applies.  Measured level with or behind the
+      // 16-row form above on every batched layer of unet_lc (round 6, profiles/r06_a_dma_kbench.txt: 64^2 128->128 dropout 158 vs 158 us,
+      // 32^2 256->256 164 vs 143, two-source 64^2 256->128 223 vs 211): a stage is bound by the CU's ~18 B/clk L2 -> LDS fill and by the
+      // drain of the matrix pipe at every stage barrier, not by the weight slab's re-reads -- so it is NOT a default (FI_DMA = 1 makes it
+      // the choice for the batched launches the 16-row form would take, except the one-group head)
+      {
+        static const long dma_on = env_long("FI_DMA", 0);
+        const bool okd = okb && cout % 128 == 0 && cin % 32 == 0;
+        const bool forced = g_tune[0] == 7 && g_tune[1] == 8;
+        const bool si_shape = cin == 64 && cout / 128 >= 2 && cout / 128 <= 4;
+        const bool auto_dma = dma_on && g_tune[0] < 0 && env_ws2() == 1 && xfok && ok16 && !si_shape && tiles16 * (cout / 128) >= 1024;
+        if (okd && (forced || auto_dma)) {
+          a.w = d->w16;
+          a.wrows = rows;
+          a.tilesY = fi_cdiv(d->H, 16);
+          a.nct = cout / 128;
+          const int rc = d->dtype == FI_F16 ? fi_conv_fwd_dma_f16((int)g_tune[3], a, st) : fi_conv_fwd_dma_bf16((int)g_tune[3], a, st);
+          if (rc != FI_ERR_UNSUPPORTED) return rc;
+          a.w = w_plain, a.wrows = 0, a.tilesY = tilesY_plain, a.nct = nct_plain;
+        }
+      }
+      if (ok32 && wanted && !(g_tune[0] == 7 && g_tune[1] == 8)) {
         int tr = ok16 ? 16 : 32;
         static const long force_tr = env_long("FI_WS2_TR", 0);
         if (force_tr == 16 && ok16) tr = 16;

@@ -148,7 +148,9 @@ int fi_conv2d_stats_xcorr(const FiConv* d, const FiInXform* t0, int group_images
  * consumer waves, double-buffered LDS stages; additionally Cin, Cout >= 32, destinations of whole 8-channel groups) with
  * 4 + 4, 4 + 8 or 8 + 2x4 consumer + producer waves, 7: the 64 x 64-wave-tile kernel wherever it applies (needs FiConv.w16;
  * nf = 1: 16-row x 128-channel tiles, 2: 32 x 64, 4: the whole filter resident in LDS -- Cout = 32 or 64 and
- * Cin * Cout * 18 bytes <= ~84 KB); nf / ck / wgs_per_cu = 0 keep the defaults, else force the slab width
+ * Cin * Cout * 18 bytes <= ~84 KB, 8: the LDS-DMA form -- two 16 x 16-pixel sub-tiles x 128 channels per workgroup, every
+ * operand byte by buffer_load ... lds, the input transform in place in LDS; Cout % 128 == 0, sources of whole 32-channel
+ * groups); nf / ck / wgs_per_cu = 0 keep the defaults, else force the slab width
  * (1, 2, 4 fragments of 16 channels; 2 or 4 for the wave-specialised kernel), channel chunk (16, 32) and workgroups per CU.
  * Process-wide, not thread-safe.  The kernels compute the same products in fp32; only the ORDER in which the channel chunks
  * are accumulated follows the chunk width, so two configurations agree to fp32 round-off (a bf16 output may differ in its

@@ -119,7 +119,8 @@ def test_ws2_kernel_equals_the_one_tile_kernel(dtype, case):
         L.conv_tuning(0)
         want, st_want = run()                                  # no chunk-major operand attached: the one-tile kernel
         w._fi_w16 = w16
-        forms = ([1] if cout % 128 == 0 else []) + ([2] if cout % 64 == 0 else [])
+        # 8 = the LDS-DMA GEMM tile (conv_fwd_dma_kernel, csrc/conv_dma.h): 128-channel slabs
+        forms = ([1, 8] if cout % 128 == 0 else []) + ([2] if cout % 64 == 0 else [])
         if cout in (32, 64) and 78336 + (c0 + c1) * cout * 18 + 768 <= 160 * 1024:
             forms.append(4)
         assert forms

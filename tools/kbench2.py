@@ -22,7 +22,8 @@ LAYERS = [(1, 16, 0, 16, "drop"), (0.5, 16, 0, 32, "pool"), (0.5, 32, 0, 32, "dr
           (0.0625, 128, 0, 256, "pool"), (0.0625, 256, 0, 256, "drop"),
           (0.125, 128, 128, 128, "xf"), (0.125, 128, 0, 128, "xf"), (0.25, 64, 64, 64, "xf"), (0.25, 64, 0, 64, "xf"),
           (0.5, 32, 32, 32, "xf"), (0.5, 32, 0, 32, "xf"), (1, 16, 16, 16, "xf"), (1, 16, 0, 16, "xf"),
-          (0.25, 64, 0, 512, "head")]
+          (0.25, 64, 0, 512, "head"),
+          (0.125, 64, 0, 128, "xf"), (0.0625, 128, 0, 256, "xf")]   # (the pooled DownBlock inputs as the batched launches see them)
 
 
 def timeit(fn, reps):
@@ -55,6 +56,7 @@ def main():
     ap.add_argument("--ws", action="store_true", help="only the one-tile kernel vs the wave-specialised kernel")
     ap.add_argument("--thin", action="store_true", help="only the one-tile kernel vs the thin-layer kernel, thin layers only")
     ap.add_argument("--ws2", action="store_true", help="one-tile kernel vs the library's old choice (FI_V2 rule) vs the 64x64-wave-tile kernel")
+    ap.add_argument("--cfgs", default="", help="comma-separated config names to keep (v1 always runs)")
     a = ap.parse_args()
     td = torch.bfloat16
     dev = "cuda"
@@ -68,7 +70,10 @@ def main():
     if a.ws2:
         a.ws = True
         configs = [("v1", (0, 0, 0, 0)), ("old", (2, 0, 0, 0)), ("ws2_16", (7, 1, 0, 0)), ("ws2_32", (7, 2, 0, 0)),
-                   ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2)), ("ws2_res", (7, 4, 0, 0)), ("ws2_resw2", (7, 4, 0, 2))]
+                   ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2)), ("ws2_res", (7, 4, 0, 0)), ("ws2_resw2", (7, 4, 0, 2)),
+                   ("dma", (7, 8, 0, 0))]
+    if a.cfgs:
+        configs = [c for c in configs if c[0] == "v1" or c[0] in a.cfgs.split(",")]
     tot = {}
     for mode in ("plain", "fused"):
         if a.only and a.only != mode:
@@ -117,7 +122,7 @@ def main():
                     continue
                 if cfg[0] == 3 and (c0 + c1 > 32 or cout > 32):
                     continue
-                if cfg[0] == 7 and (not hasattr(w, "_fi_w16") or pool or (cfg[1] == 1 and cout % 128) or (cfg[1] == 2 and cout % 64)):
+                if cfg[0] == 7 and (not hasattr(w, "_fi_w16") or pool or (cfg[1] in (1, 8) and cout % 128) or (cfg[1] == 2 and cout % 64)):
                     continue
                 if cfg[0] == 7 and cfg[1] == 4 and not (cout in (32, 64) and 78336 + (c0 + c1) * cout * 18 + 768 <= 160 * 1024):
                     continue
