@@ -192,22 +192,32 @@ __device__ __forceinline__ uint32_t fi_rand32(uint64_t seed, uint64_t idx) {
   x ^= x >> 16;
   return x ^ (uint32_t)(seed >> 32);
 }
-// Element-wise dropout draws for the 4 consecutive elements of group `group` (= flat element index / 4): ONE full
-// hash of the group index gives the word h, one more multiply-xorshift round of h the word g: four 16-BIT draws, returned
-// in the top halves of r[0..3] so that callers keep comparing against the 32-bit threshold (the keep probability is
-// quantised to 2^-16: 1.5e-5 relative at p = 0.05 .. 0.5).  g is a BIJECTION of h, so the four draws carry 32 bits of
-// entropy, not 64: (r[2], r[3]) is a deterministic function of (r[0], r[1]) -- a mixing one, which is what a keep mask
-// needs: each position keeps at the nominal rate and the four keep bits of a group (and of neighbouring groups) show no
-// pairwise correlation at p = 0.05 / 0.3 / 0.5 (tests/test_ops_gpu.py::test_dropout_rng_statistics_and_replay).  Integer multiplies are quarter rate on CDNA and every conv / BN kernel
-// that regenerates the mask is VALU-issue-bound (tools/ws2_trace.py: a loader stage of 256^2 32->32 takes 3 200 cycles
-// without and 5 700 with dropout): per 4 elements this is 4 multiplies + ~14 other VALU ops where the per-element
-// multiply-xorshift it replaces (round 2) cost 7 + ~30, and a full hash per element ~65 instructions per element.
-__device__ __forceinline__ void fi_rand32x4(uint64_t seed, uint64_t group, uint32_t (&r)[4]) {
-  const uint32_t h = fi_rand32(seed, group);
+// Element-wise dropout draws for the 4 consecutive elements of group `group` (= flat element index / 4).  A PAIR of groups (8
+// consecutive elements: one 16-byte vector of 16-bit storage) shares ONE full hash of the pair index, the word w0; three more
+// multiply-xorshift rounds give w1 = m(w0), w2 = m(w1), w3 = m(w2): eight 16-BIT draws, the even group from (w0, w1), the odd one from
+// (w2, w3), returned in the top halves of r[0..3] so that callers keep comparing against the 32-bit threshold (the keep probability is
+// quantised to 2^-16: 1.5e-5 relative at p = 0.05 .. 0.5).  m is a BIJECTION, so the eight draws carry 32 bits of entropy: each is a
+// deterministic -- mixing -- function of the others, which is what a keep mask needs: each position keeps at the nominal rate and the
+// keep bits of a pair (and of neighbouring pairs) show no pairwise correlation at p = 0.05 / 0.3 / 0.5
+// (tests/test_ops_gpu.py::test_dropout_rng_statistics_and_replay).  Integer multiplies are quarter rate on CDNA and every conv / BN kernel
+// that regenerates the mask is VALU-issue-bound (tools/ws2_trace.py: a loader stage of 256^2 32->32 takes 3 200 cycles without and
+// 5 700 with dropout; tools/dma_trace.py: +2 700 on a 7 100-cycle stage): per 8 elements this is 6 multiplies + ~25 other VALU ops where
+// one hash per 4 elements (rounds 3-5) cost 8 + ~28 and a full hash per element ~65 instructions per element.  A caller that draws both
+// groups of a vector (VG = 8) shares the hash and w1 by common-subexpression elimination -- the calls are inlined.
+__device__ __forceinline__ uint32_t fi_rand_mix(uint32_t h) {
   uint32_t g = (h ^ 0x9E3779B9u) * 0x2C1B3C6Du;
-  g ^= g >> 15;
-  r[0] = h << 16, r[1] = h & 0xFFFF0000u;
-  r[2] = g << 16, r[3] = g & 0xFFFF0000u;
+  return g ^ (g >> 15);
+}
+__device__ __forceinline__ void fi_rand32x4(uint64_t seed, uint64_t group, uint32_t (&r)[4]) {
+  const uint32_t w0 = fi_rand32(seed, group >> 1);
+  const uint32_t w1 = fi_rand_mix(w0);
+  uint32_t a = w0, b = w1;
+  if (group & 1) {
+    a = fi_rand_mix(w1);
+    b = fi_rand_mix(a);
+  }
+  r[0] = a << 16, r[1] = a & 0xFFFF0000u;
+  r[2] = b << 16, r[3] = b & 0xFFFF0000u;
 }
 // keep with probability (1-p): threshold on a 32-bit uniform
 __device__ __forceinline__ bool fi_keep(uint64_t seed, uint64_t idx, uint32_t drop_thresh) {

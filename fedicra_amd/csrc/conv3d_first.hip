@@ -306,7 +306,7 @@ extern "C" int fi_conv3d_first_fwd(int dtype, int N, int D, int H, int W, const 
                                    void* y, double* stats, long stats_stride, void* stream) {
   if (!x || !w || !y) return FI_ERR_NULL;
   if (dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_UNSUPPORTED;
-  if (N < 1 || D < 1 || H < 1 || W < 1 || (long)N * D * H * W * 32 >= (1L << 32) - 64) return FI_ERR_SHAPE;
+  if (N < 1 || D < 1 || H < 1 || W < 1 || (long)N * D * H * W * 32 >= (1L << 31) - 64) return FI_ERR_SHAPE;
   First3dArgs a{x, w, bias, y, stats, stats_stride, nullptr, N, D, H, W};
   const dim3 g((unsigned)first3d_blocks(N, D, H, W)), b(256);
   if (dtype == FI_BF16)
@@ -321,7 +321,7 @@ extern "C" int fi_conv3d_first_wgrad(int dtype, int N, int D, int H, int W, cons
                                      void* workspace, long workspace_bytes, void* stream) {
   if (!x || !dy || !workspace || (!dw && !dbias)) return FI_ERR_NULL;
   if (dtype != FI_BF16 && dtype != FI_F16) return FI_ERR_UNSUPPORTED;
-  if (N < 1 || D < 1 || H < 1 || W < 1 || (long)N * D * H * W * 32 >= (1L << 32) - 64) return FI_ERR_SHAPE;
+  if (N < 1 || D < 1 || H < 1 || W < 1 || (long)N * D * H * W * 32 >= (1L << 31) - 64) return FI_ERR_SHAPE;
   if (workspace_bytes < fi_conv3d_first_wgrad_workspace(N, D, H, W)) return FI_ERR_SHAPE;
   First3dArgs a{x, nullptr, nullptr, const_cast<void*>(dy), nullptr, 0, (float*)workspace, N, D, H, W};
   const long blocks = first3d_blocks(N, D, H, W);

@@ -10,9 +10,11 @@
 
 namespace {
 
-// torch's area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false): max(0, scale * (dst + 0.5) - 0.5)
+// torch's area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false): max(0, scale * (dst + 0.5) - 0.5), the
+// multiply-subtract as ONE fused operation -- what ATen's CPU build contracts it to (checked bit for bit on ragged scales, 37 x 29 ->
+// 101 x 131: every element with the fused form, 93 % with two roundings)
 __device__ __forceinline__ float src_index(float scale, int dst) {
-  const float s = scale * ((float)dst + 0.5f) - 0.5f;
+  const float s = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
   return s < 0.f ? 0.f : s;
 }
 // bilinear taps along one axis (upsample_bilinear2d: i0 = (int)src, i1 = i0 + (i0 < n - 1), l1 = src - i0, l0 = 1 - l1)
@@ -72,9 +74,16 @@ __global__ __launch_bounds__(256) void tree_prep_kernel(const float* __restrict_
       float* d = m.dst[k] + (long)n * Ck * HW + r;
       for (int c = 0; c < Ck; ++c) {
         const float* sc = s + (long)c * m.sc[k];
-        // upsample_bilinear2d's expression: h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (w0lambda * c + w1lambda * d)
-        d[(long)c * HW] = ly0 * (lx0 * sc[y0 * sy + x0 * sx] + lx1 * sc[y0 * sy + x1 * sx]) +
-                          ly1 * (lx0 * sc[y1 * sy + x0 * sx] + lx1 * sc[y1 * sy + x1 * sx]);
+        // upsample_bilinear2d's expression h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (w0lambda * c + w1lambda * d) in ATen-CPU's
+        // ROUNDING ORDER (round 6): its generic kernel evaluates `out = t0 * w0; out += t1 * w1` per axis, which its build
+        // contracts to fma(t0, w0, round(t1 * w1)) = fi_lerp2 -- along x for both rows, then along y.  Checked against torch-CPU in this
+        // image: every element of 24^2 -> 96^2 and 64^2 -> 256^2, 96 % of a ragged 30 x 41 -> 120 x 131; on SMALL outputs (64^2 and below)
+        // torch's kernel mixes contractions by position on ~25 % of the elements and no single formula reproduces it -- the golden g17 maps
+        // are of that size, so its tree-tie bars stay an envelope (tests/test_parity2_gpu.py), but a tighter one than with hipcc's own
+        // contraction of the line: this order lands on the trees torch's GPU kernel lands on (tools/tree_g17_diag.py)
+        const float r0 = fi_lerp2(lx0, sc[y0 * sy + x0 * sx], lx1, sc[y0 * sy + x1 * sx]);
+        const float r1 = fi_lerp2(lx0, sc[y1 * sy + x0 * sx], lx1, sc[y1 * sy + x1 * sx]);
+        d[(long)c * HW] = fi_lerp2(ly0, r0, ly1, r1);
       }
     }
     if (roi_src) {

@@ -781,6 +781,9 @@ def run_probe_deferred(items):
     layers in one launch (fi_bn_running_groups_multi; FI_BN_RUN_MULTI=0 = one launch per layer, the same kernel arithmetic)."""
     if not items:
         return
+    cur = torch.cuda.current_stream()
+    for it in items:                                   # the statistics were produced on the probe stream and are read here, on another one:
+        it[0].record_stream(cur)                       # tell the caching allocator (a buffer that is not the arena's could be handed out again; ADVICE r5)
     with torch.no_grad():
         if _BN_RUN_MULTI:
             L.bn_running_groups_multi(items)

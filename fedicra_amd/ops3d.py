@@ -159,21 +159,35 @@ def _w_all(weight, dtype, mode):
 
 
 _const_cache = {}
+_capture_consts = {}          # constants first made inside the CURRENT stream capture: (device, width) -> tensors
+_capture_state = [False]      # was the previous call inside a capture?  (a capture that begins drops the previous capture's set)
 
 
 def _norm_consts(cout, dev):
     """(ones, zeros, running-mean scratch, running-var scratch) of an affine-free InstanceNorm: the same four vectors for every
     layer of that width (momentum 0 leaves the scratch statistics as they are) -- four fill launches per convolution otherwise.
-    Cached per (device, width) and only when created EAGERLY: tensors first made inside a stream capture live in that graph's
-    private pool and their fills are merely recorded, so another graph must not find them in a process-global cache (ADVICE
-    r4) -- a capture without an eager warm-up before it makes its own, uncached."""
+    Cached per (device, width) process-wide only when created EAGERLY: tensors first made inside a stream capture live in that
+    graph's private pool and their fills are merely recorded, so another graph must not find them.  A capture
+    without an eager warm-up keeps its own set for ITS duration: one set per width and capture, not four fills per layer baked
+    into the graph."""
     key = (dev.index, cout)
     c = _const_cache.get(key)
-    if c is None:
-        c = (torch.ones(cout, device=dev), torch.zeros(cout, device=dev), torch.zeros(cout, device=dev),
-             torch.ones(cout, device=dev))
-        if not torch.cuda.is_current_stream_capturing():
-            _const_cache[key] = c
+    if c is not None:
+        return c
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and not _capture_state[0]:
+        _capture_consts.clear()                      # a new capture began
+    _capture_state[0] = capturing
+    if capturing:
+        c = _capture_consts.get(key)
+        if c is not None:
+            return c
+    c = (torch.ones(cout, device=dev), torch.zeros(cout, device=dev), torch.zeros(cout, device=dev),
+         torch.ones(cout, device=dev))
+    if capturing:
+        _capture_consts[key] = c
+    else:
+        _const_cache[key] = c
     return c
 
 
@@ -186,7 +200,8 @@ _FIRST3D = os.environ.get("FI_FIRST3D", "1") != "0"            # measurement swi
 def _first_ok(dt, ydt, kd, ksize, x0, x1, cout):
     """The shape csrc/conv3d_first.hip covers: ONE input channel, 16 output channels, 3x3x3, 16-bit storage."""
     return (_FIRST3D and dt != torch.float32 and ydt == dt and kd == 3 and ksize == 3 and x1 is None and x0.shape[4] == 1
-            and cout == 16 and x0.numel() * 32 < (1 << 32) - 64)
+            and cout == 16 and x0.numel() * 32 < (1 << 31) - 64)      # (byte offsets into the 16-channel side stay below 2^31: the kernel marks
+                                                                        #  out-of-image lanes by setting bit 31 of the offset -- ADVICE r5)
 
 
 def _point_ok(dt, ydt, kd, ksize, x0, x1, cout, norm):

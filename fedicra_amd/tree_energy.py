@@ -99,7 +99,9 @@ class _MaskedL1(Function):
 
 def _prep(preds, low_feats, unlabeled_ROIs, highs):
     """-> prob, low, rois, N, size, [highs resized]: one HIP launch, or (FI_TREE_GLUE=0 / CPU tensors) the torch expressions."""
-    if _use_glue(preds):
+    # (the kernel reads the mask as 0 / 1: a float or integer mask with other values -- which the reference would use as per-pixel
+    #  weights, flower_common.py:776-778 -- takes the torch expressions; ADVICE r5)
+    if _use_glue(preds) and unlabeled_ROIs.dtype == torch.bool:
         out = _TreePrep.apply(preds, low_feats, unlabeled_ROIs, *highs)
         return out[0], out[1], out[2], out[3], tuple(preds.shape[2:]), list(out[4:])
     preds = preds.float()

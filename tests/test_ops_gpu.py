@@ -225,7 +225,7 @@ def test_dropout_rng_statistics_and_replay():
     keep = (z1 != 0).float().mean().item()
     assert abs(keep - 0.7) < 0.01
     assert abs(z1.max().item() - 1 / 0.7) < 1e-5
-    # the four draws of a 4-element group come from ONE hash (two 32-bit words, 16 bits per draw): every position keeps at the
+    # the eight draws of a PAIR of 4-element groups come from ONE hash (four 32-bit words by a mixing chain, 16 bits per draw): every position keeps at the
     # nominal rate, and positions -- of one group and of neighbouring groups -- are pairwise independent
     big = torch.ones(8, 128, 128, 16, device=DEV)
     for p_drop in (0.05, 0.3, 0.5):

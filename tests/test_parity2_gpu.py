@@ -441,9 +441,12 @@ def test_g17_hip_tree_losses_against_the_references_own_vectors(golden):
     # guidance maps rounded differently by one ulp on 40 % of their elements (another correct fp32 evaluation of the same
     # bilinear formula: torch's own CPU and GPU kernels differ that way on 40 % of these elements) -- the 1/4-resolution map's
     # gradient moves by 2e-3 .. 8e-3 of its maximum on average and 5e-2 .. 9e-2 at most, the logits' by 2e-5 .. 5e-5 / 1e-3 ..
-    # 6e-3.  Round 5's resize kernel (csrc/treeglue.hip) lands on another of these trees than ATen's did (tools/
-    # tree_g17_diag.py: 7.0e-3 / 5.3e-2 against 2.2e-3 / 5.0e-2); the bars are the oracle's own envelope.
-    bars = {"preds": (2e-4, 2e-2), "h1": (2e-2, 0.15), "h2": (2e-2, 0.15), "h3": (1e-2, 0.15)}
+    # 6e-3.  Round 6: the resize kernel (csrc/treeglue.hip) evaluates the formula in ATen-CPU's rounding order (bit for bit what torch
+    # gives at 96^2 and 256^2 outputs of integer scale; at g17's 64^2 torch's CPU kernel mixes contractions by position on ~25 % of the
+    # elements and no single formula reproduces it), which lands on the same trees as torch's own GPU kernel: tools/tree_g17_diag.py measures
+    # mean / max 1.6e-5 / 9.7e-4 (logits), 2.2e-3 / 5.0e-2, 1.4e-3 / 2.7e-2, 7.3e-4 / 3.7e-2 (head maps) of the gradient's maximum
+    # -- round 5's contraction gave 7.0e-3 / 5.3e-2 on h1.  Bars = 1.5 x those.
+    bars = {"preds": (2.4e-5, 1.5e-3), "h1": (3.4e-3, 7.5e-2), "h2": (2.2e-3, 4.1e-2), "h3": (1.1e-3, 5.6e-2)}
     for k in ("preds", "h1", "h2", "h3"):
         d = np.abs(t[k].grad.detach().float().cpu().numpy() - g["ms/g_" + k])
         m = max(1e-6, float(np.abs(g["ms/g_" + k]).max()))

@@ -69,7 +69,7 @@ def main():
         configs = [c for c in configs if c[0] == "v1" or c[0].startswith("ws")]
     if a.ws2:
         a.ws = True
-        configs = [("v1", (0, 0, 0, 0)), ("old", (2, 0, 0, 0)), ("ws2_16", (7, 1, 0, 0)), ("ws2_32", (7, 2, 0, 0)),
+        configs = [("v1", (0, 0, 0, 0)), ("lib", (-1, 0, 0, 0)), ("old", (2, 0, 0, 0)), ("ws2_16", (7, 1, 0, 0)), ("ws2_32", (7, 2, 0, 0)),
                    ("ws2_16w2", (7, 1, 0, 2)), ("ws2_32w2", (7, 2, 0, 2)), ("ws2_res", (7, 4, 0, 0)), ("ws2_resw2", (7, 4, 0, 2)),
                    ("dma", (7, 8, 0, 0))]
     if a.cfgs:
