@@ -327,7 +327,7 @@ class Volumes:
             ops.bump_weights_epoch()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, stream=_capture_stream(), capture_error_mode="thread_local"):
                     self._step_eager(key)
                 self.graphs[key] = g
                 g.replay()
@@ -485,9 +485,15 @@ def volumes_line(a, vol, elapsed, agg_ms, world, roof):
     return line
 
 
-def _staging_calibration():
-    from fedicra_amd import staging
-    return list(staging.calibration)
+def _capture_stream():
+    from fedicra_amd import streams
+    return streams.get("capture")
+
+
+def _stream_positions():
+    """{role: position in torch's stream pool} of this process's streams (fedicra_amd/streams.py: one place, one fixed order)."""
+    from fedicra_amd import streams
+    return streams.describe()
 
 
 def volumes_leg(a, rank, world, dev, dist, kind, steps=20, warmup=12):
@@ -553,8 +559,9 @@ def main_c4(a, rank, local, world, dev, dist):
 def cpu_baseline(a):
     """The CPU oracle (oracle/, kind "port") on this box's host cores, on a bounded sample of the same workload:
     the FedICRA local-training iteration (LC forwards included) in the timed run's head : body mix, then one aggregation
-    round (numpy FedAvg over 8 client states + one ALA epoch), on a THIRD of a batch (4 images) so that a warm-up plus
-    three timed iterations stay within about a minute; per-image cost on the CPU does not depend on the batch size at 512^2."""
+    round (numpy FedAvg over 8 client states + one ALA epoch), on the FULL 12-image batch (rounds 3-5 extrapolated
+    from a third of it): a warm-up, one head-phase and one body-phase iteration are about a minute on the GPU box's host; the
+    thread-scaling table that picks the thread count runs on 4 images (FEDICRA_CPU_BATCH overrides the sample's batch)."""
     import numpy as np
     from oracle import fed_ref
     from oracle.unet_ref import RefUNetLC
@@ -562,7 +569,8 @@ def cpu_baseline(a):
     # torch's CPU conv path stops scaling (and collapses from oversubscription) far below the 256 hardware
     # threads of the GPU box's host: use at most 32 threads and report that number as `cores`.
     torch.manual_seed(2022)
-    B = max(1, min(a.batch, int(os.environ.get("FEDICRA_CPU_BATCH", "4"))))
+    B = max(1, min(a.batch, int(os.environ.get("FEDICRA_CPU_BATCH", str(a.batch)))))
+    BS = min(B, 4)                                                             # images of the thread-scaling table
     m = RefUNetLC(a.in_chns, a.classes, 1, FEDERATION, FEDERATION, 0, heads=1)
     batches = []
     for i in range(2):
@@ -576,7 +584,7 @@ def cpu_baseline(a):
     if forced:
         cores = min(ncpu, int(forced))
     else:
-        xb = batches[0]["image"] if a.in_chns != 1 else batches[0]["image"].unsqueeze(1)
+        xb = (batches[0]["image"] if a.in_chns != 1 else batches[0]["image"].unsqueeze(1))[:BS]
         for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu // 2, ncpu) if 0 < t <= ncpu}):
             torch.set_num_threads(th)
             ts = []
@@ -585,7 +593,7 @@ def cpu_baseline(a):
                 m.zero_grad()
                 m(xb)[0].square().mean().backward()
                 ts.append(time.perf_counter() - t0)
-            scaling[th] = round(B / ts[-1], 3)
+            scaling[th] = round(BS / ts[-1], 3)
         m.zero_grad()
         cores = max(scaling, key=scaling.get)
     torch.set_num_threads(cores)
@@ -594,7 +602,7 @@ def cpu_baseline(a):
               strategy="FedICRA", alpha=1.0, cid=0, num_clients=FEDERATION)
     fed_ref.local_train(m, st, batches, iters=1, rep_iters=0, **kw)          # warm-up: thread pool, allocator, primitives
     t_head, t_body = [], []
-    for rep in (0, 0, 1):                                                      # two head-phase + one body-phase iteration
+    for rep in (0, 1):                                                         # one head-phase + one body-phase iteration
         t0 = time.perf_counter()
         fed_ref.local_train(m, st, batches, iters=1, rep_iters=rep, **kw)
         (t_body if rep else t_head).append(time.perf_counter() - t0)
@@ -617,7 +625,7 @@ def cpu_baseline(a):
             "thread_scaling_fwd_bwd_images_per_sec": scaling or None,
             "sec_per_head_iteration": round(float(np.median(t_head)), 3), "sec_per_body_iteration": round(float(np.median(t_body)), 3),
             "sample": f"oracle.fed_ref.local_train on RefUNetLC (torch {torch.__version__} CPU fp32, {cores} threads = the fastest of the "
-                      f"measured thread-scaling table): 1 warm-up + 2 head-phase + 1 body-phase FedICRA iterations of {B}x{a.in_chns}x{a.size}x{a.size} (a third of the batch) incl. "
+                      f"measured thread-scaling table, taken on {BS} images): 1 warm-up + 1 head-phase + 1 body-phase FedICRA iteration of {B}x{a.in_chns}x{a.size}x{a.size} (the whole batch) incl. "
                       f"the 7 LC forwards, weighted {a.round_iters - 3}:3 like the timed rounds; aggregation = numpy FedAvg K=8 + one "
                       f"ALA batch of {B} images scaled to {a.loader_batches} batches of {a.batch}"}
 
@@ -663,6 +671,38 @@ def dice_leg(with_cpu=True, rounds=12):
                                                    "(tests/golden/g19_minifed_dice.npz, oracle/gen_golden.py)"}
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
+
+
+def _conv_symbol(key, dtype_name):
+    """The __global__ template csrc/conv_api.hip's measured per-layer rule launches for a profiled conv shape (kind, dtype, N, H, W,
+    Cin, Cout, k[, "fused"]) -- a restatement of conv_fwd_impl's dispatch for the shapes of the FedICRA iteration, for the bench
+    line only (tools/kbench2.py switches the forms in-process when the rule itself is in question)."""
+    kind = key[0]
+    try:
+        n, h, w, cin, cout, ks = (int(x) for x in key[2:8])
+    except (ValueError, TypeError):
+        return kind
+    fused = len(key) > 8 and key[8] == "fused"
+    if kind == "conv_wgrad":
+        return "conv_wgrad_rows_kernel" if min(cin, cout) < 32 else ("conv_wgrad_rows64_kernel" if ks == 3 and h >= 64 else "conv_wgrad_quad_kernel")
+    if kind not in ("conv_fwd", "conv_dgrad") or dtype_name == "fp32":
+        return {"conv_fwd": "conv_fwd_kernel", "conv_dgrad": "conv_fwd_kernel"}.get(kind, kind)
+    if ks != 3:
+        return "conv_fwd_kernel"
+    if cin <= 4 and cout in (8, 16):
+        return "conv_narrow_in_kernel"
+    if cin <= 32 and cout <= 32 and cin >= 16:
+        return "conv_thin_kernel"
+    tiles16 = n * -(-h // 16) * -(-w // 16)
+    if fused and cout in (32, 64) and 78336 + cin * cout * 18 + 768 <= 160 * 1024 and n * -(-h // 32) * -(-w // 16) >= 1024:
+        return "conv_fwd_ws2_kernel (filter resident)"
+    if fused and cout % 128 == 0 and cin % 64 == 0 and tiles16 * (cout // 128) >= 1024:
+        return "conv_fwd_ws2_kernel"
+    if fused and cout == 64 and cin % 32 == 0 and n * -(-h // 32) * -(-w // 16) >= 1024:
+        return "conv_fwd_ws2_kernel (32-row tiles)"
+    if cin >= 32 and cout >= 32:
+        return "conv_fwd_ws_kernel"
+    return "conv_fwd_kernel"
 
 
 def roofline_pass(client, a, dtype_name):
@@ -739,6 +779,16 @@ def roofline_pass(client, a, dtype_name):
         bound, ach, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, mf_peak, "TFLOP/s"
     else:
         bound, ach, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    # the single heaviest launch shape of the dominant family and the __global__ symbol csrc/conv_api.hip dispatches it to
+    # ("name the single heaviest symbol and its own frac beside the family")
+    dk = max(fam_keys, key=lambda k: prof[k]["ms"])
+    dv = prof[dk]
+    d_us = dv["ms"] / dv["calls"] * 1e3
+    d_ideal_us = ideal_ms(dv) / dv["calls"] * 1e3
+    dominant_symbol = {"symbol": _conv_symbol(dk, dtype_name), "shape": "/".join(map(str, dk)), "launches_per_step": dv["calls"] / float(iters),
+                       "avg_us": round(d_us, 1), "ideal_us": round(d_ideal_us, 1), "frac": round(d_ideal_us / max(d_us, 1e-9), 4),
+                       "bound": "mfma" if dv.get("xflops", dv["flops"]) / pk_f >= dv["bytes"] / pk_b else "hbm",
+                       "share_of_gpu_time": round(dv["ms"] / total_ms, 4)}
     breakdown = {}
     for k, v in prof.items():
         breakdown[k[0]] = breakdown.get(k[0], 0.0) + v["ms"]
@@ -750,6 +800,7 @@ def roofline_pass(client, a, dtype_name):
     roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": None, "kernel": f"{fname} (all shapes of the FedICRA iteration)/{dtype_name}",
             "profile_command": "python bench.py --roofline-only  (profiles/*_roofline_kernel_stats.csv, *_pmc_traffic.json)",
+            "dominant_symbol": dominant_symbol,
             "launches_per_step": calls / float(iters), "avg_us": round(avg_ms * 1e3, 2),
             "arithmetic_intensity_flop_per_byte": round(ai, 1),
             "frac_of_mfma_peak": round(flops / (avg_ms * 1e-3) / 1e12 / mf_peak, 4),
@@ -904,8 +955,9 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
-    from fedicra_amd import _lib
+    from fedicra_amd import _lib, streams
     _lib.lib()
+    streams.init(dev)              # every HIP stream of this rank, in one fixed order, before the communicator brings its own
     # N = 1: the round's exchange still goes through RCCL -- a process group of ONE rank (the sum over one rank is the identity,
     # the result is bit-identical to the no-group path: tests/test_round5_gpu.py), so that the communicator, the side stream,
     # the event fence and their interplay with the captured steps execute on the one GPU the driver's N = 1 run has
@@ -996,9 +1048,8 @@ def main():
                        "data_location": ("pinned host memory; batch i+1 crosses PCIe on a side stream while iteration i computes "
                                          "(inside the timed region)") if a.data == "host" else "resident in HBM",
                        "h2d_bytes_per_step": h2d_bytes_per_step,
-                       # how the staging streams were chosen (fedicra_amd.staging._copy_stream: a candidate whose copy ran BESIDE
-                       # the compute stream's kernels in a one-off trial, not behind them on a shared hardware queue)
-                       "staging_streams": _staging_calibration(),
+                       # the process's HIP streams by role and position in the creation order (fedicra_amd/streams.py)
+                       "streams": _stream_positions(),
                        "resident_images_per_sec": None if resident is None else resident["images_per_sec"],
                        "resident": resident,
                        "fp32_images_per_sec": None if fp32 is None else fp32["images_per_sec"],

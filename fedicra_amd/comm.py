@@ -21,6 +21,8 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+
+from . import streams
 import torch.distributed as dist
 
 from .flower_common import DeviceWeights
@@ -61,7 +63,7 @@ class WeightedAllReduce:
             self.total += int(cn)
             if self.rank == 0:
                 self.constant = (cw, int(cn))
-        self.side = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self.side = streams.get("comm", device) if self.on_gpu else None         # (fedicra_amd/streams.py: every role's stream is made in one place)
         self._send = None
         self._cnt = None
         self._done = None

@@ -600,8 +600,6 @@ int xc_plan(const FiConv* d, int group_images, XcPlan* p) {
   return 0;
 }
 
-hipStream_t g_side = nullptr;
-hipEvent_t g_fork = nullptr, g_join = nullptr;
 
 template <typename T>
 int xc_run_tail(const FiConv* d, const XcArgs& a, const XcPlan& p, const void* w, const float* bias, double* stats,
@@ -624,21 +622,10 @@ int xc_run(const FiConv* d, const FiInXform* t0, int group_images, const void* x
 #ifdef XC_TRACE
   a.trace = g_xc_trace;
 #endif
-  // The frame and the weight-pair tensor need nothing of the autocorrelation kernel: they run on a second stream beside it
-  // (fork / join by events: graph edges under capture; the stream is created by the first -- eager -- call) with
-  // FI_XCORR_SIDE=1.  Measured on MI355X: 303 us either way (the one-workgroup-per-CU kernel leaves the small launches no room
-  // to start beside it), so the default keeps everything in line.
-  static const bool use_side = getenv("FI_XCORR_SIDE") != nullptr && atoi(getenv("FI_XCORR_SIDE")) != 0;
-  hipStream_t ss = st;
-  if (use_side) {
-    if (!g_side) {
-      if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return FI_ERR_UNSUPPORTED;
-      if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) return FI_ERR_UNSUPPORTED;
-      if (hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) return FI_ERR_UNSUPPORTED;
-    }
-    ss = g_side;
-  }
-  return xc_run_tail<T>(d, a, p, w, bias, stats, stats_gstride, ws, st, ss);
+  // (The frame and the weight-pair tensor need nothing of the autocorrelation kernel; running them on a second stream beside it
+  // measured 303 us either way in round 4 -- the one-workgroup-per-CU kernel leaves the small launches no room -- and the form was
+  // removed in round 6: everything in line.)
+  return xc_run_tail<T>(d, a, p, w, bias, stats, stats_gstride, ws, st, st);
 }
 
 template <typename T>
@@ -669,12 +656,7 @@ int xc_launch_main(const FiConv* d, const XcArgs& a, const XcPlan& p, char* ws, 
 template <typename T>
 int xc_run_tail(const FiConv* d, const XcArgs& a, const XcPlan& p, const void* w, const float* bias, double* stats,
                 long stats_gstride, char* ws, hipStream_t st, hipStream_t ss) {
-  const bool side = ss != st;
   hipError_t he;
-  if (side) {
-    if ((he = hipEventRecord(g_fork, st)) != hipSuccess) return (int)he;            // x0 / w were produced on st
-    if ((he = hipStreamWaitEvent(ss, g_fork, 0)) != hipSuccess) return (int)he;
-  }
   {
     // the big kernel goes to its queue FIRST: it takes one workgroup slot (135 KB of LDS) on every CU, and the small launches
     // of the side stream fill in beside it
@@ -705,10 +687,6 @@ int xc_run_tail(const FiConv* d, const XcArgs& a, const XcPlan& p, const void* w
   float* B = reinterpret_cast<float*>(ws + p.o_B);
   hipLaunchKernelGGL((wpair_kernel<T>), dim3(d->co0), dim3(256), 0, ss, reinterpret_cast<const T*>(w), B);
   FI_CHECK_LAUNCH();
-  if (side) {
-    if ((he = hipEventRecord(g_join, ss)) != hipSuccess) return (int)he;
-    if ((he = hipStreamWaitEvent(st, g_join, 0)) != hipSuccess) return (int)he;
-  }
   const double* A = reinterpret_cast<const double*>(ws + p.o_A);
   const float* Af = reinterpret_cast<const float*>(ws + p.o_Af);
   double* Q = reinterpret_cast<double*>(ws + p.o_Q);

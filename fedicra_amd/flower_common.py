@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from . import fl, ops
+from . import fl, ops, streams
 from .flat import _as_view
 
 VAL_METRICS = ["dice", "hd95", "recall", "precision", "jc", "specificity", "ravd"]     # flower_common.py:121
@@ -369,7 +369,7 @@ class MyModel(nn.Module):
             torch.cuda.synchronize()
             ops.reserve_graph_tables(G + 2)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=streams.get("capture"), capture_error_mode="thread_local"):
                 ep["loss"] = epoch()
             ep["graph"] = g
             g.replay()
@@ -484,7 +484,7 @@ class MyModel(nn.Module):
                         torch.cuda.synchronize()
                         ops.reserve_graph_tables()
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        with torch.cuda.graph(g, stream=streams.get("capture"), capture_error_mode="thread_local"):
                             st["loss"] = iteration(st["x"], st["y"])
                         st["graph"] = g
                         g.replay()

@@ -22,7 +22,7 @@ import contextlib
 import numpy as np
 import torch
 
-from . import fl, ops
+from . import fl, ops, streams
 from .flower_common import BaseClient
 from .optim import FusedAdamW
 
@@ -66,16 +66,7 @@ class MyClient(BaseClient):
         # ... and their decoder half (BatchNorm statistics only: nothing the iteration reads) on beside the loss and the backward
         # pass, joined before the optimizer step (measurement switch: 0 = joined before the LC loss, as in round 3)
         self.probe_tail_beside = os.environ.get("FEDICRA_PROBE_TAIL", "1") != "0"
-        # the probe's running-statistics updates on the main stream after the join instead of per-layer events between the two
-        # streams (measurement switch: 0 = round 3's events)
-        self.probe_defer_running = os.environ.get("FEDICRA_PROBE_DEFER", "1") != "0"
         self.aux_stats_only = os.environ.get("FEDICRA_AUX_STATS", "1") != "0"   # (measurement switch: 0 = the heads in full)
-        # head phase: the own forward as group 0 of the batched LC forwards (see _iteration).  OFF by default: the two-stream form
-        # had already taken what there was to take -- the captured head-phase step replays in 5.43 ms merged against 5.51 ms with
-        # the own forward as a pass of its own beside the batch (tools/own_in_probe_ab.py, same process), and the bench's rounds
-        # measured 1 362 against 1 357-1 364 images/s (same box, gpurun_out/v9_q4.log; with eight hardware queues 1 195 against
-        # 1 375: the batch staging behind the one compute stream's queue).  FEDICRA_OWN_IN_PROBE=1 turns it on.
-        self.own_in_probe = os.environ.get("FEDICRA_OWN_IN_PROBE", "0") != "0"
         self.ctx = ops.new_context()                         # arena / dropout counter a captured step bakes in
         self.stream = None                                   # set by whoever co-locates several clients on one GPU
 
@@ -167,51 +158,28 @@ class MyClient(BaseClient):
         can_batch = (args.strategy in ["FedICRA"] and hasattr(net, "probe_heatmaps") and x.is_cuda and ops.probe_ready()
                      and net.training)
         side = self.probe_beside and can_batch
-        merged = None
-        if (can_batch and self.own_in_probe and self.__dict__.get("_head_only", False) and self.aux_stats_only
-                and hasattr(getattr(net, "decoder", None), "out_conv")):
-            # HEAD PHASE (:84-101: only decoder.out_conv trains): no gradient flows below the logits convolution, so of the own
-            # forward (:106) nothing is read but the logits' input, the heat-map and -- as side effects -- the BatchNorm statistics
-            # and the dropout draws.  It travels as GROUP 0 of the batched LC forwards (:128-139): first in every BatchNorm's
-            # update order and every dropout layer's draw order, like the reference's call order; its activations are never
-            # materialised except the last decoder feature.  12-image launches worth 1.4 ms of isolated launch time become an
-            # eighth of the batch's work (0.64 ms) on one stream -- which is what the two streams already made of them (see __init__).
-            with torch.no_grad():
-                merged = net.probe_heatmaps(x, others, own=True)
-        if merged is not None:
-            side = False
-            self.merged_iterations = self.__dict__.get("merged_iterations", 0) + 1     # (eager runs and captures; replays do not pass here)
         if side:
             # The K-1 no-grad LC forwards (:128-139) do not depend on the client's own forward (:106), only on the weights and
             # the batch: they run on a SECOND stream beside it -- the own forward's 12-image launches fill the gaps the batched
             # launches leave (measured: 91.0 -> 87.6 ms of training per round).  Order kept where it matters: the own forward is
             # enqueued first (dropout call counters), and every BatchNorm's running statistics take the own update before the
-            # probe's (ops.probe_after: one event per layer).  Fork / join are graph edges under capture.
+            # probe's (deferred to this stream after the join: ops._probe_finalize).  Fork / join are graph edges under capture.
             main = torch.cuda.current_stream()
-            # (FEDICRA_PROBE_PRIO: HIP stream priority of the probe chain, the critical path of the iteration -- -1 = high;
-            # stream_beside: never the stream this iteration runs / is captured on, whatever torch's pool hands out)
-            probe_stream = self.__dict__["_probe_stream"] = ops.stream_beside(
-                self.__dict__.get("_probe_stream"), main, priority=int(os.environ.get("FEDICRA_PROBE_PRIO", "0")))
+            # (fedicra_amd/streams.py makes every role's stream in one place: never the stream this iteration runs / is captured on)
+            probe_stream = streams.get("probe", x.device)
+            assert probe_stream.cuda_stream != main.cuda_stream
             net._fi_refresh_packs(net.compute_dtype())       # packs the probe reads: ready BEFORE the fork
             fork = torch.cuda.Event()
             fork.record(main)
-            if self.probe_defer_running:
-                # every BatchNorm's running statistics take the own forward's update first and the probe's K-1 after it: the
-                # probe makes only its coefficient rows on its stream, its running-statistics updates are made HERE, on this
-                # stream, after the join (ops._probe_finalize) -- no event between the two branches
-                ops._ctx.probe_deferred = []
-            else:
-                ops._ctx.bn_events = {}                      # (round 3's form: one event per layer, the probe waits for each)
+            # every BatchNorm's running statistics take the own forward's update first and the probe's K-1 after it: the
+            # probe makes only its coefficient rows on its stream, its running-statistics updates are made HERE, on this
+            # stream, after the join (ops._probe_finalize) -- no event between the two branches
+            ops._ctx.probe_deferred = []
         deferred = None
         try:
-            if merged is not None:
-                maps, feat = merged
-                out = [net._out(ops.conv2d(feat, None, net.decoder.out_conv, y_f32=True)), None, None, None, None, None, [maps[0]]]
-                batched = maps[1:]
-            else:
-                # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
-                # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
-                out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
+            # this procedure reads the logits and the heat-map only (:117-139): on the LC models the auxiliary heads run for
+            # their BatchNorm statistics alone (networks/unet._UNetLCBase.forward, aux="stats")
+            out = self.model(x, aux="stats") if self.aux_stats_only and hasattr(net, "probe_heatmaps") else self.model(x)
             if side:
                 probe_stream.wait_event(fork)
                 enc_done = torch.cuda.Event() if self.probe_tail_beside else None
@@ -224,7 +192,6 @@ class MyClient(BaseClient):
                     main.wait_stream(probe_stream)
                     probe_stream = None
         finally:
-            ops._ctx.bn_events = None
             deferred, ops._ctx.probe_deferred = ops._ctx.probe_deferred, None
         logits = out[0]
         loss_ce = ops.ce_loss(logits.permute(0, 2, 3, 1), y, args.num_classes)       # :124
@@ -244,15 +211,12 @@ class MyClient(BaseClient):
                     torch.cuda.current_stream().wait_stream(probe_stream)
                     self._run_deferred(deferred)
                     deferred = None
-            elif merged is None:
+            else:
                 with torch.no_grad():                                                # all K-1 forwards as one batch
                     batched = self.model.model.probe_heatmaps(x, others) if hasattr(self.model.model, "probe_heatmaps") else None
             base = None
             if batched is not None and heatmaps[-1].is_cuda:
                 base = batched[0]._base if batched[0]._base is not None else batched[0]
-                if merged is not None and base.dtype == torch.float32 and base.is_contiguous() and \
-                        base.numel() == (len(others) + 1) * heatmaps[-1].numel():
-                    base = base.reshape(-1)[heatmaps[-1].numel():]                   # the own map leads the tensor: the others follow it
                 if base.numel() != len(others) * heatmaps[-1].numel() or base.dtype != torch.float32 or not base.is_contiguous():
                     base = None
             if base is not None:
@@ -353,7 +317,7 @@ class MyClient(BaseClient):
                         g = torch.cuda.CUDAGraph()
                         # thread_local: only this thread's calls are policed during the capture -- RCCL's watchdog
                         # thread polls events of its own and must not invalidate it (multi-GPU runs)
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # records only; nothing executes
+                        with torch.cuda.graph(g, stream=streams.get("capture"), capture_error_mode="thread_local"):     # records only; nothing executes
                             self._iteration(x, y, rec)
                         rec.graph = g
                         g.replay()

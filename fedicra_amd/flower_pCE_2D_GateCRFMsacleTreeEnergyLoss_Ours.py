@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import ops, streams
 from .flower_pCE_2D import MyClient as _PCEClient
 from .tree_energy import MScaleRecurveTreeEnergyLoss
 from .utils.gate_crf_loss import ModelLossSemsegGatedCRF
@@ -50,7 +50,8 @@ class MyClient(_PCEClient):
         others = []
         if args.strategy in ["FedICRA"]:
             cur = torch.cuda.current_stream()
-            self._lc_stream = ops.stream_beside(self._lc_stream, cur, device=x.device)
+            self._lc_stream = streams.get("probe", x.device)   # (fedicra_amd/streams.py: never the stream this iteration runs / is captured on)
+            assert self._lc_stream.cuda_stream != cur.cuda_stream
             self._lc_stream.wait_stream(cur)
             with torch.cuda.stream(self._lc_stream), torch.no_grad():
                 ids = [c for c in range(args.min_num_clients) if c != args.cid]

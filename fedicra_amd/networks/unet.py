@@ -361,11 +361,9 @@ class _DecoderBase(_FiModule):
         """(head Sequential, index of the trunk output it reads) pairs."""
         return []
 
-    def _probe(self, skips, x4, groups, own_feature=False):
+    def _probe(self, skips, x4, groups):
         """Decoder of the batched no-grad forward: what it leaves behind are the BatchNorm running statistics of every block
-        and head, moved `groups` times as the separate forwards would.  own_feature: group 0 is the client's OWN forward
-        (flower_pCE_2D._iteration, head phase) -- its full-resolution decoder feature, the input of the logits convolution, is
-        written out and returned (the only activation of that forward anybody reads); None otherwise."""
+        and head, moved `groups` times as the separate forwards would."""
         def up(blk, lo, skip, store=True):
             u = ops.probe_conv_up(lo, blk.conv1x1, groups)
             return blk.conv._probe(skip, u, groups, store=store)
@@ -374,10 +372,9 @@ class _DecoderBase(_FiModule):
         o.append(up(self.up2, o[1], skips[2]))
         o.append(up(self.up3, o[2], skips[1]))
         # the full-resolution output feeds the (skipped) logits convolution and, in the multi-head decoder, a head
-        o.append(up(self.up4, o[3], skips[0], store=True if 4 in read else ("own" if own_feature else False)))
+        o.append(up(self.up4, o[3], skips[0], store=4 in read))
         for head, idx in self._heads():
             ops.probe_conv_bn(o[idx], None, head[0], head[1], 0.0, groups, store=False)
-        return ops.probe_materialize_own(o[4], groups) if own_feature else None
 
     def forward(self, feature):
         return tuple(self._out(t) for t in self._run([self._in(t) for t in feature]))
@@ -498,15 +495,14 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
         return [out(o[0]), [self._out(t) for t in f]] + [self._out(t) for t in o[1:5]] + [hm] + [out(t) for t in o[5:]]
 
 
-    def probe_heatmaps(self, x, emb_ids, enc_done=None, own=False):
+    def probe_heatmaps(self, x, emb_ids, enc_done=None):
         """The heat-maps ``self(x, e)[6][-1]`` for every e in emb_ids -- FedICRA's LC loss asks for them once per OTHER client
         in every iteration (flower_pCE_2D.py:128-139: no-grad, train mode) -- from ONE batched pass: the K-1 forwards run
         as statistics groups of the same launches (fi_conv2d_fwd_fused / fi_bn_finalize_groups), the activations between
         the convolutions are never materialised, and the first convolution, identical under every embedding, runs once.
         State afterwards is what the K-1 separate forwards leave: every BatchNorm's running statistics moved K-1 times in
         order, num_batches_tracked += K-1, the same dropout masks.  Returns None when the batched form does not apply
-        (eval mode, autograd on, host-fed masks, other architectures): the caller then makes the separate forwards.
-        ``own=True``: the client's own train-mode forward is group 0 of the same pass (K groups, K updates); see the return."""
+        (eval mode, autograd on, host-fed masks, other architectures): the caller then makes the separate forwards."""
         enc, dec = self.encoder, self.decoder
         if not (self.training and not torch.is_grad_enabled() and ops.probe_ready() and len(emb_ids) > 0):
             return None
@@ -518,7 +514,7 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
             return None
         self._fi_refresh_packs(dt)
         xin = self._in(x)
-        ids = ([0] if own else []) + list(emb_ids)            # 0 = the client's own embedding (unet.py:186, quirk 2)
+        ids = list(emb_ids)
         G, B = len(ids), xin.shape[0]
         skips, x4, h = enc._probe(xin, ids)
         maps = [self._out(h[g * B:(g + 1) * B]) for g in range(G)]
@@ -526,11 +522,8 @@ class _UNetLCBase(FlatStoreMixin, _FiModule):
             # everything the CALLER reads exists now; what follows only moves the decoder's BatchNorm statistics -- a caller that
             # runs this on a side stream may wait for this event instead of the whole stream (flower_pCE_2D._iteration)
             enc_done.record()
-        feat = dec._probe(skips, x4, G, own_feature=own)
-        # own: the client's OWN forward travels as group 0 of the batch -- first in every BatchNorm's update order and in every
-        # dropout layer's draw order, as the reference's `self.model(x)` before its K-1 `self.model(x, other)` -- and the caller
-        # gets (K heat-maps, own first; the own forward's last decoder feature, dense NHWC)
-        return (maps, feat) if own else maps
+        dec._probe(skips, x4, G)
+        return maps
 
 
 class UNet_LC(_UNetLCBase):

@@ -94,7 +94,6 @@ class _Context:
         self.seed_offset = None        # device int32[1] added to every RNG seed (training-iteration counter)
         self.call_idx = {}             # uid -> how many times this layer drew a mask in the current iteration
         self.graph_tables = []         # pinned + device reduce tables of the steps captured under this context
-        self.bn_events = None          # dict while the LC forwards run beside the client's own forward (see probe_after)
         # list while they do (flower_pCE_2D._iteration): the running-statistics updates of the batched forward, which the
         # CALLER makes on its own stream after joining the probe stream (_probe_finalize); None = made in place
         self.probe_deferred = None
@@ -216,11 +215,6 @@ _wgrad_cb_queued = False
 _table_keepalive = []          # pinned host tables of eager launches: must outlive the async copy
 
 
-_side_streams = {}             # device index -> stream the partial-wgrad kernels run on, beside the dgrad/BN chain
-_WGRAD_SIDE = os.environ.get("FI_WGRAD_STREAM", "0") != "0"   # measured: 2.59 ms/step beside vs 2.40 in line
-_side_used = False
-
-
 def stream_beside(cached, main, device=None, priority=0):
     """A stream that is NOT `main`, for work meant to run beside it.  torch hands out streams from a round-robin pool of
     32 per device and priority: in a long-lived process a freshly made stream can BE the one an earlier caller holds --
@@ -233,11 +227,6 @@ def stream_beside(cached, main, device=None, priority=0):
         if s.cuda_stream != main.cuda_stream:
             return s
     raise RuntimeError("fedicra_amd.ops.stream_beside: torch's stream pool returned the current stream 64 times")
-
-
-def _side_stream(dev):
-    s = _side_streams[dev.index] = stream_beside(_side_streams.get(dev.index), torch.cuda.current_stream(dev), device=dev)
-    return s
 
 
 def _defer_wgrad_reduce(ws, stride, slices, dw, n_dw, db, cout, keep=None, cin3=0):
@@ -257,10 +246,6 @@ def flush_wgrad():
     _wgrad_cb_queued = False
     if not _pending_wgrad:
         return
-    global _side_used
-    if _side_used:                       # join: the partial sums were produced beside the main chain
-        torch.cuda.current_stream().wait_stream(_side_stream(_pending_wgrad[0][0].device))
-        _side_used = False
     rows, nblocks = [], 0
     for ws, stride, slices, dw, n_dw, db, cout, _keep, cin3 in _pending_wgrad:
         ll = 8 if slices <= 16 else 6 if slices <= 64 else 4      # fewer lanes per row when there are many slices to fold
@@ -315,10 +300,9 @@ def _pinned_slot(nrows, capturing):
 def _conv_backward(ctx, dy, x0, x1, wk, mod):
     """Shared by _Conv and _ConvBNAct: returns (dx0, dx1, gw, gb).
 
-    The weight gradient only feeds the optimizer, so its first stage (per-workgroup partial sums) is issued on a
-    side stream and runs beside the dgrad -> BN-backward chain of the layers below; the single multi-tensor second
-    stage at the end of backward joins the two streams (a fork/join inside a captured hipGraph too)."""
-    global _side_used
+    The weight gradient only feeds the optimizer: its first stage (per-workgroup partial sums) is issued here, in line with
+    the dgrad -> BN-backward chain (beside it on a second stream measured slower, 2.59 against 2.40 ms per step: round 2), the
+    single multi-tensor second stage at the end of backward."""
     ksize, cout, cin = ctx.ksize, wk.shape[0], wk.shape[3]
     kk = ksize * ksize
     dx0 = dx1 = gw = gb = None
@@ -341,17 +325,8 @@ def _conv_backward(ctx, dy, x0, x1, wk, mod):
             # or .grad already in place): a fresh tensor returned from backward may be cloned by AccumulateGrad before the
             # deferred reduce has written it -- a plain nn.Conv2d with a 1x1 kernel (whose KRSC view is contiguous) used to
             # get zeros for dw and db that way (tools/grad_bisect.py, round 5)
-            if _WGRAD_SIDE:
-                side, main = _side_stream(dy.device), torch.cuda.current_stream()
-                side.wait_stream(main)            # dy (and, the first time, x) are produced on the main stream
-                with torch.cuda.stream(side):
-                    ws, slices, stride = L.conv2d_wgrad_partial(x0, x1, dy, db is not None, ksize=ksize)
-                _side_used = True
-                keep = (x0, x1, dy)               # the allocator must not hand these out again before the join
-            else:
-                ws, slices, stride = L.conv2d_wgrad_partial(x0, x1, dy, db is not None, ksize=ksize)
-                keep = None
-            _defer_wgrad_reduce(ws, stride, slices, dw, cout * kk * cin, db, cout, keep)
+            ws, slices, stride = L.conv2d_wgrad_partial(x0, x1, dy, db is not None, ksize=ksize)
+            _defer_wgrad_reduce(ws, stride, slices, dw, cout * kk * cin, db, cout, None)
         else:
             L.conv2d_wgrad(x0, x1, dy, dw, db, ksize=ksize)
             if ctx.need_w and dw.data_ptr() != wt_.data_ptr():
@@ -429,10 +404,6 @@ class _ConvBNAct(Function):
         # BN finalize (batch statistics -> scale/shift, running-stat update) + apply + activation + dropout: 1 launch
         L.bn_fused_fwd(y, z, stats, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                        bn.eps, training, coef, slope, drop)
-        if _ctx.bn_events is not None and training:
-            ev = torch.cuda.Event()                 # this layer's running statistics have taken the own forward's update
-            ev.record()
-            _ctx.bn_events[id(bn)] = ev
         ctx.save_for_backward(x0, x1, wk, y, coef)
         ctx.mod, ctx.bn, ctx.ksize, ctx.slope, ctx.drop, ctx.training = mod, bn, ksize, slope, drop, training
         ctx.need_x0 = ctx.needs_input_grad[0]
@@ -736,14 +707,6 @@ def conv_bn_stats_only(x0, x1, conv, bn, drop_p=0.0, drop_kind="elem"):
     coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
     L.bn_finalize(stats, float(N * H * W), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                   bn.momentum, bn.eps, True, coef[0], coef[1], coef[2], coef[3])
-    if _ctx.bn_events is not None and _ctx.probe_deferred is None:
-        # the own forward's statistics-only head (aux="stats") has moved this BatchNorm's running statistics: batched LC
-        # forwards on a second stream must order THEIR update of the same layer behind it (round 4 left the two
-        # read-modify-writes unordered).  With a per-layer event like _ConvBNAct's (this branch) -- or, as flower_pCE_2D does, by
-        # making ALL of the probe's running-statistics updates on the caller's stream after the join (_probe_finalize)
-        ev = torch.cuda.Event()
-        ev.record()
-        _ctx.bn_events[id(bn)] = ev
 
 
 # ----------------------------------------------------------------------------- fused probe forward
@@ -758,42 +721,23 @@ class RawAct:
     coefficient rows of its BatchNorm (fp32 [2][G][C], one row pair per statistics group) and the activation slope.  The
     consuming convolution applies them in its loader (fi_conv2d_fwd_fused).  `shared`: y holds ONE group's images, which
     every group reads."""
-    __slots__ = ("y", "coef", "slope", "shared", "own_only")
+    __slots__ = ("y", "coef", "slope", "shared")
 
-    def __init__(self, y, coef, slope, shared=False, own_only=False):
+    def __init__(self, y, coef, slope, shared=False):
         self.y, self.coef, self.slope, self.shared = y, coef, slope, shared
-        self.own_only = own_only            # y holds group 0's images only (probe_conv_bn(store="own")); coef has every group's rows
-
-
-def probe_after(bn):
-    """The batched LC forwards may run on a second stream beside the client's own forward (flower_pCE_2D._iteration).  The
-    reference makes them AFTER it (flower_pCE_2D.py:106,128-139), and a BatchNorm's running statistics are an order-dependent
-    recursion (r <- 0.9 r + 0.1 b): before the probe moves a layer's statistics it waits for the event the own forward recorded
-    behind its update of the same layer."""
-    if _ctx.bn_events is not None:
-        ev = _ctx.bn_events.get(id(bn))
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
 
 
 def run_probe_deferred(items):
     """The running-statistics updates the batched forward left to the caller (_probe_finalize), on the CURRENT stream: all
-    layers in one launch (fi_bn_running_groups_multi; FI_BN_RUN_MULTI=0 = one launch per layer, the same kernel arithmetic)."""
+    layers in one launch (fi_bn_running_groups_multi)."""
     if not items:
         return
     cur = torch.cuda.current_stream()
     for it in items:                                   # the statistics were produced on the probe stream and are read here, on another one:
         it[0].record_stream(cur)                       # tell the caching allocator (a buffer that is not the arena's could be handed out again; ADVICE r5)
     with torch.no_grad():
-        if _BN_RUN_MULTI:
-            L.bn_running_groups_multi(items)
-        else:
-            for stats, groups, count, rmean, rvar, nbt, momentum, shared in items:
-                L.bn_running_groups_multi([(stats, groups, count, rmean, rvar, nbt, momentum, shared)])
+        L.bn_running_groups_multi(items)
     items.clear()
-
-
-_BN_RUN_MULTI = os.environ.get("FI_BN_RUN_MULTI", "1") != "0"
 
 
 def probe_ready():
@@ -843,22 +787,6 @@ def probe_conv_bn(s0, s1, conv, bn, slope, groups, *, pool=False, in_drop=None, 
     if (pool or in_drop is not None) and t0 is None:
         raise L.FiError("pooling / dropout in the loader need a raw source 0")
     stats = _ctx.arena.take(groups * L.STATS_SLOTS * cout * 2, dev)
-    if store == "own":
-        # the caller reads group 0's output only (the client's own forward travelling as the first group of the batch,
-        # flower_pCE_2D._iteration): its images as one launch that stores, the other groups' as a statistics-only launch -- each with
-        # its own rows of the coefficient and statistics tables -- instead of writing G - 1 outputs nobody reads
-        if r0 is None or shared0 or pool or in_drop is not None or s1 is not None or groups < 2:
-            store = True                                         # (forms without a group offset: write everything, read the first)
-        else:
-            B, per = N // groups, L.STATS_SLOTS * cout * 2
-            y = torch.empty((B, H, W, cout), dtype=x0.dtype, device=dev)
-            L.conv2d_fwd_fused(x0[:B], L.in_xform(r0.coef, r0.slope), None, None, wp, conv.bias, y, stats[:per], ksize=ksize, groups=1,
-                               cout=cout)
-            L.conv2d_fwd_fused(x0[B:], L.in_xform(r0.coef, r0.slope, group0=1), None, None, wp, conv.bias, None, stats[per:], ksize=ksize,
-                               groups=groups - 1, cout=cout)
-            coef = torch.empty((2, groups, cout), dtype=torch.float32, device=dev)
-            _probe_finalize(stats, groups, float(B * H * W), bn, coef)
-            return RawAct(y, coef, slope, own_only=True)
     y = torch.empty((N, H, W, cout), dtype=x0.dtype, device=dev) if store else None
     done = False
     if (not store and _XCORR and ksize == 3 and x1 is None and not shared0 and not pool and in_drop is None
@@ -893,7 +821,6 @@ def _probe_finalize(stats, groups, count, bn, coef, shared=False):
         return
     if coef is None:
         coef = torch.empty((2, groups, bn.weight.numel()), dtype=torch.float32, device=stats.device)
-    probe_after(bn)
     L.bn_finalize_groups(stats, groups, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, bn.momentum, bn.eps, coef, shared=shared)
 
@@ -939,15 +866,6 @@ def probe_materialize(r, groups):
     selection; every level for the ALA epoch's frozen encoder): all statistics groups in one launch."""
     z = torch.empty_like(r.y)
     L.bn_act_pool_groups(r.y, r.coef, r.slope, z, groups, pool=False)
-    return z
-
-
-def probe_materialize_own(r, groups):
-    """z = act(BN(y)) of GROUP 0 of a raw activation (the client's own forward inside the batch): r.y holds group 0's images
-    (probe_conv_bn(store="own")) or every group's."""
-    y = r.y if r.own_only else r.y[:r.y.shape[0] // groups]
-    z = torch.empty_like(y)
-    L.bn_act_pool_groups(y, r.coef[:, 0:1], r.slope, z, 1, pool=False)
     return z
 
 

@@ -16,75 +16,17 @@ import os
 _NO_PREFETCH = os.environ.get("FEDICRA_NO_PREFETCH", "0") != "0"      # measurement switch: every copy serial, as in the reference
 
 
-_CALIBRATE = os.environ.get("FEDICRA_STAGE_CALIBRATE", "0") != "0"    # (measurement switch, off: see _copy_stream)
-# HIP priority of the staging stream (measurement switch).  -1 = high was tried as a way to give the copies hardware queues of their
-# own whatever the creation order: 1 344 / 1 350 -> 1 204 / 1 199 images/s on one box (gpurun_out/w1_prio.log) -- the blit kernels then go
-# ahead of the compute kernels they were meant to hide behind.  0 stays.
-_STAGE_PRIO = int(os.environ.get("FEDICRA_STAGE_PRIO", "0"))
-calibration = []               # one record per stager: {"tries", "overlap", "copy_alone_ms", "copy_beside_ms", "kernels_ms"} (bench.py reports it)
-
-
 def _copy_stream(device):
-    """A side stream whose copies really RUN BESIDE the kernels of the current stream.  A HIP stream lives on one of the GPU's
-    hardware queues (GPU_MAX_HW_QUEUES, handed out round-robin as streams are made) and a host-to-device copy from pinned memory is a
-    blit kernel on its stream's queue: a staging stream that lands on the compute stream's queue is served in order WITH the compute
-    kernels, and the "hidden" 41 MB per step come back as 12-13 ms per round (round 5: the same bench measured 1 392 images/s with
-    a one-rank RCCL group alive and 1 298 without it -- the communicator's streams had shifted the round-robin).  So candidates are
-    TRIED: ~3 ms of fill kernels on the current stream, a 64 MB pinned copy on the candidate behind the same start event; the
-    candidate is taken when its copy finishes about as fast as alone (not behind the kernels).  One-off, ~20 ms per stager."""
+    """The staging stream: the `staging` role of fedicra_amd/streams.py, which creates every role's stream in one place and in a fixed
+    order.  (A host-to-device copy from pinned memory is a blit kernel on its stream's hardware queue: a staging stream that lands on
+    the compute stream's queue is served in order WITH the compute kernels and the "hidden" 41 MB per step come back as 12-13 ms per
+    round.  Round 5 tried to pick the stream by a one-off overlap trial and by HIP priority; the trial did not see the collision and
+    the priority cost 10 % -- both are gone, the creation order is what is controlled now.)"""
+    from . import streams
     dev = torch.device(device)
-    if not _CALIBRATE or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
-        return torch.cuda.Stream(device=dev, priority=_STAGE_PRIO)
-    from . import ops
-    main = torch.cuda.current_stream(dev)
-    host = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
-    dst = torch.empty(16 << 20, dtype=torch.float32, device=dev)
-    work = torch.empty(256 << 20, dtype=torch.float32, device=dev)           # 1 GB: a fill is ~0.25 ms
-
-    def timed(fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record(main)
-        fn()
-        e1.record(main)
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1)
-
-    def kernels():
-        for _ in range(12):
-            work.fill_(1.0)
-
-    kernels()
-    t_k = timed(kernels)
-    rec, best = None, None
-    for tries in range(1, 9):
-        s = ops.stream_beside(None, main, device=dev)
-        with torch.cuda.stream(s):
-            dst.copy_(host, non_blocking=True)                               # (first touch of the pinned pages by this queue)
-        torch.cuda.synchronize(dev)
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record(s)
-        with torch.cuda.stream(s):
-            dst.copy_(host, non_blocking=True)
-        a1.record(s)
-        torch.cuda.synchronize(dev)
-        t_c = a0.elapsed_time(a1)
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b0.record(main)
-        s.wait_event(b0)
-        kernels()
-        with torch.cuda.stream(s):
-            dst.copy_(host, non_blocking=True)
-        b1.record(s)
-        torch.cuda.synchronize(dev)
-        t_b = b0.elapsed_time(b1)
-        rec = {"tries": tries, "overlap": t_b <= t_c + 0.35 * t_k, "copy_alone_ms": round(t_c, 3), "copy_beside_ms": round(t_b, 3),
-               "kernels_ms": round(t_k, 3)}
-        best = s
-        if rec["overlap"]:
-            break
-    calibration.append(rec)
-    return best
+    if dev.type != "cuda":
+        return None
+    return streams.get("staging", dev)
 
 
 class _Hip:

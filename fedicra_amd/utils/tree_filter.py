@@ -29,9 +29,6 @@ class Tree:
         return self.edges.shape
 
 
-_side_streams = {}
-
-
 def _parallel(*branches):
     """Run independent launch sequences as parallel branches: branch 0 on the current stream, the others on side HIP
     streams forked from / joined to it (inside a stream capture they become parallel branches of the hipGraph).  A tree
@@ -41,10 +38,13 @@ def _parallel(*branches):
         for b in branches:
             b()
         return
+    from .. import streams
     cur = torch.cuda.current_stream()
-    pool = _side_streams.setdefault(cur.device.index, [])
-    while len(pool) < len(branches) - 1:
-        pool.append(torch.cuda.Stream(device=cur.device))
+    pool = [s for s in (streams.get(f"tree{i}", cur.device) for i in range(len(branches) - 1)) if s.cuda_stream != cur.cuda_stream]
+    if len(pool) < len(branches) - 1:                      # (the caller already runs on a tree stream: the surplus branches in line)
+        for b in branches[len(pool) + 1:]:
+            b()
+        branches = branches[:len(pool) + 1]
     for b, s in zip(branches[1:], pool):
         s.wait_stream(cur)
         with torch.cuda.stream(s):

@@ -308,7 +308,6 @@ def test_lc_forwards_beside_the_own_forward_leave_the_state_of_the_in_line_order
         model = MyModel(args, net, batches, batches)
         client = MyClient(args, model, batches, batches)
         client.probe_beside = beside
-        client.own_in_probe = False                          # (stream placement of a SEPARATE own forward is what is compared here)
         cfg = {"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
         client._train(cfg)
         client._train(cfg)                                   # second round: the captured steps replay

@@ -101,18 +101,15 @@ def test_weighted_allreduce_and_captured_rounds_through_a_one_rank_rccl_group(tm
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-@pytest.mark.parametrize("mode", ["deferred", "events"])
-def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
+def test_probe_moves_running_statistics_behind_the_own_forward(use_graph):
     """The K-1 batched LC forwards beside the client's own forward must move every BatchNorm's running statistics AFTER the own
     forward's update of the same layer (/root/reference/code/flower_pCE_2D.py:106,128-139: own forward first, then the K-1
     forwards; the recursion r <- 0.9 r + 0.1 b is order dependent).  ADVICE r4 (medium): with aux="stats" the own forward's
     auxiliary head moved its BatchNorm on the main stream with nothing ordering the probe's update of it on the second stream.
-      * "deferred" (default, round 5): the probe makes only the coefficient rows on its stream; the running-statistics half of
-        every grouped finalize -- heads included -- runs on the OWN forward's stream after the join (ops._probe_finalize):
-        checked call by call (stream, and behind the own update of the same BatchNorm in that iteration);
-      * "events" (FEDICRA_PROBE_DEFER=0, round 3's form): one event per layer, now also behind the statistics-only head:
-        every BatchNorm the probe finalises finds the own forward's event.
-    Either way the state equals the in-line order's."""
+    The probe makes only the coefficient rows on its stream; the running-statistics half of every grouped finalize -- heads
+    included -- runs on the OWN forward's stream after the join (ops._probe_finalize): checked call by call (stream, and behind
+    the own update of the same BatchNorm in that iteration).  The state equals the in-line order's.  (Round 3's form -- one event
+    per layer between the two streams -- was removed in round 6.)"""
     from fedicra_amd import _lib as L
     from fedicra_amd import ops
     from fedicra_amd.flower_common import MyModel
@@ -120,18 +117,13 @@ def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
     from fedicra_amd.networks import net_factory
     from helpers import loader
     seen, log = [], []
-    orig_after, orig_fin, orig_fused, orig_one, orig_begin = ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration
+    orig_fin, orig_fused, orig_one, orig_begin = L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration
     orig_multi = L.bn_running_groups_multi
 
     def spy_multi(items):
         for it in items:
             log.append(("probe", it[3].data_ptr(), False, cur()))
         return orig_multi(items)
-
-    def spy_after(bn):
-        ev = None if ops._ctx.bn_events is None else ops._ctx.bn_events.get(id(bn))
-        seen.append((id(bn), ops._ctx.bn_events is not None, ev is not None))
-        return orig_after(bn)
 
     def cur():
         return torch.cuda.current_stream().cuda_stream
@@ -163,30 +155,21 @@ def test_probe_moves_running_statistics_behind_the_own_forward(use_graph, mode):
         batches = loader(3, 4, 64, cid=1, device=DEV)
         client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
         client.probe_beside = beside
-        client.own_in_probe = False                  # (this test is about the own forward as a pass of its own beside the batch)
-        client.probe_defer_running = mode == "deferred"
         assert client.aux_stats_only
         names = {id(m): n for n, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
         rm = {m.running_mean.data_ptr(): n for n, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
         seen.clear(), log.clear()
-        ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = spy_after, spy_fin, spy_fused, spy_one, spy_begin
+        L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = spy_fin, spy_fused, spy_one, spy_begin
         L.bn_running_groups_multi = spy_multi
         try:
             cfg = {"iter_global": 60, "iters": 5, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
             client._train(cfg)
             client._train(cfg)
         finally:
-            ops.probe_after, L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = orig_after, orig_fin, orig_fused, orig_one, orig_begin
+            L.bn_finalize_groups, L.bn_fused_fwd, L.bn_finalize, ops.begin_iteration = orig_fin, orig_fused, orig_one, orig_begin
             L.bn_running_groups_multi = orig_multi
         torch.cuda.synchronize()
-        if beside and mode == "events":
-            forked = [(names.get(i, "?"), found) for i, on, found in seen if on]
-            assert forked, "the probe never ran beside the own forward"
-            missing = sorted({n for n, found in forked if not found})
-            assert not missing, f"BatchNorms the probe updated without waiting for the own forward's update: {missing}"
-            assert any("dsn_head" in n for n, _ in forked), sorted({n for n, _ in forked})
-        if beside and mode == "deferred":
-            assert not seen or not any(on for _, on, _ in seen)          # no per-layer events in this form
+        if beside:
             iters, curi = [], None
             for rec in log:
                 if rec[0] == "begin":
@@ -395,62 +378,6 @@ def test_unet3d_deferred_filter_gradients_and_skip_sums_equal_the_per_layer_form
     assert float((res["captured"] - res["deferred"]).abs().max()) <= 2e-3 * scale
 
 
-@pytest.mark.parametrize("dtype,use_graph", [("fp32", False), ("fp32", True), ("bf16", True)])
-def test_head_phase_own_forward_as_group_0_of_the_batched_forwards(dtype, use_graph):
-    """Head phase of FedICRA's schedule (/root/reference/code/flower_pCE_2D.py:84-101: only decoder.out_conv trains): the own forward
-    (:106) travels as group 0 of the batched LC forwards (:128-139) and only its last decoder feature is written out
-    (MyClient.own_in_probe, _UNetLCBase.probe_heatmaps(own=True), ops.probe_conv_bn(store="own")) -- against the own forward as a pass
-    of its own (autograd graph, materialised activations) beside the batch: two rounds of 4 head-phase iterations from the same seeds
-    leave the same losses, parameters (decoder.out_conv is what trains), BatchNorm running statistics and counters (every BatchNorm
-    moved 1 + (K-1) times per iteration in the same order, the same dropout draws), fp32 to round-off, bf16 to its own noise; the
-    merged form really ran.  (tools/own_in_probe_diff.py: after one and after three fp32 iterations every running statistic and the
-    out_conv gradient agree to 2.5e-7 of their scale.  Rounds WITH body-phase iterations are not compared tightly: there AdamW on
-    every parameter amplifies such round-off like any other -- DESIGN section 5, the parity horizon.)"""
-    from fedicra_amd import ops
-    from fedicra_amd.flower_common import MyModel
-    from fedicra_amd.flower_pCE_2D import MyClient
-    from fedicra_amd.networks import net_factory
-    from fedicra_amd.networks.unet import set_compute_dtype
-    from helpers import loader
-    res, merged_calls = [], []
-    for merged in (False, True):
-        args = argparse.Namespace(strategy="FedICRA", amp=0, model="unet_lc", cid=1, min_num_clients=4, num_classes=2,
-                                  img_class="faz", base_lr=0.01, max_iterations=200, iters=4, rep_iters=0, alpha=1.0,
-                                  snapshot_path=None, use_graph=use_graph)
-        torch.manual_seed(2022)
-        ops.manual_seed(11)
-        net = net_factory(args, net_type="unet_lc", in_chns=1, class_num=2).to(DEV)
-        set_compute_dtype(net, dtype)
-        batches = loader(3, 4, 64, cid=1, device=DEV)
-        client = MyClient(args, MyModel(args, net, batches, batches), batches, batches)
-        assert client.probe_beside and not client.own_in_probe             # (an option: measured level with the two-stream form)
-        client.own_in_probe = merged
-        orig, n = net.probe_heatmaps, [0, 0]
-
-        def spy(x, ids, enc_done=None, own=False, _orig=orig, _n=n):
-            _n[1 if own else 0] += 1
-            return _orig(x, ids, enc_done=enc_done, own=own)
-
-        net.probe_heatmaps = spy
-        cfg = {"iter_global": 60, "iters": 4, "eval_iters": 10, "batch_size": 4, "stage": "fit"}
-        client._train(cfg)
-        client._train(cfg)
-        torch.cuda.synchronize()
-        merged_calls.append(tuple(n))
-        res.append((list(client.last_losses), net.flat_state.clone(), net.flat_counters.clone()))
-    assert merged_calls[0][1] == 0 and merged_calls[1][1] >= (2 if use_graph else 8) and merged_calls[1][0] == 0, merged_calls     # (captured: eager + capture, then replays)
-    (l0, s0, c0), (l1, s1, c1) = res
-    assert torch.equal(c0, c1)
-    if dtype == "fp32":
-        assert np.allclose(l0, l1, rtol=0, atol=2e-5), (l0, l1)
-        assert torch.allclose(s0, s1, rtol=1e-4, atol=2e-5), float((s0 - s1).abs().max())
-    else:
-        assert np.allclose(l0, l1, rtol=0, atol=3e-2), (l0, l1)
-        d = (s0 - s1).abs()
-        assert float(d.max()) <= 5e-2 * max(1.0, float(s0.abs().max())) and float(d.mean()) <= 2e-3, (float(d.max()), float(d.mean()))
-
-
-# ------------------------------------------------------------------------------------------------ tree-energy glue (csrc/treeglue.hip)
 def _nchw_view(t):
     """the layout the trainer hands over: an NCHW view of a dense NHWC tensor"""
     return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
@@ -740,7 +667,7 @@ def test_bf16_iteration_of_config3_with_every_form_on_against_the_fp32_mode():
         net = net_factory(args, net_type="unet_lc", in_chns=3, class_num=3).to(DEV)
         set_compute_dtype(net, dtype)
         client = MyClient(args, MyModel(args, net, batch, batch), batch, batch)
-        assert client.probe_beside and client.probe_defer_running and client.aux_stats_only
+        assert client.probe_beside and client.aux_stats_only
         client._train({"iter_global": 60, "iters": 1, "eval_iters": 10, "batch_size": 12, "stage": "fit"})   # iters - rep_iters = 0: body phase
         torch.cuda.synchronize()
         grads = {n: p._fi_gview.detach().double().clone() for n, p in net.named_parameters() if getattr(p, "_fi_gview", None) is not None}
