@@ -1,7 +1,7 @@
 // Forward / dgrad kernel, sixth form: the GEMM-shaped tile for the channel-rich 3x3 layers -- 512 pixels x 128 output channels per
 // workgroup, every operand byte brought into LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no producer waves.
 //
-// Why (round 6; DESIGN.md "conv", profiles/r03_h_ws2_trace.txt): conv_fwd_ws2_kernel's 256-pixel x 128-channel tile streams a 37 KB
+// Why (round 6; DESIGN.md 4.1, LOG.md (6) / (10), profiles/r03_h_ws2_trace.txt): conv_fwd_ws2_kernel's 256-pixel x 128-channel tile streams a 37 KB
 // weight slab per 10 KB of pixels through the CU's ~20 B/clk L2 -> LDS fill path -- 2 350 cycles of fill for 2 304 cycles of MFMAs --
 // and its BatchNorm / LeakyReLU / dropout input transform is the vector work of ONE 4-wave producer team at a time.  Here
 //   * a weight slab serves TWICE the pixels: two 16 x 16-pixel sub-tiles (A, B: consecutive tiles of the launch) share the slab

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   //      strides -- no div/mod, one bounds compare and one multiply-add per vector.  Loads are unconditional
   //      (clamped address, zeroed at the LDS write): a load under a divergent branch makes the compiler wait for
   //      it at the merge point, which serialises one HBM round trip per vector.
-  //      Tried and measured slower on MI355X (tools/kbench.py): prefetching the next chunk
+  //      Tried and measured slower on MI355X (tools/kbench.py, LOG.md section 6): prefetching the next chunk
   //      into registers (VGPRs 100 -> 180-240, occupancy halves: 354 -> 499 us over the U-Net forward convs) and
   //      persistent workgroups walking several tiles (354 -> 415 us): many independent workgroups hide the
   //      staging round trips better.

@@ -12,7 +12,7 @@ iteration, the same metrics dict.  MI355X-native differences:
     once per round instead of the reference's ``loss.item()`` sync every iteration (:152);
   * batches are staged into static device buffers (the graph's inputs).
 
-Reference defect handled: :117-118 unpacks UNet_LC's 8 outputs into 7 names; here the
+Reference defect handled (LOG.md section 2): :117-118 unpacks UNet_LC's 8 outputs into 7 names; here the
 logits are ``out[0]`` and the heat-maps ``out[6]``.
 """
 from __future__ import annotations

@@ -5,7 +5,7 @@ are created), and work on two streams that share a queue is served in order, not
 made its own stream when it first needed one -- the batched LC forwards (flower_pCE_2D.MyClient), the batch stager, the
 aggregation's side stream (comm.WeightedAllReduce), torch.cuda.graph's capture stream, the tree filter's branches -- so which
 streams shared a queue depended on the order the components happened to be built in: the same bench measured 1 392 images/s with
-a one-rank RCCL group alive and 1 298 without it, and 66 against 72 ms of training per round between two
+a one-rank RCCL group alive and 1 298 without it (LOG.md (24)), and 66 against 72 ms of training per round between two
 construction orders.  Here the first request for ANY role creates the streams of ALL roles of that device, in the order of
 `ROLES`, distinct from one another and from the stream that is current at that moment; later requests return them.  Entry points
 (bench.py, run_federated.py, the trainers' constructors) call `init()` before anything else makes a stream -- before the process

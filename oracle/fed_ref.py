@@ -13,7 +13,7 @@
     ``load_state_dict`` (copy_ truncates toward zero) path is reproduced in
     ``set_weights_plain``.
 
-Known reference defects restated as *working* code (documented in DESIGN.md):
+Known reference defects restated as *working* code (documented in LOG.md section 2):
   * flower_pCE_2D.py:117-118 unpacks UNet_LC's 8-element return list into 7 names
     (ValueError as shipped); the restatement indexes out[0] (logits) / out[6] (heat-maps).
 """

@@ -76,7 +76,7 @@ def test_g6_device_aggregate_reproduces_the_references_counter_path(golden):
 
 @pytest.mark.parametrize("frozen", ["torch1", "torch2"])
 def test_fused_adamw_frozen_parameter_semantics_against_torch_adamw(frozen):
-    """FedICRA's freeze schedule under the two zero_grad semantics ('a stated deviation'): FusedAdamW against
+    """FedICRA's freeze schedule under the two zero_grad semantics (LOG.md section 5, 'a stated deviation'): FusedAdamW against
     torch.optim.AdamW on the CPU fed the same gradients for two rounds of 3 head-phase + 2 body-phase iterations, a fresh
     optimizer per round (flower_pCE_2D.py:55).  torch1 = PyTorch 1.10.2 of the reference's environment: a parameter that has
     held a gradient keeps a zero gradient while frozen, so AdamW keeps decaying it; torch2 = gradients set to None: skipped."""

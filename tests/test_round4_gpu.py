@@ -131,7 +131,7 @@ def test_staging_ring_under_stress_serves_every_iteration_the_batch_it_asked_for
 
 
 def test_two_streams_copying_pageable_host_memory_at_once_probe():
-    """the round-3 flake (eager-vs-captured losses apart from the first iteration on, 2 of ~10 fresh
+    """LOG.md section 4 (8): the round-3 flake (eager-vs-captured losses apart from the first iteration on, 2 of ~10 fresh
     boxes) appeared when PAGEABLE batches were copied ahead on the side stream while the compute stream also copied pageable
     memory -- the runtime bounces such copies through its own staging buffer.  This probe drives exactly that pattern, 400
     times with the flaky test's sizes, and reports how many copies arrived torn; it asserts nothing about the runtime (the
