@@ -19,7 +19,7 @@ STATS_SLOTS = 8                # FI_STATS_SLOTS in include/fedicra_hip.h
 DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_wgrad_fused", "fi_conv3d_wgrad_fused_workspace", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
+    "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_wgrad_fused", "fi_conv3d_wgrad_fused_workspace", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_conv3d_tuning", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
     "fi_wgrad_reduce_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
@@ -64,7 +64,7 @@ class FiError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 4             # include/fedicra_hip.h FI_ABI_VERSION
+ABI_VERSION = 5             # include/fedicra_hip.h FI_ABI_VERSION
 
 
 def source_hash():
@@ -936,6 +936,11 @@ def conv3d_fwd_fused(x0, x1, w_all, bias, y, stats, *, ksize):
         return False
     _chk(rc, "fi_conv3d_fwd_fused")
     return True
+
+
+def conv3d_tuning(stream_on=-1):
+    """fi_conv3d_tuning: measurement / test hook (1 = the depth-streaming kernel for the thin 128^3 layers, 0 = the general form)."""
+    _chk(lib().fi_conv3d_tuning(int(stream_on)), "fi_conv3d_tuning")
 
 
 def conv3d_dgrad_fused(dy, wt_all, d0, d1, *, ksize):

@@ -38,6 +38,9 @@ int fi_conv_fwd_ws2_bf16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_
 int fi_conv_fwd_ws2_f16(int form, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_dma_bf16(int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_fwd_dma_f16(int wgs_per_cu, const ConvArgs& a, hipStream_t st);
+// conv3d_stream.hip: the thin full-resolution 3x3x3 layers streamed along the depth axis (FI_ERR_UNSUPPORTED: shape not covered)
+int fi_conv3d_stream(int dtype, int N, int D, int H, int W, int c0, int c1, int co0, int co1, const void* x0, const void* x1, const void* w,
+                     const float* bias, void* y0, void* y1, double* stats, long stats_stride, hipStream_t st);
 int fi_conv_thin_f32n_bf16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_thin_f32n_f16(int ck, int wgs_per_cu, const ConvArgs& a, hipStream_t st);
 int fi_conv_narrow_in_bf16(const ConvArgs& a, hipStream_t st);
@@ -846,6 +849,11 @@ extern "C" int fi_conv3d_fwd_fused(const FiConv* d, int D, const void* x0, const
   if (D < 1 || d->co1 != 0 || (d->c1 > 0 && !x1)) return FI_ERR_SHAPE;
   if (d->ksize != 3 || d->accumulate0 || d->accumulate1 || d->y_f32) return FI_ERR_UNSUPPORTED;
   if ((long)d->N * D > 0x7fffffffL) return FI_ERR_UNSUPPORTED;
+  {  // the thin 128^3 layers (16 [+ 32] -> 16): one staging of every input slice per tile instead of three (conv3d_stream.hip)
+    const int rc = fi_conv3d_stream(d->dtype, d->N, D, d->H, d->W, d->c0, d->c1, d->co0, 0, x0, x1, w_all, bias, y, nullptr, stats,
+                                    stats_stride, (hipStream_t)stream);
+    if (rc != FI_ERR_UNSUPPORTED) return rc;
+  }
   FiConv s = *d;
   s.N = d->N * D;
   return conv_fwd_impl(&s, nullptr, nullptr, D, 0, x0, x1, w_all, bias, y, nullptr, stats, stats_stride, stream, D);
@@ -859,6 +867,11 @@ extern "C" int fi_conv3d_dgrad_fused(const FiConv* d, int D, const void* dy, con
   if (D < 1 || d->c1 != 0 || (d->co1 > 0 && !d1)) return FI_ERR_SHAPE;
   if (d->ksize != 3 || d->accumulate0 || d->accumulate1 || d->y_f32) return FI_ERR_UNSUPPORTED;
   if ((long)d->N * D > 0x7fffffffL) return FI_ERR_UNSUPPORTED;
+  {  // 16 -> 16 and 16 -> (16 + 32): the same streaming kernel on the flipped, transposed filter
+    const int rc = fi_conv3d_stream(d->dtype, d->N, D, d->H, d->W, d->c0, 0, d->co0, d->co1, dy, nullptr, wt_all, nullptr, d0, d1, nullptr, 0,
+                                    (hipStream_t)stream);
+    if (rc != FI_ERR_UNSUPPORTED) return rc;
+  }
   FiConv s = *d;
   s.N = d->N * D;
   return conv_fwd_impl(&s, nullptr, nullptr, 0, 0, dy, nullptr, wt_all, nullptr, d0, d1, nullptr, 0, stream, D);

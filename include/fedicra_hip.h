@@ -50,8 +50,9 @@ extern "C" {
  *   2: round 3 (FiConv.w16 / w16_rows + fi_pack_weights modes 2 / 3 and the 8-column pack table, fi_conv_weight_chunk16,
  *      fi_pcs_gate_*, fi_lc_loss_*, fi_conv3d_wgrad_fused*, this check)
  *   3: round 4 (new entry points: fi_conv2d_stats_xcorr*, fi_bn_act_pool_groups, fi_conv1x1_up2x_fwd, fi_wgrad_tuning / fi_narrow_tuning /
- *      fi_upfuse_tuning, fi_pack_weights3d_multi; fi_wgrad_tuning's argument became a bit mask) */
-#define FI_ABI_VERSION 4
+ *      fi_upfuse_tuning, fi_pack_weights3d_multi; fi_wgrad_tuning's argument became a bit mask)
+ *   5: round 6 (fi_conv3d_tuning; fi_conv_tuning(7, 8): the LDS-DMA forward form) */
+#define FI_ABI_VERSION 5
 int fi_abi_version(void);
 
 /* ---------------------------------------------------------------- convolution ------------
@@ -187,6 +188,11 @@ int fi_conv3d_dgrad(const FiConv* d, int D, const void* dy, const void* const* w
 int fi_conv3d_fwd_fused(const FiConv* d, int D, const void* x0, const void* x1, const void* w_all, const float* bias, void* y,
                         double* stats, long stats_stride, void* stream);
 int fi_conv3d_dgrad_fused(const FiConv* d, int D, const void* dy, const void* wt_all, void* d0, void* d1, void* stream);
+/* Measurement / test hook: 1 (default; FI_CONV3D_STREAM) = fi_conv3d_fwd_fused / fi_conv3d_dgrad_fused run the thin full-resolution
+ * layers of unet_3D (/root/reference/code/networks/unet_3D.py:40-41,60-61: 16 -> 16, (16 + 32) -> 16; their input gradients 16 -> 16,
+ * 16 -> (16 + 32); 16-bit storage) on the depth-streaming kernel (csrc/conv3d_stream.hip: every input slice staged once per 16 x 16
+ * tile through a three-slice LDS ring); 0 = the general one-launch form for them too; -1 = the environment default. */
+int fi_conv3d_tuning(int stream_on);
 long fi_conv3d_wgrad_workspace(const FiConv* d, int D);
 int fi_conv3d_wgrad(const FiConv* d, int D, const void* x0, const void* x1, const void* dy, float* dw_taps, float* dbias,
                     void* workspace, long workspace_bytes, void* stream);

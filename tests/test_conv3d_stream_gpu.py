@@ -1,0 +1,73 @@
+"""conv3d_stream_kernel (csrc/conv3d_stream.hip: the thin full-resolution 3x3x3 layers of unet_3D streamed along the depth axis,
+/root/reference/code/networks/unet_3D.py:40-41,60-61 with utils.py:99-123,260-276) against the general one-launch form on the same
+operands (fi_conv3d_tuning switches between them in-process) and against torch's conv3d on the CPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TD = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+# (N, D, H, W, c0, c1, cout0, cout1, kind)
+CASES = [
+    (2, 16, 32, 32, 16, 0, 16, 0, "fwd"),           # conv1.conv2 / up_concat1.conv2
+    (1, 12, 40, 24, 16, 32, 16, 0, "fwd"),          # up_concat1.conv1: cat([skip 16, up-sampled 32]); ragged tiles
+    (2, 9, 17, 33, 16, 0, 16, 0, "fwd"),            # odd depth, ragged rows and columns
+    (1, 20, 32, 48, 16, 0, 16, 0, "dgrad"),         # input gradient 16 -> 16
+    (2, 8, 24, 40, 16, 0, 16, 32, "dgrad"),         # input gradient of the concatenation: two destinations
+    (1, 32, 64, 64, 16, 32, 16, 0, "fwd"),          # several runs per tile column
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_streaming_kernel_equals_the_general_form_and_torch(dtype, case):
+    from fedicra_amd import _lib as L
+    N, D, H, W, c0, c1, co0, co1, kind = CASES[case]
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(700 + case)
+    cin, cout = c0 + c1, co0 + co1
+    x0 = torch.randn(N, D, H, W, c0, generator=gen).to(DEV).to(td)
+    x1 = torch.randn(N, D, H, W, c1, generator=gen).to(DEV).to(td) if c1 else None
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=gen) * 0.08).to(td)            # as the forward conv's [Cout][Cin][kD][kH][kW]
+    # the library's operand: [Cout][kH * kW][kD][Cin] (ops3d._w_all mode 0; a dgrad's flipped / transposed filter has the same layout)
+    w_all = w.permute(0, 3, 4, 2, 1).contiguous().view(cout, 9, 3, cin).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV) if kind == "fwd" else None
+
+    def run():
+        st = torch.zeros(N, L.STATS_SLOTS, cout, 2, dtype=torch.float64, device=DEV) if kind == "fwd" else None
+        if kind == "fwd":
+            y = torch.empty(N, D, H, W, cout, dtype=td, device=DEV)
+            assert L.conv3d_fwd_fused(x0, x1, w_all, bias, y, st, ksize=3)
+            return (y,), st
+        d0 = torch.empty(N, D, H, W, co0, dtype=td, device=DEV)
+        d1 = torch.empty(N, D, H, W, co1, dtype=td, device=DEV) if co1 else None
+        assert L.conv3d_dgrad_fused(x0, w_all, d0, d1, ksize=3)
+        return (d0, d1), None
+
+    try:
+        L.conv3d_tuning(0)
+        want, st_want = run()
+        L.conv3d_tuning(1)
+        got, st_got = run()
+        torch.cuda.synchronize()
+    finally:
+        L.conv3d_tuning(-1)
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    for a, b in zip(got, want):
+        if a is not None:
+            d = (a.float() - b.float()).abs()
+            assert bool((d <= 2 * ulp * b.float().abs() + 2e-3).all()), float(d.max())
+            assert float((d > 0).float().mean()) < 2e-2                            # same fp32 products, another accumulation order
+    if st_want is not None:
+        assert torch.allclose(st_got.sum(1), st_want.sum(1), rtol=5e-3, atol=2e-2)
+    # torch on the CPU, fp32 arithmetic on the same 16-bit values
+    xin = torch.cat([x0] + ([x1] if c1 else []), 4).float().cpu().permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.conv3d(xin, w.float(), None if bias is None else bias.cpu(), padding=1).permute(0, 2, 3, 4, 1)
+    out = torch.cat([t.float().cpu() for t in got if t is not None], 4)
+    err = (out - ref).abs()
+    assert float(err.max()) <= 4 * ulp * float(ref.abs().max()) + 1e-3, float(err.max())
+    if st_got is not None:
+        s = st_got.sum(1).cpu()
+        assert torch.allclose(s[..., 0], out.double().sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(s[..., 1], (out.double() ** 2).sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
