@@ -20,7 +20,7 @@ DROP_NONE, DROP_MASK_ELEM, DROP_RNG_ELEM, DROP_MASK_CHAN, DROP_RNG_CHAN = 0, 1, 
 
 EXPORTS = [
     "fi_abi_version", "fi_conv_weight_chunk16", "fi_conv3d_wgrad_fused", "fi_conv3d_wgrad_fused_workspace", "fi_pcs_gate_fwd", "fi_pcs_gate_bwd", "fi_lc_loss_fwd", "fi_lc_loss_bwd", "fi_conv3d_fwd_fused", "fi_conv3d_dgrad_fused", "fi_conv3d_tuning", "fi_global_avgmax_ranges", "fi_global_avgmax_split", "fi_conv2d_fwd", "fi_conv2d_fwd_fused", "fi_bn_finalize_groups", "fi_conv_tuning", "fi_conv2d_wgrad", "fi_conv2d_wgrad_workspace", "fi_conv2d_wgrad_partial",
-    "fi_wgrad_reduce_multi", "fi_pack_weights",
+    "fi_wgrad_reduce_multi", "fi_wgrad_permute3d_multi", "fi_pack_weights",
     "fi_pack_weights_multi", "fi_bn_fused_fwd", "fi_bn_finalize", "fi_bn_act_fwd",
     "fi_bn_act_bwd_reduce", "fi_bn_act_bwd_apply", "fi_maxpool2_fwd", "fi_maxpool2_bwd", "fi_maxpool2_bwd_add", "fi_upsample2x_fwd",
     "fi_upsample2x_bwd", "fi_maxpool3d_fwd", "fi_maxpool3d_bwd", "fi_maxpool3d_bwd_add", "fi_conv3d_wgrad_fused_partial", "fi_upsample3d2x_fwd", "fi_upsample3d2x_bwd", "fi_ce_fwd", "fi_ce_finalize", "fi_ce_bwd", "fi_pdice_fwd", "fi_pdice_finalize",
@@ -64,7 +64,7 @@ class FiError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 5             # include/fedicra_hip.h FI_ABI_VERSION
+ABI_VERSION = 6             # include/fedicra_hip.h FI_ABI_VERSION
 
 
 def source_hash():
@@ -455,13 +455,16 @@ def conv2d_wgrad_partial(x0, x1, dy, want_bias, *, ksize):
     return ws, slices.value, stride.value
 
 
-WGRAD_ROW = 10       # FI_WGRAD_ROW
+WGRAD_ROW = 11       # FI_WGRAD_ROW
 CE_SLOTS = 16        # FI_CE_SLOTS
 
 
-def wgrad_reduce_multi(table, n, nblocks):
+def wgrad_reduce_multi(table, n, nblocks, nblocks3d=0):
+    """nblocks3d > 0: rows with word 9 < 0 get their second launch (fi_wgrad_permute3d_multi) right behind the reduce."""
     with _timed("wgrad_reduce", (n,), 0, 0):
         _chk(lib().fi_wgrad_reduce_multi(ptr(_dev(table)), int(n), int(nblocks), stream()), "fi_wgrad_reduce_multi")
+        if nblocks3d > 0:
+            _chk(lib().fi_wgrad_permute3d_multi(ptr(_dev(table)), int(n), int(nblocks3d), stream()), "fi_wgrad_permute3d_multi")
 
 
 def pack_weights3d_multi(table, ntensors, nblocks, dtype):

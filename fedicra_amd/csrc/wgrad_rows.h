@@ -18,6 +18,7 @@
 //     per workgroup and written as ONE partial slice in the layout of conv_wgrad_kernel, which fi_wgrad_reduce_multi folds.
 #pragma once
 #include "conv_impl.h"
+#include <type_traits>
 
 struct WgRowsArgs {
   const void* x0;
@@ -32,7 +33,19 @@ struct WgRowsArgs {
   int depth;               // conv_wgrad_rows3d_kernel: slices per volume (an "image" is a slice)
   int cd;                  // NARROW == 2: channels of the gradient tensor (<= 4); NARROW == 1: c0 <= 4 is the input's, c1 = 0
   int cout, nct, nit;      // conv_wgrad_rows64_kernel: gradient channels, gradient / input channel tiles per item
+#ifdef FI_TRACE
+  long long* trace;        // conv_wgrad_rows3d_kernel: [workgroup][wave][16 rows][8] s_memtime stamps (tools/rows3d_trace.py); debug builds only
+#endif
 };
+#ifdef FI_TRACE
+#define FI_TROW(slot)                                                                                                            \
+  do {                                                                                                                           \
+    if (a.trace && lane == 0 && rho - r0 >= 16 && rho - r0 < 32)                                                                 \
+      a.trace[(((size_t)blockIdx.x * 4 + wave) * 16 + (rho - r0 - 16)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define FI_TROW(slot) do { } while (0)
+#endif
 
 template <typename T>
 __device__ __forceinline__ typename DT<T>::frag_t wgr_frag(const char* addr) {
@@ -303,7 +316,7 @@ static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st
 // roofline).  Cout = 16.  NCI = 1: the four waves split the K steps; NCI = 2, 3: wave w < NCI owns input block w (27
 // accumulators of 4 registers each either way), the blocks of a wave's run need no cross-wave sum.
 template <typename T, int NCI, int MAXW>
-__global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
   typedef typename DT<T>::frag_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,7 +325,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
   const int xrow = NCI * xplane;
   char* const xs = smem;                        // [2][NCI][ws + 2][16]
   char* const ds = smem + 2 * xrow;             // [3 kd][4][ws][16]
-  int item = blockIdx.x;
+  // workgroup -> item: an XCD (blockIdx % 8) takes a contiguous run of slices, so the dy rows the items of the slices
+  // sigma - 1, sigma, sigma + 1 all load come out of that XCD's L2 once instead of from three XCDs' worth of fabric traffic
+  const int total = a.N * a.strips * a.chunks, per_xcd = (total + 7) >> 3;
+  int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int slice_idx = item;
   const int chunk = item % a.chunks;
   item /= a.chunks;
   const int strip = item % a.strips, n = item / a.strips;        // n: slice index over all volumes
@@ -327,52 +345,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
   constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 + 255) / 256;
   const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2;
   uint4 xrA[NXV], xrB[NXV], drA[3][NDV], drB[3][NDV];
-  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
-    const bool rowok = rho >= 0 && rho < H;
+  // Everything a row's loads and LDS stores need per thread is fixed for the whole run and computed once: the source pointer of each
+  // vector at row 0 (column and channel folded in, out-of-range columns clamped to a valid address), its row pitch, its place in the
+  // LDS plane, and a bit per vector for "inside the strip".  A row step then costs one 64-bit multiply-add per load and a scalar row
+  // test -- recomputing the addresses per row was 0.9 + 0.8 of a step's 6.6 k cycles at 48 -> 16 and half of a step at 16 -> 16
+  // (tools/rows3d_trace.py), issue slots taken from the MFMAs of the workgroup sharing the SIMDs.
+  const char* xsrc[NXV];
+  unsigned xpitch[NXV], xdst[NXV], xin = 0, xcol = 0;
 #pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCI), px = i / (2 * NCI);
-      const int gx = cs + px - 1, ch = v * 8;
-      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
-      const bool first = ch < a.c0;
-      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
-                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
-      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
+  for (int it = 0; it < NXV; ++it) {
+    const int i = tid + it * 256;
+    const int v = i % (2 * NCI), px = i / (2 * NCI);
+    const int gx = cs + px - 1, ch = v * 8;
+    const bool in = i < nxv, colok = in && gx >= 0 && gx < W;
+    const bool first = ch < a.c0;
+    xsrc[it] = reinterpret_cast<const char*>(first ? x0 + (size_t)(colok ? gx : 0) * a.c0 + ch : x1 + (size_t)(colok ? gx : 0) * a.c1 + (ch - a.c0));
+    xpitch[it] = (unsigned)((first ? a.c0 : a.c1) * W * (int)sizeof(T));
+    xdst[it] = (unsigned)((v >> 1) * xplane + px * 32 + (v & 1) * 16);
+    xin |= (unsigned)in << it;
+    xcol |= (unsigned)colok << it;
+  }
+  unsigned dsrc[NDV], ddst[NDV], din = 0;
+#pragma unroll
+  for (int it = 0; it < NDV; ++it) {
+    const int i = tid + it * 256;
+    const bool in = i < ndv;
+    dsrc[it] = (unsigned)(((cs + (in ? i >> 1 : 0)) * 16 + (i & 1) * 8) * (int)sizeof(T));
+    ddst[it] = (unsigned)((i >> 1) * 32 + (i & 1) * 16);
+    din |= (unsigned)in << it;
+  }
+  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
+    const unsigned rc = (unsigned)min(max(rho, 0), H - 1);   // out-of-range rows read a valid one; store_x zeroes them
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) xr[it] = *reinterpret_cast<const uint4*>(xsrc[it] + (size_t)rc * xpitch[it]);
+  };
+  // The zeroing of out-of-range lanes happens when a row is STORED to LDS, a step or two after its loads were issued: a select right
+  // at the load is a use of the loaded registers that the compiler places (with its s_waitcnt vmcnt) at the end of the same step.
+  auto load_d = [&](uint4 (&dr)[3][NDV], int r) {           // dy rows r of the slices sigma + 1, sigma, sigma - 1 (kd = 0, 1, 2)
+    const int rc = min(max(r, 0), H - 1);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int sd = sigma - kd + 1;
+      const bool sok = sd >= 0 && sd < D;
+      const char* const base = reinterpret_cast<const char*>(dyv + ((size_t)(sok ? n - kd + 1 : n) * plane + (size_t)rc * W) * 16);   // uniform
+#pragma unroll
+      for (int it = 0; it < NDV; ++it) dr[kd][it] = *reinterpret_cast<const uint4*>(base + dsrc[it]);
     }
   };
-  auto load_d = [&](uint4 (&dr)[3][NDV], int r) {           // dy rows r of the slices sigma + 1, sigma, sigma - 1 (kd = 0, 1, 2)
+  auto store_x = [&](const uint4 (&xr)[NXV], int rho) {      // the registers hold x row rho
+    char* const dst = xs + (rho & 1) * xrow;
+    const bool rowok = rho >= 0 && rho < H;
+#pragma unroll
+    for (int it = 0; it < NXV; ++it)
+      if ((xin >> it) & 1u) *reinterpret_cast<uint4*>(dst + xdst[it]) = fi_vec_select(rowok && ((xcol >> it) & 1u), xr[it]);
+  };
+  auto store_d = [&](const uint4 (&dr)[3][NDV], int r) {      // the registers hold dy rows r of the three slices
     const bool rowok = r >= 0 && r < H;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
       const int sd = sigma - kd + 1;
-      const bool sok = rowok && sd >= 0 && sd < D;
-      const T* const base = dyv + (size_t)(sok ? n - kd + 1 : n) * plane * 16;
+      const bool ok = rowok && sd >= 0 && sd < D;
+      char* const dst = ds + (kd * 4 + (r & 3)) * dplane;
 #pragma unroll
-      for (int it = 0; it < NDV; ++it) {
-        const int i = tid + it * 256;
-        const int v = i & 1, px = i >> 1;
-        const bool ok = sok && i < ndv;
-        dr[kd][it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(base + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * 16 + v * 8));
-      }
+      for (int it = 0; it < NDV; ++it)
+        if ((din >> it) & 1u) *reinterpret_cast<uint4*>(dst + ddst[it]) = fi_vec_select(ok, dr[kd][it]);
     }
-  };
-  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
-#pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCI), px = i / (2 * NCI);
-      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
-    }
-  };
-  auto store_d = [&](const uint4 (&dr)[3][NDV], int slot) {
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-      for (int it = 0; it < NDV; ++it) {
-        const int i = tid + it * 256;
-        if (i < ndv) *reinterpret_cast<uint4*>(ds + (kd * 4 + slot) * dplane + (i >> 1) * 32 + (i & 1) * 16) = dr[kd][it];
-      }
   };
 
   f32x4 acc[3][3][3];                            // [kd][kr][kc]
@@ -390,15 +427,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
   const int blk = CISPLIT ? wave : 0;            // this wave's input block
   const bool active = !CISPLIT || wave < NCI;
   const int ks0 = CISPLIT ? 0 : wave, ksstep = CISPLIT ? 1 : 4;
+  // the bias sum rides along as a 28th MFMA against ones (zeros where it is not wanted: no branch inside the MFMA block)
+  union {
+    frag_t v;
+    uint4 u;
+  } bias_u;
+  bias_u.v = onesv;
+  if (!(a.want_bias && blk == 0)) bias_u.u = make_uint4(0u, 0u, 0u, 0u);
+  const frag_t bias_b = bias_u.v;
 
   load_x(xrA, r0);
   load_d(drA, r0 - 1);
   load_d(drB, r0);
-  store_x(xrA, r0 & 1);
-  store_d(drA, (r0 - 1) & 3);
+  store_x(xrA, r0);
+  store_d(drA, r0 - 1);
   load_d(drA, r0 + 1);
-  store_d(drB, r0 & 3);
-  store_d(drA, (r0 + 1) & 3);
+  store_d(drB, r0);
+  store_d(drA, r0 + 1);
   load_x(xrA, r0 + 1);
   load_d(drA, r0 + 2);
   load_x(xrB, r0 + 2);
@@ -407,40 +452,88 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
 
   const int nks = ws / 32;
   auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[3][NDV]) __attribute__((always_inline)) {
-    store_x(xr, (rho + 1) & 1);
-    store_d(dr, (rho + 2) & 3);
+    FI_TROW(0);
+    store_x(xr, rho + 1);
+    store_d(dr, rho + 2);
+    FI_TROW(1);
     load_x(xr, rho + 3);
     load_d(dr, rho + 4);
+    FI_TROW(2);
     if (active) {
+      // A K step is three groups of 9 MFMAs (one depth tap each: 3 gradient fragments x the 3 column-shifted input fragments).  The
+      // reads of group j + 1 are issued as one block BEFORE the MFMAs of group j, the scheduler fenced between the blocks: left to
+      // itself the compiler reads each gradient fragment right before its three MFMAs -- nine exposed LDS latencies per step, 2.7x
+      // the MFMA time at one or two waves per SIMD.  Two sets of 3 + 3 fragments: the same 48 registers (a whole step ahead would be
+      // 96 and cost the second workgroup of a CU).
       const char* const xb = xs + (rho & 1) * xrow + blk * xplane + laneoff;
-      for (int ks = ks0; ks < nks; ks += ksstep) {
-        frag_t bv[3];
+      const char* dbk[3];
+#pragma unroll
+      for (int kr = 0; kr < 3; ++kr) dbk[kr] = ds + ((rho - kr + 1) & 3) * dplane + laneoff;
+      auto rd_b = [&](frag_t (&bv)[3], int ks) __attribute__((always_inline)) {
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc) bv[kc] = wgr_frag<T>(xb + (ks * 32 + kc) * 32);
+      };
+      auto rd_a = [&](frag_t (&av)[3], int ks, int kd) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd)
+        for (int kr = 0; kr < 3; ++kr) av[kr] = wgr_frag<T>(dbk[kr] + kd * 4 * dplane + ks * 32 * 32);
+      };
+      auto mm = [&](const frag_t (&av)[3], const frag_t (&bv)[3], auto kdc) __attribute__((always_inline)) {
+        constexpr int kd = decltype(kdc)::value;
+        if constexpr (kd == 1) accb = mfma16(av[1], bias_b, accb);
 #pragma unroll
-          for (int kr = 0; kr < 3; ++kr) {
-            const frag_t av = wgr_frag<T>(ds + (kd * 4 + ((rho - kr + 1) & 3)) * dplane + laneoff + ks * 32 * 32);
-            if (kd == 1 && kr == 1 && a.want_bias && blk == 0) accb = mfma16(av, onesv, accb);
+        for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-            for (int kc = 0; kc < 3; ++kc) acc[kd][kr][kc] = mfma16(av, bv[kc], acc[kd][kr][kc]);
-          }
+          for (int kc = 0; kc < 3; ++kc) acc[kd][kr][kc] = mfma16(av[kr], bv[kc], acc[kd][kr][kc]);
+      };
+      // one K step: its first group's fragments are in a0 / b0; leaves the next step's first group in a1 / b1
+      auto kstep = [&](frag_t (&a0)[3], frag_t (&a1)[3], frag_t (&b0)[3], frag_t (&b1)[3], int ks) __attribute__((always_inline)) {
+        rd_a(a1, ks, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0, std::integral_constant<int, 0>());
+        __builtin_amdgcn_sched_barrier(0);
+        rd_a(a0, ks, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b0, std::integral_constant<int, 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + ksstep < nks) {
+          rd_b(b1, ks + ksstep);
+          rd_a(a1, ks + ksstep, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0, std::integral_constant<int, 2>());
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      frag_t avA[3], avB[3], bvA[3], bvB[3];
+      int ks = ks0;
+      if (ks < nks) {
+        rd_b(bvA, ks);
+        rd_a(avA, ks, 0);
+      }
+      for (; ks < nks; ks += 2 * ksstep) {
+        kstep(avA, avB, bvA, bvB, ks);
+        if (ks + ksstep < nks) kstep(avB, avA, bvB, bvA, ks + ksstep);
       }
     }
+    FI_TROW(3);
     fi_lds_barrier();
+    FI_TROW(4);
   };
-  for (int rho = r0; rho < r1; rho += 2) {
+  // (no conditional step inside the loop: a merge of the two register stages after it would be copies of registers whose loads are
+  // still in flight -- another early s_waitcnt vmcnt)
+  int rho = r0;
+  for (; rho + 1 < r1; rho += 2) {
     step(rho, xrA, drA);
-    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+    step(rho + 1, xrB, drB);
   }
+  if (rho < r1) step(rho, xrA, drA);
 
-  // ---- red[kd * 9 + t][block][co 16][ci 16]: K-split waves take turns adding; block-owning waves just write
-  constexpr int NACC = 27 * NCI * 256;
-  float* const red = reinterpret_cast<float*>(smem);
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w && active) {
+  // slice[((co * 9 + t) * 3 + kd) * cin + ci], bias behind it (the one-launch form's layout); D[row = co = g * 4 + r][col = ci = li]
+  constexpr int CIN = NCI * 16;
+  float* const slice = a.part + (size_t)slice_idx * a.part_stride;
+  if constexpr (CISPLIT) {
+    // block-owning waves: no cross-wave sum, so the accumulators go straight to the slice -- a reduction buffer of 27 x NCI x 1 KB
+    // (83 KB at 48 -> 16) would be the workgroup's LDS footprint and leave ONE workgroup per CU where the row ring allows two
+    if (active) {
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -448,38 +541,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
 #pragma unroll
           for (int kc = 0; kc < 3; ++kc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* dst = &red[(((kd * 9 + kr * 3 + kc) * NCI + blk) * 16 + g * 4 + r) * 16 + li];
-              *dst = (CISPLIT || w == 0) ? acc[kd][kr][kc][r] : *dst + acc[kd][kr][kc][r];
-            }
-      if (li == 0 && blk == 0) {
+            for (int r = 0; r < 4; ++r)
+              slice[(((size_t)(g * 4 + r) * 9 + kr * 3 + kc) * 3 + kd) * CIN + blk * 16 + li] = acc[kd][kr][kc][r];
+      if (a.want_bias && blk == 0 && li == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* dst = &red[NACC + g * 4 + r];
-          *dst = (CISPLIT || w == 0) ? accb[r] : *dst + accb[r];
+        for (int r = 0; r < 4; ++r) slice[(size_t)16 * 27 * CIN + g * 4 + r] = accb[r];
+      }
+    }
+  } else {
+    // ---- red[kd * 9 + t][co 16][ci 16]: the K-split waves take turns adding
+    constexpr int NACC = 27 * 256;
+    float* const red = reinterpret_cast<float*>(smem);
+    for (int w = 0; w < 4; ++w) {
+      __syncthreads();
+      if (wave == w) {
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float* dst = &red[((kd * 9 + kr * 3 + kc) * 16 + g * 4 + r) * 16 + li];
+                *dst = w == 0 ? acc[kd][kr][kc][r] : *dst + acc[kd][kr][kc][r];
+              }
+        if (li == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = &red[NACC + g * 4 + r];
+            *dst = w == 0 ? accb[r] : *dst + accb[r];
+          }
         }
       }
     }
+    __syncthreads();
+    for (int e = tid; e < 16 * 27 * CIN; e += 256) {
+      const int ci = e % CIN, kd = (e / CIN) % 3, t = (e / (CIN * 3)) % 9, co = e / (CIN * 27);
+      slice[e] = red[((kd * 9 + t) * 16 + co) * 16 + ci];
+    }
+    if (a.want_bias && tid < 16) slice[(size_t)16 * 27 * CIN + tid] = red[NACC + tid];
   }
-  __syncthreads();
-  // slice[((co * 9 + t) * 3 + kd) * cin + ci], bias behind it (the one-launch form's layout)
-  constexpr int CIN = NCI * 16;
-  float* const slice = a.part + (size_t)blockIdx.x * a.part_stride;
-  for (int e = tid; e < 16 * 27 * CIN; e += 256) {
-    const int ci = e % CIN, kd = (e / CIN) % 3, t = (e / (CIN * 3)) % 9, co = e / (CIN * 27);
-    slice[e] = red[(((kd * 9 + t) * NCI + (ci >> 4)) * 16 + co) * 16 + (ci & 15)];
-  }
-  if (a.want_bias && tid < 16) slice[(size_t)16 * 27 * CIN + tid] = red[NACC + tid];
 }
 
 template <typename T, int NCI, int MAXW>
 static int launch_conv_wgrad_rows3d(const WgRowsArgs& a, int items, hipStream_t st) {
   size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)12 * a.ws * 32;
-  const size_t red = (size_t)(27 * NCI * 256 + 16) * sizeof(float);
+  const size_t red = NCI > 1 ? 0 : (size_t)(27 * 256 + 16) * sizeof(float);
   if (lds < red) lds = red;
   static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows3d_kernel<T, NCI, MAXW>));
   if (lds > 160 * 1024 || (lds > 64 * 1024 && !allowed)) return FI_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)items), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -246,18 +246,22 @@ def flush_wgrad():
     _wgrad_cb_queued = False
     if not _pending_wgrad:
         return
-    rows, nblocks = [], 0
+    rows, nblocks, nblocks3d = [], 0, 0
     for ws, stride, slices, dw, n_dw, db, cout, _keep, cin3 in _pending_wgrad:
         ll = 8 if slices <= 16 else 6 if slices <= 64 else 4      # fewer lanes per row when there are many slices to fold
+        # 3x3x3 layers (cin3 > 0): word 9 < 0 -- the reduce leaves their sums in slice 0 and fi_wgrad_permute3d_multi, one
+        # workgroup per (output channel, 64 input channels), adds them into the parameter layout (include/fedicra_hip.h)
         rows.append([ws.data_ptr(), stride, slices, dw.data_ptr(), n_dw, 0 if db is None else db.data_ptr(), cout,
-                     nblocks, ll, cin3])
+                     nblocks, ll, -cin3, nblocks3d])
         nblocks += -(-stride // (4 << ll))
+        if cin3 > 0:
+            nblocks3d += cout * -(-cin3 // 64)
     dev = _pending_wgrad[0][0].device
     capturing = torch.cuda.is_current_stream_capturing()
     host = _pinned_slot(len(rows), capturing)
     host.copy_(torch.tensor(rows, dtype=torch.int64))
     table = host.to(dev, non_blocking=True)
-    L.wgrad_reduce_multi(table, len(rows), nblocks)
+    L.wgrad_reduce_multi(table, len(rows), nblocks, nblocks3d)
     if capturing:
         # the graph re-reads the host table and the partials on every replay: they live as long as the owning client
         _ctx.graph_tables.append((host, table, [p[:7] for p in _pending_wgrad]))

@@ -52,7 +52,7 @@ extern "C" {
  *   3: round 4 (new entry points: fi_conv2d_stats_xcorr*, fi_bn_act_pool_groups, fi_conv1x1_up2x_fwd, fi_wgrad_tuning / fi_narrow_tuning /
  *      fi_upfuse_tuning, fi_pack_weights3d_multi; fi_wgrad_tuning's argument became a bit mask)
  *   5: round 6 (fi_conv3d_tuning; fi_conv_tuning(7, 8): the LDS-DMA forward form) */
-#define FI_ABI_VERSION 5
+#define FI_ABI_VERSION 6
 int fi_abi_version(void);
 
 /* ---------------------------------------------------------------- convolution ------------
@@ -212,16 +212,22 @@ int fi_conv3d_wgrad_fused_partial(const FiConv* d, int D, const void* x0, const 
 /* Deferred form: only stage 1 (partial sums into `workspace`); *slices / *stride (floats) describe the layout
  * [slices][cout*k*k*cin (+ cout bias sums when want_bias)].  Many layers' stage 2 are then done by ONE launch of
  * fi_wgrad_reduce_multi over a device table (int64[n][FI_WGRAD_ROW]):
- * { partial ptr, stride (multiple of 4), slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout, first_block, log2(lanes), cin3 }
- * (cin3 = 0: dw has the slices' own layout; cin3 > 0: the slices come from fi_conv3d_wgrad_fused_partial -- [cout][9][3][cin3] --
- * and dw is the parameter's [cout][cin3][3][3][3])
+ * { partial ptr, stride (multiple of 4), slices, dw ptr, cout*k*k*cin, dbias ptr or 0, cout, first_block, log2(lanes), cin3,
+ *   first_block of fi_wgrad_permute3d_multi }
+ * (cin3 = 0: dw has the slices' own layout; cin3 != 0: the slices come from fi_conv3d_wgrad_fused_partial -- [cout][9][3][|cin3|] --
+ * and dw is the parameter's [cout][|cin3|][3][3][3].  cin3 > 0: fi_wgrad_reduce_multi permutes as it adds -- 4-byte read-modify-writes
+ * 108 B apart, 202 us per unet_3D iteration; cin3 < 0: it adds the bias gradient but leaves the weight sums in slice 0 of the partials,
+ * and ONE launch of fi_wgrad_permute3d_multi over the same table then adds them into dw through an LDS transpose -- a workgroup per
+ * (output channel, <= 64 input channels), so tensor t owns its workgroups [word 10, word 10 + cout * ceil(|cin3| / 64)) and nblocks is
+ * their total over the rows with cin3 < 0 -- 77 + 12 us)
  * where a workgroup folds 4*lanes consecutive elements (lanes in {16, 64, 256}: few lanes when there are many slices),
  * tensor t owns workgroups [first_block_t, first_block_t + ceil(stride_t / (4*lanes_t))) and nblocks is their total.
  * dw/dbias += fixed-order slice sums. */
-#define FI_WGRAD_ROW 10
+#define FI_WGRAD_ROW 11
 int fi_conv2d_wgrad_partial(const FiConv* d, const void* x0, const void* x1, const void* dy, int want_bias,
                             void* workspace, long workspace_bytes, int* slices, long* stride, void* stream);
 int fi_wgrad_reduce_multi(const long long* table, int ntensors, int nblocks, void* stream);
+int fi_wgrad_permute3d_multi(const long long* table, int ntensors, int nblocks, void* stream);
 /* Measurement / test hook (a bit mask): rows = 0 keeps every filter gradient on the tile kernels, bit 0 lets the thin 3x3 layers on
  * large maps (16 / 32 channels a side, 16-bit storage, W % 32 == 0, a workspace given) take the row-streaming kernel
  * (csrc/wgrad_rows.h), bit 1 the channel-rich 3x3 layers (32 ... 256 channels a side, one side a multiple of 64, 64 <= W, W <= 128

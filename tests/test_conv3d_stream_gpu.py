@@ -71,3 +71,49 @@ def test_streaming_kernel_equals_the_general_form_and_torch(dtype, case):
         s = st_got.sum(1).cpu()
         assert torch.allclose(s[..., 0], out.double().sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
         assert torch.allclose(s[..., 1], (out.double() ** 2).sum((1, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_deferred_3x3x3_reduce_with_the_transposed_add_equals_the_permuting_reduce_and_numpy():
+    """fi_wgrad_reduce_multi over rows whose word 9 is -cin (sums left in slice 0) + fi_wgrad_permute3d_multi, against the same table
+    with word 9 = +cin (the reduce permutes as it adds) -- the same fixed-order sums, one add each: bit-equal -- and against the
+    slices summed in float64 and permuted by numpy.  Ragged channel counts (48: a 64-chunk's tail; 80: two chunks), slice counts
+    either side of the kernel's lane-group thresholds, a 2D row (word 9 = 0) in between."""
+    import numpy as np
+    from fedicra_amd import _lib as L
+    shapes = [(16, 16, 3, True), (16, 48, 40, False), (24, 80, 17, True), (32, 0, 70, True), (256, 128, 2, False)]   # cout, cin3, slices, bias
+    out = {}
+    for sign in (1, -1):
+        rows, keep, nblocks, nblocks3d = [], [], 0, 0
+        for cout, cin3, slices, bias in shapes:
+            n_dw = cout * 27 * cin3 if cin3 else cout * 9 * 32
+            stride = (n_dw + cout + 3) & ~3
+            g = torch.Generator().manual_seed(1000 + cout)
+            part = torch.randn(slices, stride, generator=g).to(DEV)
+            dw = torch.randn(n_dw, generator=g).to(DEV)
+            db = torch.randn(cout, generator=g).to(DEV) if bias else None
+            ll = 8 if slices <= 16 else 6 if slices <= 64 else 4
+            rows.append([part.data_ptr(), stride, slices, dw.data_ptr(), n_dw, db.data_ptr() if bias else 0, cout, nblocks, ll,
+                         sign * cin3, nblocks3d])
+            nblocks += -(-stride // (4 << ll))
+            if cin3 and sign < 0:
+                nblocks3d += cout * -(-cin3 // 64)
+            keep.append((part.clone(), dw.clone(), None if db is None else db.clone(), part, dw, db))
+        assert len(rows[0]) == L.WGRAD_ROW
+        table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+        L.wgrad_reduce_multi(table, len(rows), nblocks, nblocks3d)
+        torch.cuda.synchronize()
+        out[sign] = keep
+    for (cout, cin3, slices, bias), a, b in zip(shapes, out[1], out[-1]):
+        assert torch.equal(a[4], b[4]), (cout, cin3)
+        if bias:
+            assert torch.equal(a[5], b[5])
+        part0, dw0, db0, _, dw, db = b
+        n_dw = dw0.numel()
+        s = part0.double().sum(0).cpu().numpy()
+        w = s[:n_dw]
+        if cin3:
+            w = w.reshape(cout, 9, 3, cin3).transpose(0, 3, 2, 1).reshape(-1)              # [co][t][kd][ci] -> [co][ci][kd][t]
+        np.testing.assert_allclose(dw.cpu().numpy(), dw0.cpu().numpy() + w, rtol=0, atol=2e-5 * max(1, slices) ** 0.5)
+        if bias:
+            np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy() + s[n_dw:n_dw + cout], rtol=0, atol=2e-5 * max(1, slices) ** 0.5)

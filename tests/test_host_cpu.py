@@ -268,6 +268,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
                              ctypes.c_float(1e-8), None, None) == 0                        # empty range: no-op
     assert lib.fi_wgrad_reduce_multi(None, 3, 10, None) == ERR_NULL
     assert lib.fi_wgrad_reduce_multi(p, 0, 0, None) == 0
+    assert lib.fi_wgrad_permute3d_multi(None, 3, 10, None) == ERR_NULL
+    assert lib.fi_wgrad_permute3d_multi(p, 2, 0, None) == 0                                # no 3x3x3 rows: no launch
     # 3D entries: validated before the first depth-slice launch
     taps = (ctypes.c_void_p * 3)(0x1000, 0x1000, 0x1000)
     assert lib.fi_conv3d_fwd(ctypes.byref(ok), 4, None, None, taps, None, p, None, ctypes.c_long(0), None) == ERR_NULL

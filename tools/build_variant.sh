@@ -1,13 +1,11 @@
 #!/bin/bash
-# Build libfedicra_hip.so from the csrc/ of a given commit (or "WORK" = working tree) into variants/<name>.so
+# Variant build of libfedicra_hip.so for kernel A/B runs: the listed units are recompiled with $EXTRA (e.g. -DFI_ROWS3D_PIPE=0), the
+# other objects come from fedicra_amd/csrc/build (run make first).  bash tools/build_variant.sh <name> <unit> [unit ...] -> variants/<name>.so
 set -e
-REV=$1; NAME=$2; ROOT=$(cd "$(dirname "$0")/.." && pwd)
-T=$(mktemp -d /tmp/var_XXXX)
-if [ "$REV" = "WORK" ]; then
-  mkdir -p $T/fedicra_amd && cp -r $ROOT/fedicra_amd/csrc $T/fedicra_amd/ && cp -r $ROOT/include $T/ && rm -rf $T/fedicra_amd/csrc/build
-else
-  git -C $ROOT archive $REV fedicra_amd/csrc include | tar -x -C $T
-fi
-make -C $T/fedicra_amd/csrc -j8 EXTRA="$EXTRA" > $T/build.log 2>&1 || { tail -20 $T/build.log; exit 1; }
-mkdir -p $ROOT/variants && cp $T/fedicra_amd/libfedicra_hip.so $ROOT/variants/$NAME.so && rm -rf $T
-echo built variants/$NAME.so
+NAME=$1; shift; ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/fedicra_amd/csrc; T=$(mktemp -d /tmp/var_XXXX)
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $EXTRA"
+PAT=""
+for u in "$@"; do (cd $C && hipcc $FL -c $u.hip -o $T/$u.o) & PAT="$PAT\|/$u.o"; done; wait
+mkdir -p $ROOT/variants
+hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/variants/$NAME.so $(ls $C/build/*.o | grep -v "${PAT:2}") $T/*.o
+rm -rf $T; echo built variants/$NAME.so
