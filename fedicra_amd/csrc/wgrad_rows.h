@@ -106,9 +106,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 * NCO + 255) / 256;
   const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2 * NCO;
   uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];      // two register stages: a row's loads are issued two steps before its store
+  // Per thread and vector, fixed for the whole run and computed once: the source at row 0 (column and channel folded in, columns outside
+  // the image clamped to a valid address), the row pitch, the place in the LDS plane, a bit for "inside the strip" / "inside the
+  // image".  A row step is then one multiply-add per load and a scalar row test (the per-row address arithmetic was a quarter of a
+  // step of the 3D kernel: tools/rows3d_trace.py).  Lanes outside the image are zeroed when the row is STORED to LDS, two steps after
+  // its loads were issued: a select at the load is a use the compiler places -- with its s_waitcnt vmcnt -- at the end of the same step.
+  const char* xsrc[NXV];
+  unsigned xpitch[NXV], xdst[NXV], dsrc[NDV], ddst[NDV], xin = 0, xcol = 0, din = 0;
+  if constexpr (NARROW != 1) {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCI), px = i / (2 * NCI);
+      const int gx = cs + px - 1, ch = v * 8;
+      const bool in = i < nxv, colok = in && gx >= 0 && gx < W;
+      const bool first = ch < a.c0;
+      xsrc[it] = reinterpret_cast<const char*>(first ? x0 + (size_t)(colok ? gx : 0) * a.c0 + ch : x1 + (size_t)(colok ? gx : 0) * a.c1 + (ch - a.c0));
+      xpitch[it] = (unsigned)((first ? a.c0 : a.c1) * W * (int)sizeof(T));
+      xdst[it] = (unsigned)((v >> 1) * xplane + px * 32 + (v & 1) * 16);
+      xin |= (unsigned)in << it;
+      xcol |= (unsigned)colok << it;
+    }
+  }
+  if constexpr (NARROW != 2) {
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) {
+      const int i = tid + it * 256;
+      const int v = i % (2 * NCO), px = i / (2 * NCO);
+      const bool in = i < ndv;
+      dsrc[it] = (unsigned)(((cs + (in ? px : 0)) * (NCO * 16) + v * 8) * (int)sizeof(T));
+      ddst[it] = (unsigned)((v >> 1) * dplane + px * 32 + (v & 1) * 16);
+      din |= (unsigned)in << it;
+    }
+  }
   auto load_x = [&](uint4 (&xr)[NXV], int rho) {                  // x row rho, columns cs - 1 .. cs + ws
-    const bool rowok = rho >= 0 && rho < H;
     if constexpr (NARROW == 1) {
+      const bool rowok = rho >= 0 && rho < H;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int px = tid + it * 256, gx = cs + px - 1;
@@ -117,61 +150,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
       }
       return;
     }
+    const unsigned rc = (unsigned)min(max(rho, 0), H - 1);
 #pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCI), px = i / (2 * NCI);
-      const int gx = cs + px - 1, ch = v * 8;
-      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
-      const bool first = ch < a.c0;
-      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
-                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
-      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
-    }
+    for (int it = 0; it < NXV; ++it) xr[it] = *reinterpret_cast<const uint4*>(xsrc[it] + (size_t)rc * xpitch[it]);
   };
   auto load_d = [&](uint4 (&dr)[NDV], int r) {                    // dy row r, columns cs .. cs + ws - 1
-    const bool rowok = r >= 0 && r < H;
     if constexpr (NARROW == 2) {
-      const bool ok = rowok && tid < ws;
+      const bool ok = r >= 0 && r < H && tid < ws;
       dr[0] = narrow_px(rnd, (unsigned)(r * W + cs + tid), a.cd, ok);
       return;
     }
+    const char* const base = reinterpret_cast<const char*>(dyg + (size_t)min(max(r, 0), H - 1) * W * (NCO * 16));     // uniform
 #pragma unroll
-    for (int it = 0; it < NDV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCO), px = i / (2 * NCO);
-      const bool ok = rowok && i < ndv;
-      const T* src = dyg + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * (NCO * 16) + v * 8;
-      dr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
-    }
+    for (int it = 0; it < NDV; ++it) dr[it] = *reinterpret_cast<const uint4*>(base + dsrc[it]);
   };
-  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
+  auto store_x = [&](const uint4 (&xr)[NXV], int rho) {           // the registers hold x row rho
+    char* const dst = xs + (rho & 1) * xrow;
     if constexpr (NARROW == 1) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int px = tid + it * 256;
-        if (px < ws + 2) *reinterpret_cast<uint2*>(xs + slot * xrow + px * 32) = make_uint2(xr[it].x, xr[it].y);
+        if (px < ws + 2) *reinterpret_cast<uint2*>(dst + px * 32) = make_uint2(xr[it].x, xr[it].y);
       }
       return;
     }
+    const bool rowok = rho >= 0 && rho < H;
 #pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCI), px = i / (2 * NCI);
-      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
-    }
+    for (int it = 0; it < NXV; ++it)
+      if ((xin >> it) & 1u) *reinterpret_cast<uint4*>(dst + xdst[it]) = fi_vec_select(rowok && ((xcol >> it) & 1u), xr[it]);
   };
-  auto store_d = [&](const uint4 (&dr)[NDV], int slot) {
+  auto store_d = [&](const uint4 (&dr)[NDV], int r) {             // the registers hold dy row r
+    char* const dst = ds + (r & 3) * drow;
     if constexpr (NARROW == 2) {
-      if (tid < ws) *reinterpret_cast<uint2*>(ds + slot * drow + tid * 32) = make_uint2(dr[0].x, dr[0].y);
+      if (tid < ws) *reinterpret_cast<uint2*>(dst + tid * 32) = make_uint2(dr[0].x, dr[0].y);
       return;
     }
+    const bool rowok = r >= 0 && r < H;
 #pragma unroll
-    for (int it = 0; it < NDV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * NCO), px = i / (2 * NCO);
-      if (i < ndv) *reinterpret_cast<uint4*>(ds + slot * drow + (v >> 1) * dplane + px * 32 + (v & 1) * 16) = dr[it];
-    }
+    for (int it = 0; it < NDV; ++it)
+      if ((din >> it) & 1u) *reinterpret_cast<uint4*>(dst + ddst[it]) = fi_vec_select(rowok, dr[it]);
   };
 
   f32x4 acc[3][3][NCO][NCI];
@@ -200,11 +217,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   load_x(xrA, r0);
   load_d(drA, r0 - 1);
   load_d(drB, r0);
-  store_x(xrA, r0 & 1);
-  store_d(drA, (r0 - 1) & 3);
+  store_x(xrA, r0);
+  store_d(drA, r0 - 1);
   load_d(drA, r0 + 1);
-  store_d(drB, r0 & 3);
-  store_d(drA, (r0 + 1) & 3);
+  store_d(drB, r0);
+  store_d(drA, r0 + 1);
   load_x(xrA, r0 + 1);
   load_d(drA, r0 + 2);
   load_x(xrB, r0 + 2);
@@ -213,8 +230,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
 
   const int nks = ws / 32;
   auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[NDV]) __attribute__((always_inline)) {
-    store_x(xr, (rho + 1) & 1);                 // x row rho + 1, dy row rho + 2: slots nobody reads during this step
-    store_d(dr, (rho + 2) & 3);
+    store_x(xr, rho + 1);                       // x row rho + 1, dy row rho + 2: slots nobody reads during this step
+    store_d(dr, rho + 2);
     load_x(xr, rho + 3);                        // back in two steps
     load_d(dr, rho + 4);
     const char* const xb = xs + (rho & 1) * xrow + laneoff;
@@ -246,10 +263,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
     }
     fi_lds_barrier();
   };
-  for (int rho = r0; rho < r1; rho += 2) {
+  // (no conditional step inside the loop: the merge of the two register stages behind it would be copies of registers whose loads are
+  // still in flight -- an early s_waitcnt vmcnt)
+  int rho = r0;
+  for (; rho + 1 < r1; rho += 2) {
     step(rho, xrA, drA);
-    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+    step(rho + 1, xrB, drB);
   }
+  if (rho < r1) step(rho, xrA, drA);
 
   // ---- fold the four waves' sums through LDS (the ring is dead), fixed order: deterministic
   constexpr int NACC = 9 * NCO * NCI * 256;
@@ -646,46 +667,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows64_kernel(WgRowsArgs a) {
   constexpr int NXV = ((MAXW + 2) * 2 * TCI + 255) / 256, NDV = (MAXW * 2 * TCO + 255) / 256;
   const int nxv = (ws + 2) * 2 * TCI, ndv = ws * 2 * TCO;
   uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];
-  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
-    const bool rowok = rho >= 0 && rho < H;
+  // per thread and vector, once for the run: source at row 0, row pitch, LDS offset, in-strip / in-image bits (conv_wgrad_rows_kernel)
+  const char* xsrc[NXV];
+  unsigned xpitch[NXV], xdst[NXV], dsrc[NDV], ddst[NDV], xin = 0, xcol = 0, din = 0;
 #pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * TCI), px = i / (2 * TCI);
-      const int gx = cs + px - 1, ch = cib + v * 8;
-      const bool ok = rowok && i < nxv && gx >= 0 && gx < W;
-      const bool first = ch < a.c0;
-      const T* src = first ? x0 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c0 + ch
-                           : x1 + ((size_t)(ok ? rho : 0) * W + (ok ? gx : 0)) * a.c1 + (ch - a.c0);
-      xr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
-    }
+  for (int it = 0; it < NXV; ++it) {
+    const int i = tid + it * 256;
+    const int v = i % (2 * TCI), px = i / (2 * TCI);
+    const int gx = cs + px - 1, ch = cib + v * 8;
+    const bool in = i < nxv, colok = in && gx >= 0 && gx < W;
+    const bool first = ch < a.c0;
+    xsrc[it] = reinterpret_cast<const char*>(first ? x0 + (size_t)(colok ? gx : 0) * a.c0 + ch : x1 + (size_t)(colok ? gx : 0) * a.c1 + (ch - a.c0));
+    xpitch[it] = (unsigned)((first ? a.c0 : a.c1) * W * (int)sizeof(T));
+    xdst[it] = (unsigned)((v >> 1) * xplane + px * 32 + (v & 1) * 16);
+    xin |= (unsigned)in << it;
+    xcol |= (unsigned)colok << it;
+  }
+#pragma unroll
+  for (int it = 0; it < NDV; ++it) {
+    const int i = tid + it * 256;
+    const int v = i % (2 * TCO), px = i / (2 * TCO);
+    const bool in = i < ndv;
+    dsrc[it] = (unsigned)(((cs + (in ? px : 0)) * cout + v * 8) * (int)sizeof(T));
+    ddst[it] = (unsigned)((v >> 1) * dplane + px * 32 + (v & 1) * 16);
+    din |= (unsigned)in << it;
+  }
+  auto load_x = [&](uint4 (&xr)[NXV], int rho) {
+    const unsigned rc = (unsigned)min(max(rho, 0), H - 1);
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) xr[it] = *reinterpret_cast<const uint4*>(xsrc[it] + (size_t)rc * xpitch[it]);
   };
   auto load_d = [&](uint4 (&dr)[NDV], int r) {
+    const char* const base = reinterpret_cast<const char*>(dyg + (size_t)min(max(r, 0), H - 1) * W * cout);     // uniform
+#pragma unroll
+    for (int it = 0; it < NDV; ++it) dr[it] = *reinterpret_cast<const uint4*>(base + dsrc[it]);
+  };
+  auto store_x = [&](const uint4 (&xr)[NXV], int rho) {           // the registers hold x row rho; lanes outside the image are zeroed here
+    char* const dst = xs + (rho & 1) * xrow;
+    const bool rowok = rho >= 0 && rho < H;
+#pragma unroll
+    for (int it = 0; it < NXV; ++it)
+      if ((xin >> it) & 1u) *reinterpret_cast<uint4*>(dst + xdst[it]) = fi_vec_select(rowok && ((xcol >> it) & 1u), xr[it]);
+  };
+  auto store_d = [&](const uint4 (&dr)[NDV], int r) {
+    char* const dst = ds + (r & 3) * drow;
     const bool rowok = r >= 0 && r < H;
 #pragma unroll
-    for (int it = 0; it < NDV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * TCO), px = i / (2 * TCO);
-      const bool ok = rowok && i < ndv;
-      const T* src = dyg + ((size_t)(ok ? r : 0) * W + cs + (ok ? px : 0)) * cout + v * 8;
-      dr[it] = fi_vec_select(ok, *reinterpret_cast<const uint4*>(src));
-    }
-  };
-  auto store_x = [&](const uint4 (&xr)[NXV], int slot) {
-#pragma unroll
-    for (int it = 0; it < NXV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * TCI), px = i / (2 * TCI);
-      if (i < nxv) *reinterpret_cast<uint4*>(xs + slot * xrow + (v >> 1) * xplane + px * 32 + (v & 1) * 16) = xr[it];
-    }
-  };
-  auto store_d = [&](const uint4 (&dr)[NDV], int slot) {
-#pragma unroll
-    for (int it = 0; it < NDV; ++it) {
-      const int i = tid + it * 256;
-      const int v = i % (2 * TCO), px = i / (2 * TCO);
-      if (i < ndv) *reinterpret_cast<uint4*>(ds + slot * drow + (v >> 1) * dplane + px * 32 + (v & 1) * 16) = dr[it];
-    }
+    for (int it = 0; it < NDV; ++it)
+      if ((din >> it) & 1u) *reinterpret_cast<uint4*>(dst + ddst[it]) = fi_vec_select(rowok, dr[it]);
   };
 
   f32x4 acc[3][3][OB][IB];
@@ -709,11 +738,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows64_kernel(WgRowsArgs a) {
   load_x(xrA, r0);
   load_d(drA, r0 - 1);
   load_d(drB, r0);
-  store_x(xrA, r0 & 1);
-  store_d(drA, (r0 - 1) & 3);
+  store_x(xrA, r0);
+  store_d(drA, r0 - 1);
   load_d(drA, r0 + 1);
-  store_d(drB, r0 & 3);
-  store_d(drA, (r0 + 1) & 3);
+  store_d(drB, r0);
+  store_d(drA, r0 + 1);
   load_x(xrA, r0 + 1);
   load_d(drA, r0 + 2);
   load_x(xrB, r0 + 2);
@@ -722,8 +751,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows64_kernel(WgRowsArgs a) {
 
   const int nks = ws / 32;
   auto step = [&](int rho, uint4 (&xr)[NXV], uint4 (&dr)[NDV]) __attribute__((always_inline)) {
-    store_x(xr, (rho + 1) & 1);
-    store_d(dr, (rho + 2) & 3);
+    store_x(xr, rho + 1);
+    store_d(dr, rho + 2);
     load_x(xr, rho + 3);
     load_d(dr, rho + 4);
     const char* const xb = xs + (rho & 1) * xrow + wi * IB * xplane + laneoff;
@@ -755,10 +784,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows64_kernel(WgRowsArgs a) {
     }
     fi_lds_barrier();
   };
-  for (int rho = r0; rho < r1; rho += 2) {
+  int rho = r0;                                 // (no conditional step inside the loop: conv_wgrad_rows_kernel)
+  for (; rho + 1 < r1; rho += 2) {
     step(rho, xrA, drA);
-    if (rho + 1 < r1) step(rho + 1, xrB, drB);
+    step(rho + 1, xrB, drB);
   }
+  if (rho < r1) step(rho, xrA, drA);
 
   // ---- this wave's blocks of the item's slice: slice[(co * 9 + t) * cin + ci], D[row = co = g * 4 + r][col = ci = li]
   float* const slice = a.part + (size_t)slice_idx * a.part_stride;
