@@ -12,8 +12,8 @@ int fi_conv_wgrad_bf16_k1(int th, int nfo, int nfi, const WgradArgs& a, hipStrea
 int fi_conv_wgrad_bf16_k3(int th, int nfo, int nfi, const WgradArgs& a, hipStream_t st);
 int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
-int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
-int fi_conv_wgrad_rows3d_f16(int nci, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows3d_bf16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
+int fi_conv_wgrad_rows3d_f16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows_narrow_bf16(int narrow, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows64_bf16(int tco, int tci, const WgRowsArgs& a, int items, hipStream_t st);
 int fi_conv_wgrad_rows64_f16(int tco, int tci, const WgRowsArgs& a, int items, hipStream_t st);
@@ -585,20 +585,27 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     p->chunks = fi_cdiv(d->H, p->rpw);
     p->sb_rows = d->N * p->strips * p->chunks;
   }
-  // ... and the thin 3x3x3 layers (conv_wgrad_rows3d_kernel): Cout = 16, c0 + c1 = 16 / 32 / 48, slices up to 128 wide
+  // ... and the 3x3x3 layers on slices >= 32 wide (conv_wgrad_rows3d_kernel): Cout = 16 with c0 + c1 = 16 / 32 / 48 on slices up to 128
+  // wide (one tile of 1 x 1 ... 3 blocks), or Cout a multiple of 32 with c0 + c1 = 16 or a multiple of 32 on slices up to 64 wide
+  // (tiles of 2 gradient x 1 / 2 input blocks; bit 1 of the switch)
   const int cr = d->c0 + d->c1;
-  if (wgrad_rows_on() && depth > 0 && d->dtype != FI_F32 && d->ksize == 3 && cout == 16 && (cr == 16 || cr == 32 || cr == 48) &&
-      d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->W % 32 == 0 && d->W <= 128 && d->H >= 8 && d->N % depth == 0 &&
-      (long)d->N * d->H * d->W >= (1L << 17)) {
+  const bool thin3 = cout == 16 && (cr == 16 || cr == 32 || cr == 48) && d->W <= 128 && (long)d->N * d->H * d->W >= (1L << 17);
+  const bool wide3 = wgrad_rows64_on() && cout % 32 == 0 && (cr == 16 || cr % 32 == 0) && d->W <= 64 && (long)d->N * d->H * d->W >= (1L << 16);
+  if (wgrad_rows_on() && depth > 0 && d->dtype != FI_F32 && d->ksize == 3 && (thin3 || wide3) &&
+      d->c0 % 16 == 0 && d->c1 % 16 == 0 && d->W % 32 == 0 && d->H >= 8 && d->N % depth == 0) {
     p->rows = 2;
     p->ws = d->W;
     p->strips = 1;
+    p->tco = thin3 ? 1 : 2;                                   // blocks of a workgroup's tile
+    p->tci = thin3 ? cr / 16 : (cr == 16 ? 1 : 2);
+    p->nct = cout / (p->tco * 16);
+    p->nit = cr / (p->tci * 16);
     static const long items3 = env_long("FI_WGRAD_ROWS3D_ITEMS", 512);          // ~2 workgroups per CU (56 ... 73 KB of LDS)
-    long rpw = ((long)d->N * d->H + items3 - 1) / items3;
+    long rpw = ((long)d->N * d->H * p->nct * p->nit + items3 - 1) / items3;
     if (rpw < 16) rpw = 16;
     if (rpw > d->H) rpw = d->H;
-    p->rpw = (int)rpw;
-    p->chunks = fi_cdiv(d->H, p->rpw);
+    p->chunks = fi_cdiv(d->H, (int)rpw);
+    p->rpw = fi_cdiv(d->H, p->chunks);                        // even runs
     p->sb_rows = d->N * p->chunks;
   }
   return 0;
@@ -788,19 +795,12 @@ static int wgrad_impl(const FiConv* d, const void* x0, const void* x1, const voi
 #ifdef FI_TRACE
     ra.trace = g_trace;
 #endif
-    if (p.rows == 2) {
-      static const long xcd3 = env_long("FI_WGRAD_ROWS3D_XCD", 1);
-      ra.nct = (int)xcd3;                                       // conv_wgrad_rows3d_kernel: XCD-contiguous item order
-      static const long dbg3 = env_long("FI_WGRAD_ROWS3D_DBG", 0);
-      ra.nit = (int)dbg3;
-    }
     if (p.rows == 3)
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows64_f16(p.tco, p.tci, ra, p.sb, st) : fi_conv_wgrad_rows64_bf16(p.tco, p.tci, ra, p.sb, st);
     else if (p.rows == 1 && p.narrow)
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_narrow_f16(p.narrow, ra, p.sb, st) : fi_conv_wgrad_rows_narrow_bf16(p.narrow, ra, p.sb, st);
     else if (p.rows == 2)
-      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows3d_f16((d->c0 + d->c1) / 16, ra, p.sb, st)
-                             : fi_conv_wgrad_rows3d_bf16((d->c0 + d->c1) / 16, ra, p.sb, st);
+      r = d->dtype == FI_F16 ? fi_conv_wgrad_rows3d_f16(p.tci, p.tco, ra, p.sb, st) : fi_conv_wgrad_rows3d_bf16(p.tci, p.tco, ra, p.sb, st);
     else
       r = d->dtype == FI_F16 ? fi_conv_wgrad_rows_f16(cin / 16, cout / 16, ra, p.sb, st)
                              : fi_conv_wgrad_rows_bf16(cin / 16, cout / 16, ra, p.sb, st);

@@ -329,29 +329,40 @@ static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st
 
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The same for the 3x3x3 filter gradient of the thin 3D layers (unet_3D at 128^3: 16 -> 16, 48 -> 16; /root/reference/code/
-// networks/utils.py:99-123), layout of the one-launch form: dw [16][9][3][c0 + c1], the depth taps as channel groups.  An item
-// is a run of x rows of ONE slice sigma; x row (sigma, rho) meets the NINE gradient rows (sigma - kd + 1, rho - kr + 1): per K step
-// 3 x operands and 9 dy operands feed 27 MFMAs per 16-channel block.  The dy ring holds 4 rows of each of the three slices (every
-// dy row is loaded by the items of three slices: 2x the ideal traffic at 16 -> 16, against a tile kernel at 0.09 of the
-// roofline).  Cout = 16.  NCI = 1: the four waves split the K steps; NCI = 2, 3: wave w < NCI owns input block w (27
-// accumulators of 4 registers each either way), the blocks of a wave's run need no cross-wave sum.
-template <typename T, int NCI, int MAXW>
+// The same for the 3x3x3 filter gradient of the 3D layers whose slices are >= 32 wide (unet_3D at 128^3: 16 -> 16, 48 -> 16; at
+// 64^3: 16 -> 32, 32 -> 32, 96 -> 32; at 32^3: 32 / 64 / 192 -> 64; /root/reference/code/networks/utils.py:99-123), layout of the
+// one-launch form: dw [cout][9][3][c0 + c1], the depth taps as channel groups.  An item is a run of x rows of ONE slice sigma; x
+// row (sigma, rho) meets the NINE gradient rows (sigma - kd + 1, rho - kr + 1): per K step 3 x operands and 9 dy operands feed 27
+// MFMAs per pair of 16-channel blocks (one gradient block x one input block: 27 accumulators of 4 registers, all a wave can hold).
+// The dy ring holds 4 rows of each of the three slices (every dy row is loaded by the items of three slices: they sit on one XCD).
+// A workgroup owns a tile of NCO gradient x NCI input blocks of its item (a.nct x a.nit tiles per item, next to each other in the
+// launch order); its P = NCO * NCI pairs go to the waves: P = 1: the four waves split the K steps, P = 2: two waves a pair, P = 3, 4:
+// a wave a pair (no cross-wave sum: the accumulators go straight to the item's partial slice).
+template <typename T, int NCI, int NCO, int MAXW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a) {
   typedef typename DT<T>::frag_t frag_t;
+  constexpr int P = NCI * NCO;
+  static_assert(P >= 1 && P <= 4, "pairs of 16-channel blocks per workgroup");
+  constexpr int KSPLIT = P == 1 ? 4 : (P == 2 ? 2 : 1);          // waves sharing a pair (they split the K steps of a row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = a.H, W = a.W, ws = a.ws, D = a.depth;
   const int xplane = (ws + 2) * 32, dplane = ws * 32;
-  const int xrow = NCI * xplane;
+  const int xrow = NCI * xplane, drow = NCO * dplane;
   char* const xs = smem;                        // [2][NCI][ws + 2][16]
-  char* const ds = smem + 2 * xrow;             // [3 kd][4][ws][16]
-  // workgroup -> item: an XCD (blockIdx % 8) takes a contiguous run of slices, so the dy rows the items of the slices
-  // sigma - 1, sigma, sigma + 1 all load come out of that XCD's L2 once instead of from three XCDs' worth of fabric traffic
-  const int total = a.N * a.strips * a.chunks, per_xcd = (total + 7) >> 3;
-  int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (item >= total) return;
+  char* const ds = smem + 2 * xrow;             // [3 kd][4][NCO][ws][16]
+  // workgroup -> (item, tile): an XCD (blockIdx % 8) takes a contiguous run of the logical order, so the dy rows the items of the slices
+  // sigma - 1, sigma, sigma + 1 (and the tiles of an item) all load come out of that XCD's L2 once
+  const int ntiles = a.nct * a.nit;
+  const int total = a.N * a.strips * a.chunks * ntiles, per_xcd = (total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= total) return;
+  const int tile = logical % ntiles;
+  int item = logical / ntiles;
   const int slice_idx = item;
+  const int cit = tile % a.nit, cot = tile / a.nit;
+  const int cib = cit * NCI * 16, cob = cot * NCO * 16;
+  const int cin = a.c0 + a.c1, cout = a.cout;
   const int chunk = item % a.chunks;
   item /= a.chunks;
   const int strip = item % a.strips, n = item / a.strips;        // n: slice index over all volumes
@@ -361,10 +372,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
   const size_t plane = (size_t)H * W;
   const T* const x0 = reinterpret_cast<const T*>(a.x0) + (size_t)n * plane * a.c0;
   const T* const x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * plane * a.c1;
-  const T* const dyv = reinterpret_cast<const T*>(a.dy);
+  const T* const dyv = reinterpret_cast<const T*>(a.dy) + cob;
 
-  constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 + 255) / 256;
-  const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2;
+  constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 * NCO + 255) / 256;
+  const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2 * NCO;
   uint4 xrA[NXV], xrB[NXV], drA[3][NDV], drB[3][NDV];
   // Everything a row's loads and LDS stores need per thread is fixed for the whole run and computed once: the source pointer of each
   // vector at row 0 (column and channel folded in, out-of-range columns clamped to a valid address), its row pitch, its place in the
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
   for (int it = 0; it < NXV; ++it) {
     const int i = tid + it * 256;
     const int v = i % (2 * NCI), px = i / (2 * NCI);
-    const int gx = cs + px - 1, ch = v * 8;
+    const int gx = cs + px - 1, ch = cib + v * 8;
     const bool in = i < nxv, colok = in && gx >= 0 && gx < W;
     const bool first = ch < a.c0;
     xsrc[it] = reinterpret_cast<const char*>(first ? x0 + (size_t)(colok ? gx : 0) * a.c0 + ch : x1 + (size_t)(colok ? gx : 0) * a.c1 + (ch - a.c0));
@@ -390,9 +401,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
 #pragma unroll
   for (int it = 0; it < NDV; ++it) {
     const int i = tid + it * 256;
+    const int v = i % (2 * NCO), px = i / (2 * NCO);
     const bool in = i < ndv;
-    dsrc[it] = (unsigned)(((cs + (in ? i >> 1 : 0)) * 16 + (i & 1) * 8) * (int)sizeof(T));
-    ddst[it] = (unsigned)((i >> 1) * 32 + (i & 1) * 16);
+    dsrc[it] = (unsigned)(((cs + (in ? px : 0)) * cout + v * 8) * (int)sizeof(T));
+    ddst[it] = (unsigned)((v >> 1) * dplane + px * 32 + (v & 1) * 16);
     din |= (unsigned)in << it;
   }
   auto load_x = [&](uint4 (&xr)[NXV], int rho) {
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
 #pragma unroll
     for (int it = 0; it < NXV; ++it) xr[it] = *reinterpret_cast<const uint4*>(xsrc[it] + (size_t)rc * xpitch[it]);
   };
-  // The zeroing of out-of-range lanes happens when a row is STORED to LDS, a step or two after its loads were issued: a select right
+  // The zeroing of out-of-range lanes happens when a row is STORED to LDS, two steps after its loads were issued: a select right
   // at the load is a use of the loaded registers that the compiler places (with its s_waitcnt vmcnt) at the end of the same step.
   auto load_d = [&](uint4 (&dr)[3][NDV], int r) {           // dy rows r of the slices sigma + 1, sigma, sigma - 1 (kd = 0, 1, 2)
     const int rc = min(max(r, 0), H - 1);
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
     for (int kd = 0; kd < 3; ++kd) {
       const int sd = sigma - kd + 1;
       const bool sok = sd >= 0 && sd < D;
-      const char* const base = reinterpret_cast<const char*>(dyv + ((size_t)(sok ? n - kd + 1 : n) * plane + (size_t)rc * W) * 16);   // uniform
+      const char* const base = reinterpret_cast<const char*>(dyv + ((size_t)(sok ? n - kd + 1 : n) * plane + (size_t)rc * W) * cout);   // uniform
 #pragma unroll
       for (int it = 0; it < NDV; ++it) dr[kd][it] = *reinterpret_cast<const uint4*>(base + dsrc[it]);
     }
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
     for (int kd = 0; kd < 3; ++kd) {
       const int sd = sigma - kd + 1;
       const bool ok = rowok && sd >= 0 && sd < D;
-      char* const dst = ds + (kd * 4 + (r & 3)) * dplane;
+      char* const dst = ds + (kd * 4 + (r & 3)) * drow;
 #pragma unroll
       for (int it = 0; it < NDV; ++it)
         if ((din >> it) & 1u) *reinterpret_cast<uint4*>(dst + ddst[it]) = fi_vec_select(ok, dr[kd][it]);
@@ -444,17 +456,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
   const frag_t onesv = WgFrag<T>::ones();
   const int g = lane >> 4, li = lane & 15;
   const int laneoff = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
-  constexpr bool CISPLIT = NCI > 1;
-  const int blk = CISPLIT ? wave : 0;            // this wave's input block
-  const bool active = !CISPLIT || wave < NCI;
-  const int ks0 = CISPLIT ? 0 : wave, ksstep = CISPLIT ? 1 : 4;
+  const int pair = KSPLIT == 4 ? 0 : (KSPLIT == 2 ? (wave & 1) : wave);      // this wave's (gradient block, input block)
+  const bool active = pair < P;
+  const int ob = active ? pair / NCI : 0, ib = active ? pair % NCI : 0;
+  const int ks0 = KSPLIT == 4 ? wave : (KSPLIT == 2 ? (wave >> 1) : 0), ksstep = KSPLIT;
   // the bias sum rides along as a 28th MFMA against ones (zeros where it is not wanted: no branch inside the MFMA block)
   union {
     frag_t v;
     uint4 u;
   } bias_u;
   bias_u.v = onesv;
-  if (!(a.want_bias && blk == 0)) bias_u.u = make_uint4(0u, 0u, 0u, 0u);
+  const bool bias_wave = a.want_bias && cit == 0 && ib == 0 && active;
+  if (!bias_wave) bias_u.u = make_uint4(0u, 0u, 0u, 0u);
   const frag_t bias_b = bias_u.v;
 
   load_x(xrA, r0);
@@ -483,20 +496,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
     if (active) {
       // A K step is three groups of 9 MFMAs (one depth tap each: 3 gradient fragments x the 3 column-shifted input fragments).  The
       // reads of group j + 1 are issued as one block BEFORE the MFMAs of group j, the scheduler fenced between the blocks: left to
-      // itself the compiler reads each gradient fragment right before its three MFMAs -- nine exposed LDS latencies per step, 2.7x
-      // the MFMA time at one or two waves per SIMD.  Two sets of 3 + 3 fragments: the same 48 registers (a whole step ahead would be
-      // 96 and cost the second workgroup of a CU).
-      const char* const xb = xs + (rho & 1) * xrow + blk * xplane + laneoff;
+      // itself the compiler reads each gradient fragment right before its three MFMAs -- nine exposed LDS latencies per step.
+      // Two sets of 3 + 3 fragments: the same 48 registers (a whole step ahead would be 96 and cost the second workgroup of a CU).
+      const char* const xb = xs + (rho & 1) * xrow + ib * xplane + laneoff;
       const char* dbk[3];
 #pragma unroll
-      for (int kr = 0; kr < 3; ++kr) dbk[kr] = ds + ((rho - kr + 1) & 3) * dplane + laneoff;
+      for (int kr = 0; kr < 3; ++kr) dbk[kr] = ds + ((rho - kr + 1) & 3) * drow + ob * dplane + laneoff;
       auto rd_b = [&](frag_t (&bv)[3], int ks) __attribute__((always_inline)) {
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc) bv[kc] = wgr_frag<T>(xb + (ks * 32 + kc) * 32);
       };
       auto rd_a = [&](frag_t (&av)[3], int ks, int kd) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kr = 0; kr < 3; ++kr) av[kr] = wgr_frag<T>(dbk[kr] + kd * 4 * dplane + ks * 32 * 32);
+        for (int kr = 0; kr < 3; ++kr) av[kr] = wgr_frag<T>(dbk[kr] + kd * 4 * drow + ks * 32 * 32);
       };
       auto mm = [&](const frag_t (&av)[3], const frag_t (&bv)[3], auto kdc) __attribute__((always_inline)) {
         constexpr int kd = decltype(kdc)::value;
@@ -549,33 +561,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
   if (rho < r1) step(rho, xrA, drA);
 
   // slice[((co * 9 + t) * 3 + kd) * cin + ci], bias behind it (the one-launch form's layout); D[row = co = g * 4 + r][col = ci = li]
-  constexpr int CIN = NCI * 16;
   float* const slice = a.part + (size_t)slice_idx * a.part_stride;
-  if constexpr (CISPLIT) {
-    // block-owning waves: no cross-wave sum, so the accumulators go straight to the slice -- a reduction buffer of 27 x NCI x 1 KB
-    // (83 KB at 48 -> 16) would be the workgroup's LDS footprint and leave ONE workgroup per CU where the row ring allows two
-    if (active) {
-#pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kr = 0; kr < 3; ++kr)
-#pragma unroll
-          for (int kc = 0; kc < 3; ++kc)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              slice[(((size_t)(g * 4 + r) * 9 + kr * 3 + kc) * 3 + kd) * CIN + blk * 16 + li] = acc[kd][kr][kc][r];
-      if (a.want_bias && blk == 0 && li == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slice[(size_t)16 * 27 * CIN + g * 4 + r] = accb[r];
-      }
-    }
-  } else {
-    // ---- red[kd * 9 + t][co 16][ci 16]: the K-split waves take turns adding
+  if constexpr (KSPLIT > 1) {
+    // ---- red[pair][kd * 9 + t][co 16][ci 16]: the waves of a pair take turns adding (fixed order: deterministic); the ring is dead
     constexpr int NACC = 27 * 256;
-    float* const red = reinterpret_cast<float*>(smem);
-    for (int w = 0; w < 4; ++w) {
+    float* const red = reinterpret_cast<float*>(smem) + (size_t)pair * (NACC + 16);
+    for (int w = 0; w < KSPLIT; ++w) {
       __syncthreads();
-      if (wave == w) {
+      if (ks0 == w) {
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -597,22 +590,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows3d_kernel(WgRowsArgs a)
       }
     }
     __syncthreads();
-    for (int e = tid; e < 16 * 27 * CIN; e += 256) {
-      const int ci = e % CIN, kd = (e / CIN) % 3, t = (e / (CIN * 3)) % 9, co = e / (CIN * 27);
-      slice[e] = red[((kd * 9 + t) * 16 + co) * 16 + ci];
+    const float* const redall = reinterpret_cast<const float*>(smem);
+    for (int e = tid; e < P * 16 * 27 * 16; e += 256) {
+      const int c = e & 15, kd = (e >> 4) % 3, t = (e / 48) % 9, co = (e / 432) & 15, pr = e / 6912;
+      const int o = pr / NCI, i = pr % NCI;
+      slice[(((size_t)(cob + o * 16 + co) * 9 + t) * 3 + kd) * cin + cib + i * 16 + c] = redall[(size_t)pr * (NACC + 16) + ((kd * 9 + t) * 16 + co) * 16 + c];
     }
-    if (a.want_bias && tid < 16) slice[(size_t)16 * 27 * CIN + tid] = red[NACC + tid];
+    if (a.want_bias && cit == 0 && tid < NCO * 16)
+      slice[(size_t)cout * 27 * cin + cob + tid] = redall[(size_t)((tid >> 4) * NCI) * (NACC + 16) + NACC + (tid & 15)];
+  } else {
+    // pair-owning waves: no cross-wave sum, so the accumulators go straight to the slice -- a reduction buffer of 27 x P x 1 KB
+    // (83 KB at 48 -> 16) would be the workgroup's LDS footprint and leave ONE workgroup per CU where the row ring allows two
+    if (active) {
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+          for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              slice[(((size_t)(cob + ob * 16 + g * 4 + r) * 9 + kr * 3 + kc) * 3 + kd) * cin + cib + ib * 16 + li] = acc[kd][kr][kc][r];
+      if (bias_wave && li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slice[(size_t)cout * 27 * cin + cob + ob * 16 + g * 4 + r] = accb[r];
+      }
+    }
   }
 }
 
-template <typename T, int NCI, int MAXW>
+template <typename T, int NCI, int NCO, int MAXW>
 static int launch_conv_wgrad_rows3d(const WgRowsArgs& a, int items, hipStream_t st) {
-  size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)12 * a.ws * 32;
-  const size_t red = NCI > 1 ? 0 : (size_t)(27 * 256 + 16) * sizeof(float);
+  constexpr int P = NCI * NCO;
+  if (a.ws > MAXW) return FI_ERR_UNSUPPORTED;
+  size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)12 * NCO * a.ws * 32;
+  const size_t red = P > 2 ? 0 : (size_t)P * (27 * 256 + 16) * sizeof(float);
   if (lds < red) lds = red;
-  static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows3d_kernel<T, NCI, MAXW>));
+  static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows3d_kernel<T, NCI, NCO, MAXW>));
   if (lds > 160 * 1024 || (lds > 64 * 1024 && !allowed)) return FI_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, MAXW>), dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), lds, st, a);
+  const long total = (long)items * a.nct * a.nit;
+  hipLaunchKernelGGL((conv_wgrad_rows3d_kernel<T, NCI, NCO, MAXW>), dim3((unsigned)(((total + 7) / 8) * 8)), dim3(256), lds, st, a);
   FI_CHECK_LAUNCH();
   return 0;
 }

@@ -9,11 +9,13 @@ int fi_conv_wgrad_rows_bf16(int nci, int nco, const WgRowsArgs& a, int items, hi
   return FI_ERR_UNSUPPORTED;
 }
 
-int fi_conv_wgrad_rows3d_bf16(int nci, const WgRowsArgs& a, int items, hipStream_t st) {
-  if (a.ws > 128) return FI_ERR_UNSUPPORTED;
-  if (nci == 1) return launch_conv_wgrad_rows3d<bf16_t, 1, 128>(a, items, st);
-  if (nci == 2) return launch_conv_wgrad_rows3d<bf16_t, 2, 128>(a, items, st);
-  if (nci == 3) return launch_conv_wgrad_rows3d<bf16_t, 3, 128>(a, items, st);
+// (input blocks, gradient blocks) of a workgroup's tile; slices up to 128 wide for the 16-channel gradients, up to 64 for the 32-channel tiles
+int fi_conv_wgrad_rows3d_bf16(int nci, int nco, const WgRowsArgs& a, int items, hipStream_t st) {
+  if (nco == 1 && nci == 1) return launch_conv_wgrad_rows3d<bf16_t, 1, 1, 128>(a, items, st);
+  if (nco == 1 && nci == 2) return launch_conv_wgrad_rows3d<bf16_t, 2, 1, 128>(a, items, st);
+  if (nco == 1 && nci == 3) return launch_conv_wgrad_rows3d<bf16_t, 3, 1, 128>(a, items, st);
+  if (nco == 2 && nci == 1) return launch_conv_wgrad_rows3d<bf16_t, 1, 2, 64>(a, items, st);
+  if (nco == 2 && nci == 2) return launch_conv_wgrad_rows3d<bf16_t, 2, 2, 64>(a, items, st);
   return FI_ERR_UNSUPPORTED;
 }
 

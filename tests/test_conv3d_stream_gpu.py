@@ -117,3 +117,44 @@ def test_deferred_3x3x3_reduce_with_the_transposed_add_equals_the_permuting_redu
         np.testing.assert_allclose(dw.cpu().numpy(), dw0.cpu().numpy() + w, rtol=0, atol=2e-5 * max(1, slices) ** 0.5)
         if bias:
             np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy() + s[n_dw:n_dw + cout], rtol=0, atol=2e-5 * max(1, slices) ** 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64, 16, 0, 32), (1, 16, 64, 64, 32, 0, 32), (1, 26, 40, 64, 32, 64, 32),
+                                   (2, 32, 32, 32, 32, 0, 64), (2, 32, 32, 32, 64, 128, 64)])
+def test_row_streaming_3d_wgrad_channel_tiles_against_fp64_and_the_tile_kernels(shape, dtype):
+    """conv_wgrad_rows3d_kernel with tiles of 2 gradient x 1 / 2 input blocks (unet_3D's 64^3 and 32^3 levels: 16 / 32 / 96 -> 32,
+    32 / 64 / 192 -> 64) against an fp64 conv3d backward and the one-launch tile kernel it replaces: a pair split over two waves'
+    K steps (16 -> 32), a pair a wave, several input / gradient tiles per item writing one partial slice, two sources with the
+    boundary inside a tile, ragged row runs, 32-wide slices (one K step a row), depth padding at both ends of two volumes."""
+    import torch.nn.functional as F
+    from fedicra_amd import _lib as L
+    N, D, H, W, c0, c1, cout = shape
+    cin = c0 + c1
+    g = torch.Generator().manual_seed(D + H + c1)
+    x0 = torch.randn(N, D, H, W, c0, generator=g).to(dtype).to(DEV)
+    x1 = torch.randn(N, D, H, W, c1, generator=g).to(dtype).to(DEV) if c1 else None
+    dy = (torch.randn(N, D, H, W, cout, generator=g) * 0.1).to(dtype).to(DEV)
+    res = []
+    try:
+        for rows in (3, 0):
+            L.lib().fi_wgrad_tuning(rows)
+            dw = torch.zeros(cout, 9, 3, cin, device=DEV)
+            db = torch.zeros(cout, device=DEV)
+            assert L.conv3d_wgrad_fused(x0, x1, dy, dw, db, ksize=3)
+            res.append((dw.double().cpu(), db.double().cpu()))
+    finally:
+        L.lib().fi_wgrad_tuning(-1)
+    x = x0 if x1 is None else torch.cat([x0, x1], 4)
+    xd = x.double().permute(0, 4, 1, 2, 3)
+    wref = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv3d(xd, wref, None, padding=1).backward(dy.double().permute(0, 4, 1, 2, 3))
+    want = wref.grad.permute(0, 3, 4, 2, 1).reshape(cout, 9, 3, cin).cpu()          # [cout][kh][kw][kd][cin] -> [cout][9][3][cin]
+    scale = want.abs().max().item()
+    e_new = (res[0][0] - want).abs().max().item() / scale
+    e_old = (res[1][0] - want).abs().max().item() / scale
+    assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)
+    assert not torch.equal(res[0][0], res[1][0])               # another summation order: the row-streaming kernel really ran
+    want_b = dy.double().sum((0, 1, 2, 3)).cpu()
+    assert (res[0][1] - want_b).abs().max().item() < 2e-5 * max(1.0, want_b.abs().max().item())
