@@ -536,16 +536,18 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     if (d->c0 <= 4 && cout == 16) p->narrow = 1;
     if (d->c0 == 16 && cout <= 4) p->narrow = 2;
   }
-  const bool thin16 = (cout == 16 || cout == 32) && (cin == 16 || cin == 32) && (cin == 16 || cout == 16) && d->c0 % 16 == 0 && d->c1 % 16 == 0;
+  static const long pair32 = env_long("FI_WGRAD_ROWS_PAIR", 1);     // 32 -> 32: the pair-per-wave form of conv_wgrad_rows_kernel (0: the quadrant tiles)
+  const bool thin16 = (cout == 16 || cout == 32) && (cin == 16 || cin == 32) && (cin == 16 || cout == 16 || pair32) && d->c0 % 16 == 0 && d->c1 % 16 == 0;
   if (wgrad_rows_on() && depth == 0 && d->dtype != FI_F32 && d->ksize == 3 && (thin16 || p->narrow) && d->W % 32 == 0 &&
       (d->W <= 256 || d->W % 256 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 17)) {
     p->rows = 1;
     p->ws = d->W <= 256 ? d->W : 256;
+    if (cin == 32 && cout == 32 && p->ws > 128) p->ws = 128;   // (pair form: 49 KB of LDS, three workgroups per CU)
     p->strips = d->W / p->ws;
     // ~3 workgroups per CU (16 input channels: 49 KB of LDS each), ~1.5 with 32 (66 KB; measured 67 us at 384 items against
     // 78 at 768 on 12 x 512^2 32 -> 16); a run is at least FI_WGRAD_ROWS_MINR rows (two dy halo rows per run)
     static const long items_env = env_long("FI_WGRAD_ROWS_ITEMS", 0), minr = env_long("FI_WGRAD_ROWS_MINR", 16);
-    const long items_target = items_env > 0 ? items_env : ((cin == 16 || p->narrow) ? 768 : 384);
+    const long items_target = items_env > 0 ? items_env : ((cin == 16 || p->narrow || (cin == 32 && cout == 32)) ? 768 : 384);
     long rpw = ((long)d->N * p->strips * d->H + items_target - 1) / items_target;
     if (rpw < minr) rpw = minr;
     if (rpw > d->H) rpw = d->H;

@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
     return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u);
   };
 
+  // PAIR (32 -> 32): a wave owns one (gradient block, input block) pair for every K step of the row -- 9 accumulators instead of 36, no
+  // cross-wave sum, strips of <= 128 columns: three workgroups per CU where the K-split form had one (328 registers, 98 KB)
+  constexpr bool PAIR = NCI == 2 && NCO == 2;
   // ---- staging: vectors of 8 channels.  x row: (ws + 2) pixels x 2 NCI vectors; dy row: ws pixels x 2 NCO vectors
-  constexpr int MAXW = 256;
+  constexpr int MAXW = PAIR ? 128 : 256;
   constexpr int NXV = ((MAXW + 2) * 2 * NCI + 255) / 256, NDV = (MAXW * 2 * NCO + 255) / 256;
   const int nxv = (ws + 2) * 2 * NCI, ndv = ws * 2 * NCO;
   uint4 xrA[NXV], drA[NDV], xrB[NXV], drB[NDV];      // two register stages: a row's loads are issued two steps before its store
@@ -191,18 +194,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
       if ((din >> it) & 1u) *reinterpret_cast<uint4*>(dst + ddst[it]) = fi_vec_select(rowok, dr[it]);
   };
 
-  f32x4 acc[3][3][NCO][NCI];
-  f32x4 accb[NCO];
+  constexpr int AO = PAIR ? 1 : NCO, AI = PAIR ? 1 : NCI;      // blocks a wave accumulates
+  f32x4 acc[3][3][AO][AI];
+  f32x4 accb[AO];
 #pragma unroll
   for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc)
 #pragma unroll
-      for (int o = 0; o < NCO; ++o)
+      for (int o = 0; o < AO; ++o)
 #pragma unroll
-        for (int i = 0; i < NCI; ++i) acc[kr][kc][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < AI; ++i) acc[kr][kc][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int o = 0; o < NCO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int o = 0; o < AO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int po = PAIR ? wave >> 1 : 0, pi = PAIR ? wave & 1 : 0;      // PAIR: this wave's blocks
   const frag_t onesv = WgFrag<T>::ones();
 
   // operand address of a lane: pixel 4 g + (li >> 2) of the K step (+ 16 for the second read), channels 4 (li & 3) .. + 3
@@ -234,32 +239,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
     store_d(dr, rho + 2);
     load_x(xr, rho + 3);                        // back in two steps
     load_d(dr, rho + 4);
-    const char* const xb = xs + (rho & 1) * xrow + laneoff;
+    const char* const xb = xs + (rho & 1) * xrow + pi * xplane + laneoff;
     const char* db[3];
 #pragma unroll
-    for (int kr = 0; kr < 3; ++kr) db[kr] = ds + ((rho - kr + 1) & 3) * drow + laneoff;
-    for (int ks = wave; ks < nks; ks += 4) {
-      frag_t av[3][NCO], bv[3][NCI];
+    for (int kr = 0; kr < 3; ++kr) db[kr] = ds + ((rho - kr + 1) & 3) * drow + po * dplane + laneoff;
+    for (int ks = PAIR ? 0 : wave; ks < nks; ks += PAIR ? 1 : 4) {
+      frag_t av[3][AO], bv[3][AI];
 #pragma unroll
       for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-        for (int o = 0; o < NCO; ++o) av[kr][o] = wgr_frag<T>(db[kr] + o * dplane + ks * 32 * 32);
+        for (int o = 0; o < AO; ++o) av[kr][o] = wgr_frag<T>(db[kr] + o * dplane + ks * 32 * 32);
 #pragma unroll
       for (int kc = 0; kc < 3; ++kc)
 #pragma unroll
-        for (int i = 0; i < NCI; ++i) bv[kc][i] = wgr_frag<T>(xb + i * xplane + (ks * 32 + kc) * 32);
-      if (a.want_bias) {
+        for (int i = 0; i < AI; ++i) bv[kc][i] = wgr_frag<T>(xb + i * xplane + (ks * 32 + kc) * 32);
+      if (a.want_bias && pi == 0) {
 #pragma unroll
-        for (int o = 0; o < NCO; ++o) accb[o] = mfma16(av[1][o], onesv, accb[o]);
+        for (int o = 0; o < AO; ++o) accb[o] = mfma16(av[1][o], onesv, accb[o]);
       }
 #pragma unroll
       for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc)
 #pragma unroll
-          for (int o = 0; o < NCO; ++o)
+          for (int o = 0; o < AO; ++o)
 #pragma unroll
-            for (int i = 0; i < NCI; ++i) acc[kr][kc][o][i] = mfma16(av[kr][o], bv[kc][i], acc[kr][kc][o][i]);
+            for (int i = 0; i < AI; ++i) acc[kr][kc][o][i] = mfma16(av[kr][o], bv[kc][i], acc[kr][kc][o][i]);
     }
     fi_lds_barrier();
   };
@@ -272,6 +277,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
   }
   if (rho < r1) step(rho, xrA, drA);
 
+  if constexpr (PAIR) {
+    // this wave's pair straight to the item's slice: slice[(co * 9 + t) * cin + ci], D[row = co = g * 4 + r][col = ci = li]
+    float* const slice = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          slice[((size_t)(po * 16 + g * 4 + r) * 9 + kr * 3 + kc) * (NCI * 16) + pi * 16 + li] = acc[kr][kc][0][0][r];
+    if (a.want_bias && pi == 0 && li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slice[(size_t)NCO * 16 * 9 * NCI * 16 + po * 16 + g * 4 + r] = accb[0][r];
+    }
+    return;
+  }
   // ---- fold the four waves' sums through LDS (the ring is dead), fixed order: deterministic
   constexpr int NACC = 9 * NCO * NCI * 256;
   float* const red = reinterpret_cast<float*>(smem);       // [tap][o][i][co 16][ci 16], then [NCO * 16] for the bias
@@ -283,9 +304,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc)
 #pragma unroll
-          for (int o = 0; o < NCO; ++o)
+          for (int o = 0; o < AO; ++o)
 #pragma unroll
-            for (int i = 0; i < NCI; ++i)
+            for (int i = 0; i < AI; ++i)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 // D[row = co = g * 4 + r][col = ci = li]
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
               }
       if (li == 0) {
 #pragma unroll
-        for (int o = 0; o < NCO; ++o)
+        for (int o = 0; o < AO; ++o)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* dst = &red[NACC + o * 16 + g * 4 + r];
@@ -317,8 +338,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgRowsArgs a) {
 template <typename T, int NCI, int NCO, int NARROW = 0>
 static int launch_conv_wgrad_rows(const WgRowsArgs& a, int items, hipStream_t st) {
   size_t lds = (size_t)2 * NCI * (a.ws + 2) * 32 + (size_t)4 * NCO * a.ws * 32;
-  const size_t red = (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
+  const size_t red = (NCI == 2 && NCO == 2) ? 0 : (size_t)(9 * NCO * NCI * 256 + NCO * 16) * sizeof(float);
   if (lds < red) lds = red;
+  if (NCI == 2 && NCO == 2 && a.ws > 128) return FI_ERR_UNSUPPORTED;
   // more than 64 KB (NCI = 2 at 256-wide strips: 65 792 B) must be allowed per kernel, like every other big-LDS launcher
   static const bool allowed = fi_allow_big_lds(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<T, NCI, NCO, NARROW>));
   if (lds > 160 * 1024 || (lds > 64 * 1024 && !allowed)) return FI_ERR_UNSUPPORTED;

@@ -300,11 +300,13 @@ def test_row_streaming_channel_rich_wgrad_against_fp64_and_the_tile_kernels(shap
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 256, 256, 16, 0, 16), (1, 512, 512, 16, 16, 16), (3, 250, 512, 32, 0, 16),
-                                   (2, 264, 256, 16, 0, 32), (4, 256, 128, 16, 16, 32), (1, 1024, 256, 16, 0, 16)])
+                                   (2, 264, 256, 16, 0, 32), (4, 256, 128, 16, 16, 32), (1, 1024, 256, 16, 0, 16),
+                                   (2, 256, 256, 32, 0, 32), (6, 200, 128, 16, 16, 32), (12, 136, 96, 32, 0, 32)])
 def test_row_streaming_wgrad_against_fp64_and_the_tile_kernels(shape, dtype):
     """csrc/wgrad_rows.h (the thin 3x3 layers on large maps: whole rows through an LDS ring, x row rho against dy rows rho - 1 ..
     rho + 1) against an fp64 convolution backward of the same rounded operands and against the tile kernels it replaces
     (fi_wgrad_tuning(0)): two strips per row, a second source, 32 output channels, ragged row chunks, one-image launches;
+    32 -> 32 (round 6: a (gradient block, input block) pair per wave, strips of 128 columns, the source boundary inside the tile);
     weight and bias gradients."""
     import torch.nn.functional as F
     from fedicra_amd import _lib as L
