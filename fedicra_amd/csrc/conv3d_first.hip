@@ -1,38 +1,19 @@
 // The FIRST convolution of the 3D U-Net: Conv3d(1 -> 16, 3x3x3, pad 1) on full-resolution volumes
 // (/root/reference/code/networks/unet_3D.py:38 `UnetConv3(in_channels, filters[0])`, networks/utils.py:99-123; BASELINE configs[3]/[4]:
 // 2 x 1 x 128^3).  With ONE input channel the contraction is 27 long: the implicit-GEMM forms pad it to 32 per depth tap and run
-// three read-modify-write passes over the 134 MB output (259 us forward, 229 us filter gradient per 2 x 128^3 batch: 0.07 of
-// their HBM roofline, 6.7 % of a unet_3D iteration).  It is not GEMM-shaped work: 27 multiply-adds per output element against
-// 2 bytes stored -- a vector-ALU stencil that has to stream the output once.  Both directions here:
-//
-//   lane = 4 * vx + q: sixteen consecutive voxels of an x row, four lanes (channel quads q) per voxel -- a wave's store of a row
-//     segment is 512 contiguous bytes (16 voxels x 16 channels x 2 B);
-//   a thread walks DOWN the rows of one slice with the 3 x 3 x 3 neighbourhood of its voxel in registers: a step issues the nine
-//     loads of the row AFTER next (three slices x three columns, range-checked raw buffer loads: out-of-image = 0, no branches,
-//     L1 / L2 hits -- the 8 MB input volume is read 27 x 4 times out of cache) and rotates the four-row window by loop unrolling;
-//   forward:  4 accumulators, 27 x 4 weights in registers, v_pk_fma_f32 pairs; bias, rounding to the storage type, ONE 8-byte
-//     store per voxel and quad; InstanceNorm's per-sample statistics of the values AS STORED in registers over the whole run,
-//     one fp64 atomic per channel and workgroup;
-//   filter gradient: the mirror image, one DEPTH TAP per workgroup -- per step the quad's 4 gradient values x the 9 window values of
-//     its input slice into 36 accumulators; per run ONE partial slice [16][27] (+ the bias gradient) filled by its three workgroups,
-//     summed over the runs by a second, tiny launch in a fixed order (deterministic, like fi_wgrad_reduce_multi's slices).
+// three read-modify-write passes over the 134 MB output (259 us forward, 229 us filter gradient per 2 x 128^3 batch).  Round 5's
+// answer was a vector-ALU stencil that streams the output once (86 / 105 us: 54 packed FMAs per thread and row -- ALU-bound); round 6
+// puts the same sums on the matrix pipe with the taps as the contraction (forward) / the voxels as the contraction (filter
+// gradient), an input halo tile in LDS and fragments assembled from two-byte LDS reads: 42 / 42 us against the 27 us of the 134 MB.
+// Both kernels keep round 5's decomposition (a workgroup = 64 rows x 64 columns of one slice), its statistics and its partial-slice
+// layout, so the second launch of the filter gradient and the host side are unchanged.
 #include "common.h"
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-template <typename T> __device__ __forceinline__ float ld16(const __amdgpu_buffer_rsrc_t& r, unsigned off);
-template <> __device__ __forceinline__ float ld16<bf16_t>(const __amdgpu_buffer_rsrc_t& r, unsigned off) {
-  return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
-}
-template <> __device__ __forceinline__ float ld16<f16_t>(const __amdgpu_buffer_rsrc_t& r, unsigned off) {
-  const unsigned short h = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
-  return (float)__builtin_bit_cast(f16_t, h);
-}
-
-constexpr int FIRST_RY = 64;          // rows of a slice one workgroup walks (a run); 256 threads = 64 columns x 4 channel quads
+constexpr int FIRST_RY = 64;          // rows of a slice one workgroup walks (a run); its four waves take 16 (forward) / 32 (gradient) columns each
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 struct First3dArgs {
@@ -46,11 +27,58 @@ struct First3dArgs {
   int N, D, H, W;
 };
 
-// the window: win[kd][row][kw], row = image row relative to the current one (0: y - 1, 1: y, 2: y + 1), rotated by R
-template <typename T, bool WGRAD>
-__global__ __launch_bounds__(256, 2) void conv3d_first_kernel(First3dArgs a) {
+// The halo tile of the MFMA forms: rows rr = kd * (R + 2) + r of 66 columns, thread -> (rr, c) advancing by 256 elements (3 rows + 58
+// columns).  Loads in batches of 13 before their LDS stores: one load-then-store per iteration serialises 52 L2 round trips (the
+// first build: 49 us of which ~ 25 were this loop).
+template <typename T, int TR, int TP>
+__device__ __forceinline__ void first3d_fill_tile(T* xt, const __amdgpu_buffer_rsrc_t& rx, int tid, int R, int n, int z, int y0, int x0, int D, int H,
+                                                  int W) {
+  constexpr int NIT = (3 * TR * 66 + 255) / 256, BATCH = 13;
+  const int rows = 3 * (R + 2);
+  int rr = tid / 66, c = tid - rr * 66;
+#pragma unroll 1
+  for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+    if (rr >= rows) break;
+    unsigned short v[BATCH];
+    int idx[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int kd = rr >= 2 * (R + 2) ? 2 : (rr >= R + 2 ? 1 : 0), r = rr - kd * (R + 2);
+      const int gz = z + kd - 1, gy = y0 - 1 + r, gx = x0 - 1 + c;
+      const bool in = rr < rows;
+      const bool ok = in && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)((((long)n * D + gz) * H + gy) * W + gx) * 2u : OOB;
+      v[u] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, off, 0, 0);
+      idx[u] = in ? (kd * TR + r) * TP + c : -1;
+      c += 58, rr += 3;
+      if (c >= 66) c -= 66, ++rr;
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (idx[u] >= 0) xt[idx[u]] = __builtin_bit_cast(T, v[u]);
+  }
+}
+
+// ---- the forward on the matrix pipe (round 6).  The stencil above is vector-ALU-bound: 27 x 16 multiply-adds per voxel are 54 packed
+// FMAs per thread and row, 86 us per 2 x 128^3 against the 27 us the 134 MB output needs.  The same sum as ONE 16 x 16 x 32 MFMA per 16
+// voxels: M = the 16 output channels (A = the filter), N = 16 consecutive voxels of a row, K = the 27 taps (32 slots).  The input halo
+// tile (3 slices x 66 rows x 66 columns, 27 KB) is staged once per workgroup; a lane's B fragment is 8 two-byte LDS reads (K slot
+// (g, j): g = lane >> 4 < 3 is the depth tap and j the first eight of its nine (kh, kw); g = 3 holds the three (kh, kw) = (2, 2) taps).
+// The filter stays fp32-EXACT: each weight is split into three 16-bit parts (hi + mid + lo = its 24 bits), three MFMAs against the same B
+// fragment -- the result differs from the fp32 stencil by accumulation order only, so the tests' "one rounding of the storage type"
+// bar holds (two parts do not: 2^-16 of a term is above that bar where the 27 terms cancel).
+template <typename T> struct FragOf;
+template <> struct FragOf<bf16_t> { typedef bf16x8 type; };
+template <> struct FragOf<f16_t> { typedef f16x8 type; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv3d_first_fwd_mfma_kernel(First3dArgs a) {
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int TR = FIRST_RY + 2, TP = 68;                    // tile rows (with halo), row pitch in elements (66 used)
+  __shared__ __attribute__((aligned(16))) T xt[3 * TR * TP];
+  __shared__ float red[4][4][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane & 3, vx = lane >> 2;
+  const int li = lane & 15, g = lane >> 4;
   const int D = a.D, H = a.H, W = a.W;
   const int xblocks = (W + 63) / 64, yruns = (H + FIRST_RY - 1) / FIRST_RY;
   int b = blockIdx.x;
@@ -59,221 +87,212 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(First3dArgs a) {
   const int yr = b % yruns;
   b /= yruns;
   const int z = b % D, n = b / D;
-  const int x = xb * 64 + wave * 16 + vx;
-  const int y0 = yr * FIRST_RY, y1 = min(H, y0 + FIRST_RY);
-  const bool xin = x < W;
-
+  const int y0 = yr * FIRST_RY, y1 = min(H, y0 + FIRST_RY), R = y1 - y0;
+  const int x = xb * 64 + wave * 16 + li;
   const unsigned vol = (unsigned)a.N * (unsigned)D * (unsigned)H * (unsigned)W;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, vol * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, vol * 32u, 0x00020000);
 
-  // per-thread constants: byte offsets of the three slices' rows are formed per step; column validity is per lane
-  // FOUR row slots: a step computes on rows y - 1 .. y + 1 while the nine loads of row y + 2 are in flight (a row's loads have a
-  // whole step -- ~150 vector instructions -- to land).  No condition sits at a load: hipcc turns a wave-uniform one into a BRANCH
-  // around the load with vmcnt(0) inside (the first build of this kernel: 120 us instead of ~50) and a per-lane one into exec-masked
-  // blocks with duplicated loads.  Every out-of-volume case is a PENALTY bit instead: offsets are below 2^31 (host check), so
-  // or-ing 0x80000000 into one puts it beyond the resource's range and the hardware returns zero -- per-thread constants for the
-  // column neighbours, per-slice constants for z, and for the row a sign-bit trick on (yy, H - 1 - yy).
-  const unsigned PEN = 0x80000000u;
-  unsigned xpen[3], zpen[3];
-  xpen[0] = (xin && x - 1 >= 0) ? 0u : PEN;
-  xpen[1] = xin ? 0u : PEN;
-  xpen[2] = (xin && x + 1 < W) ? 0u : PEN;
-  long zrow[3];
-#pragma unroll
-  for (int kd = 0; kd < 3; ++kd) {
-    const int zz = z + kd - 1;
-    zpen[kd] = (unsigned)zz < (unsigned)D ? 0u : PEN;
-    zrow[kd] = ((long)n * D + zz) * H;
-  }
-  float win[3][4][3];
-  auto load_row = [&](int yy, int slot) __attribute__((always_inline)) {
-    const unsigned ypen = ((unsigned)((yy | (H - 1 - yy)) >> 31)) << 31;      // yy < 0 or yy > H - 1: the sign bit, shifted back up
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd) {
-      const unsigned base = (unsigned)((zrow[kd] + yy) * W + x) * 2u;
-      const unsigned pen = ypen | zpen[kd];
-      win[kd][slot][0] = ld16<T>(rx, (base - 2u) | pen | xpen[0]);
-      win[kd][slot][1] = ld16<T>(rx, base | pen | xpen[1]);
-      win[kd][slot][2] = ld16<T>(rx, (base + 2u) | pen | xpen[2]);
-    }
-  };
+  first3d_fill_tile<T, TR, TP>(xt, rx, tid, R, n, z, y0, xb * 64, D, H, W);
 
-  if constexpr (!WGRAD) {
-    // ------------------------------------------------------------------------------------------------ forward
-    f2 w01[27], w23[27];
+  // ---- the filter as two A fragments (hi / lo parts of the fp32 weights) and the lane's eight tap offsets into the tile
+  frag_t whi, wmid, wlo;
+  unsigned off[8];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      w01[t] = f2{a.w[(q * 4 + 0) * 27 + t], a.w[(q * 4 + 1) * 27 + t]};
-      w23[t] = f2{a.w[(q * 4 + 2) * 27 + t], a.w[(q * 4 + 3) * 27 + t]};
+  for (int j = 0; j < 8; ++j) {
+    int kd, kh, kw, t;
+    if (g < 3) {
+      kd = g, kh = j / 3, kw = j % 3, t = g * 9 + j;
+    } else {
+      kd = j < 3 ? j : 0, kh = 2, kw = 2, t = j < 3 ? j * 9 + 8 : -1;
     }
-    f2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
-    if (a.bias) b01 = f2{a.bias[q * 4], a.bias[q * 4 + 1]}, b23 = f2{a.bias[q * 4 + 2], a.bias[q * 4 + 3]};
-    f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
-    load_row(y0 - 1, 0);
-    load_row(y0, 1);
-    load_row(y0 + 1, 2);
-    auto step = [&](int y, auto rot) __attribute__((always_inline)) {
-      constexpr int R = decltype(rot)::value;                  // window slot of row y - 1
-      load_row(y + 2, (R + 3) % 4);                            // one step ahead
-      f2 a01 = b01, a23 = b23;
+    const float wv = t >= 0 ? a.w[li * 27 + t] : 0.f;
+    const T hi = (T)wv, mid = (T)(wv - (float)hi);
+    whi[j] = hi;
+    wmid[j] = mid;
+    wlo[j] = (T)(wv - (float)hi - (float)mid);
+    off[j] = (unsigned)(((kd * TR + kh) * TP + wave * 16 + li + kw) * 2);
+  }
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = f32x4{a.bias[g * 4], a.bias[g * 4 + 1], a.bias[g * 4 + 2], a.bias[g * 4 + 3]};
+  const unsigned xpen = x < W ? 0u : 0x80000000u;
+  const float m = x < W ? 1.f : 0.f;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const char* const tile = reinterpret_cast<const char*>(xt);
+  unsigned yoff = ((unsigned)((((long)n * D + z) * H + y0) * W + x) * 16u + (unsigned)g * 4u) * 2u;
+  for (int r = 0; r < R; ++r) {
+    frag_t bv;
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
+    for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const T*>(tile + off[j] + (unsigned)(r * TP * 2));
+    f32x4 acc = mfma16(wlo, bv, bias4);
+    acc = mfma16(wmid, bv, acc);
+    acc = mfma16(whi, bv, acc);
+    float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    const typename Quad<T>::q_t st = Quad<T>::pack(v4);         // v4 := the values as stored
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, st), ry, yoff | xpen, 0, 0);
+    yoff += (unsigned)W * 32u;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const float v = win[kd][(R + kh) % 4][kw];
-            const int t = (kd * 3 + kh) * 3 + kw;
-            a01 += w01[t] * f2{v, v};
-            a23 += w23[t] * f2{v, v};
-          }
-      float v4[4] = {a01.x, a01.y, a23.x, a23.y};
-      const typename Quad<T>::q_t st = Quad<T>::pack(v4);       // v4 := the values as stored
-      const unsigned off = ((unsigned)((((long)n * D + z) * H + y) * W + x) * 16u + (unsigned)q * 4u) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, st), ry, off | xpen[1], 0, 0);
-      const float m = xin ? 1.f : 0.f;
-      const f2 r01 = f2{v4[0], v4[1]} * f2{m, m}, r23 = f2{v4[2], v4[3]} * f2{m, m};
-      s01 += r01, s23 += r23;
-      q01 += r01 * r01, q23 += r23 * r23;
-    };
-    int y = y0;
-    for (; y + 3 < y1; y += 4) {
-      step(y, std::integral_constant<int, 0>());
-      step(y + 1, std::integral_constant<int, 1>());
-      step(y + 2, std::integral_constant<int, 2>());
-      step(y + 3, std::integral_constant<int, 3>());
+    for (int i = 0; i < 4; ++i) {
+      const float v = v4[i] * m;
+      s4[i] += v;
+      q4[i] += v * v;
     }
-    if (y < y1) step(y, std::integral_constant<int, 0>());
-    if (y + 1 < y1) step(y + 1, std::integral_constant<int, 1>());
-    if (y + 2 < y1) step(y + 2, std::integral_constant<int, 2>());
-    if (a.stats) {
-      // lanes of one quad class are 4 apart: two row rotations sum a 16-lane row's four voxels-per-class ... (x 4 voxels) -- then LDS
-      __shared__ float red[4][4][4][8];                        // [wave][row of 16 lanes][quad][8 values]
-      float vals[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
+  }
+  if (a.stats) {
+    // a row of 16 lanes holds the same four channels (4 g + i) of 16 voxels: four row rotations, then the waves through LDS
+    float vals[8] = {s4[0], s4[1], s4[2], s4[3], q4[0], q4[1], q4[2], q4[3]};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float v = vals[i];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
-        vals[i] = v;
-      }
-      if ((lane & 15) < 4) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) red[wave][lane >> 4][lane & 3][i] = vals[i];
-      }
-      __syncthreads();
-      if (tid < 32) {                                          // channel c = tid >> 1, which = tid & 1 (sum | sum of squares)
-        const int c = tid >> 1, which = tid & 1;
-        double tot = 0.0;
-        for (int wv = 0; wv < 4; ++wv)
-          for (int r = 0; r < 4; ++r) tot += (double)red[wv][r][c >> 2][which * 4 + (c & 3)];
-        const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
-        atomicAdd(&a.stats[(size_t)n * a.stats_stride + ((size_t)slot * 16 + c) * 2 + which], tot);
-      }
+    for (int i = 0; i < 8; ++i) {
+      float v = vals[i];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));   // row_ror:1
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));   // row_ror:2
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+      vals[i] = v;
     }
-  } else {
-    // ------------------------------------------------------------------------------------------------ filter gradient
-    // ONE depth tap per workgroup (blockIdx.y = kd): 9 taps x 4 channels = 36 accumulators per thread instead of 108 -- the whole
-    // 27-tap form needed 379 registers (one wave per SIMD) and ran 289 us against the per-tap GEMMs' 229.  The three workgroups of a
-    // run read the same gradient rows (L2) and one input slice each, and write disjoint thirds of the run's partial slice.
-    const int kd = blockIdx.y;
-    f2 g01[9], g23[9];
+    if (li == 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g01[t] = g23[t] = f2{0.f, 0.f};
-    f2 gb01 = {0.f, 0.f}, gb23 = {0.f, 0.f};
-    const unsigned zp = zpen[0] * (kd == 0) | zpen[1] * (kd == 1) | zpen[2] * (kd == 2);     // (penalties are 0 or 2^31: a select without a branch)
-    const long zr = kd == 0 ? zrow[0] : (kd == 1 ? zrow[1] : zrow[2]);
-    float w3[4][3];
-    auto load_row1 = [&](int yy, int slot) __attribute__((always_inline)) {
-      const unsigned ypen = ((unsigned)((yy | (H - 1 - yy)) >> 31)) << 31;
-      const unsigned base = (unsigned)((zr + yy) * W + x) * 2u;
-      const unsigned pen = ypen | zp;
-      w3[slot][0] = ld16<T>(rx, (base - 2u) | pen | xpen[0]);
-      w3[slot][1] = ld16<T>(rx, base | pen | xpen[1]);
-      w3[slot][2] = ld16<T>(rx, (base + 2u) | pen | xpen[2]);
-    };
-    auto load_dy = [&](int yy) __attribute__((always_inline)) {
-      const unsigned off = ((unsigned)((((long)n * D + z) * H + yy) * W + x) * 16u + (unsigned)q * 4u) * 2u;
-      const unsigned ypen = ((unsigned)((y1 - 1 - yy) >> 31)) << 31;           // the row behind the run: zeros (never accumulated twice)
-      return __builtin_amdgcn_raw_buffer_load_b64(ry, off | ypen | xpen[1], 0, 0);
-    };
-    load_row1(y0 - 1, 0);
-    load_row1(y0, 1);
-    load_row1(y0 + 1, 2);
-    v2u dnext = load_dy(y0);
-    auto step = [&](int y, auto rot) __attribute__((always_inline)) {
-      constexpr int R = decltype(rot)::value;
-      load_row1(y + 2, (R + 3) % 4);                           // one step ahead, like the gradient row below
-      const v2u raw = dnext;
-      dnext = load_dy(y + 1);
-      float d4[4];
-      Quad<T>::unpack(__builtin_bit_cast(typename Quad<T>::q_t, raw), d4);
-      const f2 d01 = {d4[0], d4[1]}, d23 = {d4[2], d4[3]};
-      gb01 += d01, gb23 += d23;
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float v = w3[(R + kh) % 4][kw];
-          g01[kh * 3 + kw] += d01 * f2{v, v};
-          g23[kh * 3 + kw] += d23 * f2{v, v};
-        }
-    };
-    int y = y0;
-    for (; y + 3 < y1; y += 4) {
-      step(y, std::integral_constant<int, 0>());
-      step(y + 1, std::integral_constant<int, 1>());
-      step(y + 2, std::integral_constant<int, 2>());
-      step(y + 3, std::integral_constant<int, 3>());
-    }
-    if (y < y1) step(y, std::integral_constant<int, 0>());
-    if (y + 1 < y1) step(y + 1, std::integral_constant<int, 1>());
-    if (y + 2 < y1) step(y + 2, std::integral_constant<int, 2>());
-    // sum over the 16 voxel columns of a wave (lanes of one quad class: 4 apart within a row of 16 -- two row rotations -- then
-    // the four rows and the four waves through LDS); thread e writes element e of this depth tap's third of the slice
-    __shared__ float red[4][4][4][40];                         // [wave][row][quad][9 taps x 4 channels + 4 bias]
-    auto fold = [&](float v) __attribute__((always_inline)) {
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-      return v;
-    };
-    const bool writer = (lane & 15) < 4;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float v0 = fold(g01[t].x), v1 = fold(g01[t].y), v2 = fold(g23[t].x), v3 = fold(g23[t].y);
-      if (writer) {
-        float* dst = &red[wave][lane >> 4][lane & 3][t * 4];
-        dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
-      }
-    }
-    {
-      const float v0 = fold(gb01.x), v1 = fold(gb01.y), v2 = fold(gb23.x), v3 = fold(gb23.y);
-      if (writer) {
-        float* dst = &red[wave][lane >> 4][lane & 3][36];
-        dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
-      }
+      for (int i = 0; i < 8; ++i) red[wave][g][i] = vals[i];
     }
     __syncthreads();
-    float* const slice = a.part + (size_t)blockIdx.x * (16 * 27 + 16);
-    for (int e = tid; e < 16 * 9 + 16; e += 256) {
-      int c, idx, pos;                                         // channel, index inside the quad's 40-value record, slice position
-      if (e < 16 * 9) {
-        c = e / 9;
-        const int t9 = e - c * 9;
-        idx = t9 * 4 + (c & 3);
-        pos = c * 27 + kd * 9 + t9;
-      } else {
-        if (kd != 1) break;                                    // the bias gradient once per run: by the centre tap's workgroup
-        c = e - 16 * 9;
-        idx = 36 + (c & 3);
-        pos = 16 * 27 + c;
-      }
-      float tot = 0.f;
-      for (int wv = 0; wv < 4; ++wv)
-        for (int r = 0; r < 4; ++r) tot += red[wv][r][c >> 2][idx];
-      slice[pos] = tot;
+    if (tid < 32) {                                            // channel c = tid >> 1, which = tid & 1 (sum | sum of squares)
+      const int c = tid >> 1, which = tid & 1;
+      double tot = 0.0;
+      for (int wv = 0; wv < 4; ++wv) tot += (double)red[wv][c >> 2][which * 4 + (c & 3)];
+      const int slot = blockIdx.x & (FI_STATS_SLOTS - 1);
+      atomicAdd(&a.stats[(size_t)n * a.stats_stride + ((size_t)slot * 16 + c) * 2 + which], tot);
     }
+  }
+}
+
+// ---- the filter gradient on the matrix pipe (round 6): dW[co][tap] = sum over voxels of dy[voxel][co] * x[voxel + tap], a GEMM with
+// M = 16 channels, N = 27 taps (two blocks of 16; slot 27 multiplies ones: the bias gradient), K = voxels, 32 per MFMA.  A wave owns
+// half of the workgroup's 64 columns and every other row of its run: the 1 KB gradient segment of a K block goes global -> registers ->
+// the wave's own LDS plane [voxel][16 ch] and comes back transposed (`ds_read_b64_tr_b16`, the row-streaming kernels' operand read);
+// the B fragment -- 8 voxels of one tap's shifted input row -- is 8 two-byte reads of the halo tile the forward uses.  No workgroup
+// barrier inside the run.  The four waves' 16 x 32 sums are folded through LDS into the workgroup's partial slice; the second launch
+// (conv3d_first_reduce_kernel) is unchanged.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3d_first_wgrad_mfma_kernel(First3dArgs a) {
+  typedef typename FragOf<T>::type frag_t;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  constexpr int TR = FIRST_RY + 2, TP = 68;
+  __shared__ __attribute__((aligned(16))) T xt[3 * TR * TP];
+  __shared__ __attribute__((aligned(16))) char dplane[4][2][1024];      // [wave][buffer][32 voxels x 32 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int D = a.D, H = a.H, W = a.W;
+  const int xblocks = (W + 63) / 64, yruns = (H + FIRST_RY - 1) / FIRST_RY;
+  int b = blockIdx.x;
+  const int xb = b % xblocks;
+  b /= xblocks;
+  const int yr = b % yruns;
+  b /= yruns;
+  const int z = b % D, n = b / D;
+  const int y0 = yr * FIRST_RY, y1 = min(H, y0 + FIRST_RY), R = y1 - y0;
+  const unsigned vol = (unsigned)a.N * (unsigned)D * (unsigned)H * (unsigned)W;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, vol * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, vol * 32u, 0x00020000);
+
+  first3d_fill_tile<T, TR, TP>(xt, rx, tid, R, n, z, y0, xb * 64, D, H, W);
+
+  const int half = wave & 1, rpar = wave >> 1;                  // this wave: columns half * 32 .. + 31, rows rpar, rpar + 2, ...
+  // B fragments: N block 0 = taps li, block 1 = taps 16 + li (27: ones -> the bias gradient; 28 ..: ignored, clamped for the address)
+  unsigned boff[2];
+  int bkw[2];
+  bool ones1;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    int t = blk * 16 + li;
+    if (blk == 1) ones1 = t == 27;
+    t = t > 26 ? 26 : t;
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    boff[blk] = (unsigned)(((kd * TR + kh) * TP + half * 32 + 4 * g) * 2);     // 8-byte aligned: the column shift kw is applied in registers
+    bkw[blk] = kw;
+  }
+  frag_t onesv;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) onesv[j] = (T)1.0f;
+  const int vx = lane >> 1, hh = lane & 1;                       // the gradient segment: lane -> voxel vx, channel half hh (16 B)
+  const int gx = xb * 64 + half * 32 + vx;
+  const unsigned dpen = gx < W ? 0u : 0x80000000u;
+  const unsigned doff = ((unsigned)((((long)n * D + z) * H + y0 + rpar) * W + gx) * 16u + (unsigned)hh * 8u) * 2u;
+  const unsigned dstep = (unsigned)W * 32u * 2u;                // two rows on
+  const int trd = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;      // the transposing read's lane address inside a plane (wgrad_rows.h)
+  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  // four gradient segments in flight per wave (16 waves x 4 KB per CU: one segment ahead left the loads latency-bound at 2 TB/s)
+  v4u q0 = v4u{0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+  auto fetch = [&](int r) __attribute__((always_inline)) {
+    const unsigned o = r < R ? (doff + (unsigned)((r - rpar) >> 1) * dstep) | dpen : OOB;
+    return __builtin_amdgcn_raw_buffer_load_b128(ry, o, 0, 0);
+  };
+  q0 = fetch(rpar), q1 = fetch(rpar + 2), q2 = fetch(rpar + 4), q3 = fetch(rpar + 6);
+  __syncthreads();                                             // the tile is complete
+  char* const myp = &dplane[wave][0][0];
+  const char* const tile = reinterpret_cast<const char*>(xt);
+  auto kblock = [&](int r, v4u& q, int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<v4u*>(myp + buf * 1024 + lane * 16) = q;
+    q = fetch(r + 8);
+    // A: channel li of voxels 4 g .. 4 g + 3 and 16 + 4 g .. + 3 of the segment
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    union {
+      s16x4 h[2];
+      frag_t v;
+    } au;
+    au.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(myp + buf * 1024 + trd));
+    au.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(myp + buf * 1024 + trd + 16 * 32));
+    // B: voxels 4 g + kw .. + 3 and 16 + 4 g + kw .. + 3 of the tap's row.  Read as ALIGNED 16-byte windows and shifted by kw elements in
+    // registers: 8-byte LDS reads at 2 or 4 (mod 8) work but cost ~10 x (measured: 80 us against 41 with every kw forced to 0)
+    auto shifted = [&](const char* p, int kw) __attribute__((always_inline)) {
+      const uint2 w0 = *reinterpret_cast<const uint2*>(p), w1 = *reinterpret_cast<const uint2*>(p + 8);
+      const uint2 w2 = *reinterpret_cast<const uint2*>(p + 32), w3 = *reinterpret_cast<const uint2*>(p + 40);
+      const bool two = kw == 2;
+      const unsigned sh = kw == 1 ? 2u : 0u;
+      const unsigned a0 = two ? w0.y : w0.x, a1 = two ? w1.x : w0.y, a2 = two ? w1.y : w1.x;
+      const unsigned c0 = two ? w2.y : w2.x, c1 = two ? w3.x : w2.y, c2 = two ? w3.y : w3.x;
+      union {
+        unsigned u[4];
+        frag_t v;
+      } o;
+      o.u[0] = __builtin_amdgcn_alignbyte(a1, a0, sh);
+      o.u[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+      o.u[2] = __builtin_amdgcn_alignbyte(c1, c0, sh);
+      o.u[3] = __builtin_amdgcn_alignbyte(c2, c1, sh);
+      return o.v;
+    };
+    frag_t b0 = shifted(tile + boff[0] + (unsigned)(r * TP * 2), bkw[0]);
+    frag_t b1 = shifted(tile + boff[1] + (unsigned)(r * TP * 2), bkw[1]);
+    if (ones1) b1 = onesv;
+    acc0 = mfma16(au.v, b0, acc0);
+    acc1 = mfma16(au.v, b1, acc1);
+  };
+  int r = rpar;
+  for (; r + 6 < R; r += 8) {
+    kblock(r, q0, 0);
+    kblock(r + 2, q1, 1);
+    kblock(r + 4, q2, 0);
+    kblock(r + 6, q3, 1);
+  }
+  if (r < R) kblock(r, q0, 0);
+  if (r + 2 < R) kblock(r + 2, q1, 1);
+  if (r + 4 < R) kblock(r + 4, q2, 0);
+  // ---- fold the four waves: red[wave][co][32 taps]; D[row = co = 4 g + i][col = tap = li]
+  __syncthreads();                                             // every wave is done with the tile: its space is the buffer
+  float* const red = reinterpret_cast<float*>(xt);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[(wave * 16 + 4 * g + i) * 32 + li] = acc0[i];
+    red[(wave * 16 + 4 * g + i) * 32 + 16 + li] = acc1[i];
+  }
+  __syncthreads();
+  float* const slice = a.part + (size_t)blockIdx.x * (16 * 27 + 16);
+  for (int e = tid; e < 16 * 28; e += 256) {
+    const int c = e / 28, t = e - c * 28;
+    const float tot = red[(0 * 16 + c) * 32 + t] + red[(1 * 16 + c) * 32 + t] + red[(2 * 16 + c) * 32 + t] + red[(3 * 16 + c) * 32 + t];
+    slice[t < 27 ? c * 27 + t : 16 * 27 + c] = tot;
   }
 }
 
@@ -310,9 +329,9 @@ extern "C" int fi_conv3d_first_fwd(int dtype, int N, int D, int H, int W, const 
   First3dArgs a{x, w, bias, y, stats, stats_stride, nullptr, N, D, H, W};
   const dim3 g((unsigned)first3d_blocks(N, D, H, W)), b(256);
   if (dtype == FI_BF16)
-    hipLaunchKernelGGL((conv3d_first_kernel<bf16_t, false>), g, b, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv3d_first_fwd_mfma_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((conv3d_first_kernel<f16_t, false>), g, b, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv3d_first_fwd_mfma_kernel<f16_t>), g, b, 0, (hipStream_t)stream, a);
   FI_CHECK_LAUNCH();
   return 0;
 }
@@ -325,11 +344,10 @@ extern "C" int fi_conv3d_first_wgrad(int dtype, int N, int D, int H, int W, cons
   if (workspace_bytes < fi_conv3d_first_wgrad_workspace(N, D, H, W)) return FI_ERR_SHAPE;
   First3dArgs a{x, nullptr, nullptr, const_cast<void*>(dy), nullptr, 0, (float*)workspace, N, D, H, W};
   const long blocks = first3d_blocks(N, D, H, W);
-  const dim3 g((unsigned)blocks, 3), b(256);                  // y: the depth tap
   if (dtype == FI_BF16)
-    hipLaunchKernelGGL((conv3d_first_kernel<bf16_t, true>), g, b, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv3d_first_wgrad_mfma_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((conv3d_first_kernel<f16_t, true>), g, b, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv3d_first_wgrad_mfma_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(conv3d_first_reduce_kernel, dim3(16 * 27 + 16), dim3(64), 0, (hipStream_t)stream, (const float*)workspace,
                      (int)blocks, dw, dbias);
   FI_CHECK_LAUNCH();
