@@ -406,12 +406,28 @@ static int conv_fwd_impl(const FiConv* d, const FiInXform* t0, const FiInXform* 
                          big * d->c0 < (1L << 32) && big * d->c1 < (1L << 32) && big * d->co0 < (1L << 32) &&
                          big * d->co1 < (1L << 32) && (long)cout * 27 * cr * 2 < (1L << 32);
         if (!ok3) return FI_ERR_UNSUPPORTED;
-        const int n4 = cout > 32 ? 4 : 2;
+        static const long e_nf = env_long("FI_WS3D_NF", 0), e_pw = env_long("FI_WS3D_PW", 0), e_ck = env_long("FI_WS3D_CK", 0),
+                          e_wgs = env_long("FI_WS3D_WGS", 0);      // measurement knobs (tools/c3g_bench.py)
+        // Output slab of a workgroup (16, 32 or 64 channels).  A stage fills a 20.7 KB halo tile and 9.2 KB of filter per 16 outputs
+        // through the same ~20 B/clk path, and at the levels below 64^3 there are fewer (tile, slab) items than CUs: the slab
+        // that minimises (waves of 256 items) x (stage bytes) -- 64 channels at 64^3 / 32^3, 16 at 16^3 and 8^3 (8^3 256 -> 256
+        // 42.5 -> 24.3 us, 16^3 128 -> 128 24.7 -> 16.0; tools/c3g_bench.py, profiles/r06_d_c3g.txt)
+        int n4 = 4;
+        {
+          const long tiles3 = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16);
+          long best = -1;
+          for (int nf = 4; nf >= 1; nf >>= 1) {
+            const long items = tiles3 * fi_cdiv(cout, nf * 16), cost = ((items + 255) / 256) * (207 + 92 * nf);
+            if (best < 0 || cost < best) best = cost, n4 = nf;
+          }
+        }
+        if (e_nf) n4 = (int)e_nf;
         a.depth = depth;
         a.tilesY = fi_cdiv(d->H, 16);
         a.nct = fi_cdiv(cout, n4 * 16);
-        const int pw = cout >= 64 ? 44 : 8;
-        return d->dtype == FI_F16 ? fi_conv_fwd_ws_f16(n4, 32, pw, 0, a, st) : fi_conv_fwd_ws_bf16(n4, 32, pw, 0, a, st);
+        const int pw = e_pw ? (int)e_pw : (n4 == 4 ? 44 : 8);
+        const int ck = e_ck ? (int)e_ck : 32;
+        return d->dtype == FI_F16 ? fi_conv_fwd_ws_f16(n4, ck, pw, (int)e_wgs, a, st) : fi_conv_fwd_ws_bf16(n4, ck, pw, (int)e_wgs, a, st);
       }
       const long items = (long)d->N * fi_cdiv(d->H, 16) * fi_cdiv(d->W, 16) * fi_cdiv(cout, cout > 32 ? 64 : 32);
       const bool ws_auto = v2 == 2 && a.xf == 1 && items >= 1024;

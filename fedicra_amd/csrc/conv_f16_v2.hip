@@ -25,7 +25,7 @@ int fi_conv_thin_f16(int nf, int ck, int wgs_per_cu, const ConvArgs& a, hipStrea
 
 // pw = producer waves per workgroup: 4 or 8 beside 4 consumer waves; 44 = two alternating teams of 4 beside 8 consumer waves
 int fi_conv_fwd_ws_f16(int nf, int ck, int pw, int wgs_per_cu, const ConvArgs& a, hipStream_t st) {
-  WS_CASE(2, 16) WS_CASE(4, 16) WS_CASE(2, 32) WS_CASE(4, 32)
+  WS_CASE(2, 16) WS_CASE(4, 16) WS_CASE(1, 32) WS_CASE(2, 32) WS_CASE(4, 32)
   return FI_ERR_UNSUPPORTED;
 }
 
