@@ -1167,6 +1167,16 @@ static int launch_conv_fwd_v2(const ConvArgs& a, int wgs_per_cu, hipStream_t st)
 //   its epilogue (~750 instructions per tile: bias, rounding, stores, statistics) run under the other's MFMAs instead of
 //   idling the pipe; a team issues stage s+2 in one iteration and transforms / commits it in the next, so its loads need no
 //   wait-count bookkeeping (vmcnt(0) at commit is exact) and the coefficients are fetched at commit.
+#ifdef FI_TRACE
+// per-wave stage timeline of conv_fwd_ws_kernel (tools/ws_trace.py): [workgroup][12 waves][16 stages][8 stamps], stages 4 .. 19 of the run
+#define FI_TWS(slot, stage)                                                                                              \
+  do {                                                                                                                   \
+    if (a.trace && lane == 0 && (stage) >= 4 && (stage) < 20)                                                            \
+      a.trace[((((size_t)blockIdx.x * 12 + wave) * 16) + ((stage) - 4)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define FI_TWS(slot, stage) do { } while (0)
+#endif
 template <typename T, int NF, int CK, int XF, int PW>
 __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_ws_kernel(ConvArgs a) {
   constexpr bool DUO = PW == 44;
@@ -1493,22 +1503,30 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
       fi_lds_barrier();
       for (int s = 0; s < nstage; s += 2) {
         // stage s is being consumed from buffer 0: issue s+2 into set 0, commit s+1 (set 1) into buffer 1
+        FI_TWS(0, s);
         issue(S0, it_i, ch_i * CK, k_i < nstage);
         adv_i();
+        FI_TWS(1, s);
         if (s + 1 < nstage) {
           commit(S1, it_c, 1);
           adv_c();
         }
+        FI_TWS(2, s);
         fi_lds_barrier();
+        FI_TWS(3, s);
         if (s + 1 >= nstage) break;
         // stage s+1 is being consumed from buffer 1: issue s+3 into set 1, commit s+2 (set 0) into buffer 0
+        FI_TWS(0, s + 1);
         issue(S1, it_i, ch_i * CK, k_i < nstage);
         adv_i();
+        FI_TWS(1, s + 1);
         if (s + 2 < nstage) {
           commit(S0, it_c, 0);
           adv_c();
         }
+        FI_TWS(2, s + 1);
         fi_lds_barrier();
+        FI_TWS(3, s + 1);
       }
     } else {
       // team g owns the stages of parity g: while stage s is consumed, team (s & 1) issues stage s+2 and the other team
@@ -1679,7 +1697,9 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
     int sgrp = a.gimages > 0 ? it.n / a.gimages : 0, sct = it.ct;
     stats_clear();
     load_bias(sct);
+    int tstage = 0;
     auto consume = [&](int buf) __attribute__((always_inline)) {
+      FI_TWS(0, tstage);
       if (ch == 0) {
 #pragma unroll
         for (int m = 0; m < MF; ++m)
@@ -1689,6 +1709,7 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
 #if !(FI_WS_DEBUG & 1)
       mma(buf);
 #endif
+      FI_TWS(1, tstage);
       if (++ch == nchunk) {
         ch = 0;
         const int grp = a.gimages > 0 ? it.n / a.gimages : 0;
@@ -1708,10 +1729,16 @@ __global__ __launch_bounds__(PW == 44 ? 1024 : (4 + PW) * 64, 1) void conv_fwd_w
     fi_lds_barrier();                                            // stage 0 is in buffer 0
     for (int s = 0; s < nstage; s += 2) {
       consume(0);
+      FI_TWS(2, tstage);
       fi_lds_barrier();
+      FI_TWS(3, tstage);
+      ++tstage;
       if (s + 1 >= nstage) break;
       consume(1);
+      FI_TWS(2, tstage);
       fi_lds_barrier();
+      FI_TWS(3, tstage);
+      ++tstage;
     }
     stats_flush(sgrp, sct);
   }
