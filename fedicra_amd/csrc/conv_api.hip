@@ -571,12 +571,12 @@ static int plan_wgrad(const FiConv* d, WgradPlan* p, int depth = 0) {
     p->chunks = fi_cdiv(d->H, p->rpw);
     p->sb_rows = d->N * p->strips * p->chunks;
   }
-  // channel-rich 3x3 layers on 64 ... 256-wide maps: the same streaming with 64 x 64 (64 x 32 / 32 x 64) channel tiles.  Workgroups
+  // channel-rich 3x3 layers on 32 ... 256-wide maps (32-wide: one K step a row, still 7-12 % ahead of the quadrant tiles): the same streaming with 64 x 64 (64 x 32 / 32 x 64) channel tiles.  Workgroups
   // = items x channel tiles; every ITEM costs one |dw| slice of workspace traffic, so the run length follows the tile count
   // (at most FI_WGRAD_ROWS64_WGS workgroups in all, a run of at least 8 rows)
   if (wgrad_rows64_on() && depth == 0 && p->quad && !p->rows && d->dtype != FI_F32 && d->ksize == 3 && cout % 32 == 0 && cin % 32 == 0 &&
-      (cout % 64 == 0 || cin % 64 == 0) && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->W % 32 == 0 && d->W >= 64 &&
-      (d->W <= 128 || d->W % 128 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (1L << 15)) {
+      (cout % 64 == 0 || cin % 64 == 0) && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->W % 32 == 0 && d->W >= 32 &&
+      (d->W <= 128 || d->W % 128 == 0) && d->H >= 8 && (long)d->N * d->H * d->W >= (d->W < 64 ? (1L << 13) : (1L << 15))) {
     static const long wgs_env = env_long("FI_WGRAD_ROWS64_WGS", 512), tile_env = env_long("FI_WGRAD_ROWS64_TILE", 0);
     // tile (gradient x input side, 16-channel blocks): 32 x 64 wherever the input side allows it, else 64 x 32 -- 216 / 228 registers,
     // two workgroups per CU.  The 64 x 64 tile (348 registers: ONE wave per SIMD, nothing hides its LDS latency) measured level on

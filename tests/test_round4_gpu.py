@@ -259,12 +259,12 @@ def test_trained_dice_of_five_seeds_lies_inside_the_references_own_spread(golden
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(12, 64, 64, 128, 0, 128), (8, 64, 64, 128, 128, 128), (3, 128, 128, 64, 64, 64), (2, 128, 128, 64, 0, 64),
                                    (2, 256, 256, 32, 32, 32), (2, 128, 128, 32, 0, 64), (1, 250, 256, 64, 0, 64), (8, 72, 64, 64, 0, 128),
-                                   (6, 64, 96, 24, 40, 64), (8, 64, 64, 256, 0, 256)])
+                                   (6, 64, 96, 24, 40, 64), (8, 64, 64, 256, 0, 256), (12, 32, 32, 128, 0, 256), (9, 40, 32, 128, 128, 64)])
 def test_row_streaming_channel_rich_wgrad_against_fp64_and_the_tile_kernels(shape, dtype, monkeypatch):
     """conv_wgrad_rows64_kernel (csrc/wgrad_rows.h: 64 x 64 / 32 x 64 / 64 x 32 channel tiles of a run of image rows, every wave its
     own channel blocks) against an fp64 convolution backward of the same rounded operands and the quadrant tile kernel it
     replaces (fi_wgrad_tuning(0)): several tiles a side, a second source that splits a channel tile, two strips per row, ragged
-    runs, 96-wide rows; weight and bias gradients."""
+    runs, 96-wide rows, 32-wide rows (one K step a row; round 6); weight and bias gradients."""
     import torch.nn.functional as F
     from fedicra_amd import _lib as L
     N, H, W, c0, c1, cout = shape
