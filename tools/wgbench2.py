@@ -55,4 +55,5 @@ def main():
           f"ROWS64_WGS={os.environ.get('FI_WGRAD_ROWS64_WGS', '-')} TILE={os.environ.get('FI_WGRAD_ROWS64_TILE', '-')})")
 
 
-main()
+if __name__ == "__main__":
+    main()
