@@ -250,7 +250,7 @@ class _Conv3d(Function):
             y = torch.empty((N, D, H, W, cout), dtype=torch.float32, device=dev)
             L.conv3d_point_fwd(x0c, _w_point(weight), bias, y)
         elif _first_ok(dt, ydt, kd, ksize, x0c, x1c, cout):
-            # the network's first convolution, 1 -> 16 channels: a vector-ALU stencil that streams the output once
+            # the network's first convolution, 1 -> 16 channels: one pass on the matrix pipe that streams the output once
             # (csrc/conv3d_first.hip) instead of three read-modify-write passes of a K = 27 (padded to 32) implicit GEMM
             y = torch.empty((N, D, H, W, cout), dtype=dt, device=dev)
             L.conv3d_first_fwd(x0c, _w27(weight), bias, y, stats)

@@ -487,8 +487,9 @@ int fi_bn_act_bwd_apply_batched(const FiBnAct* d, int nbatch, long tensor_stride
                                 const float* invstd, const double* sums, int training, void* dy, void* stream);
 
 /* The first convolution of the 3D U-Net, Conv3d(1 -> 16, 3x3x3, pad 1) (/root/reference/code/networks/unet_3D.py:38,
- * networks/utils.py:99-123), as a vector-ALU stencil that streams the output once (round 5; the implicit-GEMM forms pad the
- * 27-long contraction and make three read-modify-write passes).  16-bit storage (FI_BF16 / FI_F16), x [N][D][H][W] (one channel),
+ * networks/utils.py:99-123), as ONE pass that streams the output once (the implicit-GEMM forms pad the 27-long contraction and make
+ * three read-modify-write passes): on the matrix pipe with the taps (forward) / the voxels (filter gradient) as the contraction,
+ * the fp32 filter split into three exact 16-bit parts (round 6; round 5's vector-ALU stencil gave the same results 2 x slower).  16-bit storage (FI_BF16 / FI_F16), x [N][D][H][W] (one channel),
  * w fp32 [16][27] with the taps in (kd, kh, kw) order, y / dy [N][D][H][W][16].
  * fwd: y = conv + bias, rounded to the storage type; stats (or NULL): fp64 [N][FI_STATS_SLOTS][16][2] (stats_stride doubles per
  *   sample), per-sample sum / sum of squares of the values AS STORED, added to one slot per workgroup (InstanceNorm3d's input).
